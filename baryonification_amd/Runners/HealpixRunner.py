@@ -1,0 +1,104 @@
+"""
+HEALPix-shell runners: drop-in for BaryonForge/Runners/HealpixRunner.py (`DefaultRunner` :74-221,
+`BaryonifyShell` :223-349, `PaintProfilesShell` :352-447).  Same constructor (positional order and
+attribute names, as SplitJoinParallel re-instantiates runners positionally -- Parallelize.py:237-271),
+same `process()` return value (float64 map of shape (Npix,)) and the same exceptions.
+
+`process()` does no per-halo work in Python: the catalog, the shell and the model's raw table go
+through the C ABI (include/bfgx.h) to the HIP kernels in csrc/.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..utils.cosmology import MassDef
+from ..utils.Tabulate import ParamTabulatedProfile
+from ._model import build_model
+
+__all__ = ['DefaultRunner', 'BaryonifyShell', 'PaintProfilesShell']
+
+
+class DefaultRunner(object):
+
+    def __init__(self, HaloLightConeCatalog, LightconeShell, epsilon_max, model, use_ellipticity=False,
+                 mass_def=MassDef(200, 'critical'), verbose=True):
+        self.HaloLightConeCatalog = HaloLightConeCatalog
+        self.LightconeShell = LightconeShell
+        self.cosmo = HaloLightConeCatalog.cosmology
+        self.model = model
+        self.epsilon_max = epsilon_max
+        self.mass_def = mass_def
+        self.verbose = verbose
+        self.use_ellipticity = use_ellipticity
+        # engine knobs (not in the reference): plain attributes so the runner stays picklable
+        self.device = 0
+        self.acc_f64 = None            # None -> per-runner default
+        self.last_stats = None
+        if use_ellipticity:
+            raise NotImplementedError("You have set use_ellipticity = True, but this not yet implemented for HealpixRunner")
+
+    def build_Rmat(self, A, ref):
+        A /= np.linalg.norm(A)
+        ref /= np.linalg.norm(ref)
+        ang = np.arccos(np.dot(A, ref))
+        return np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+
+    def coord_array(self, *args):
+        return np.vstack([a.flatten() for a in args]).T
+
+    # -- shared plumbing -----------------------------------------------------------------------
+    def _check_keys(self, keys):
+        if len(keys) > 0:                                             # HealpixRunner.py:284-287, :409-412
+            txt = (f"You asked to use {keys} properties in Baryonification. You must pass a ParamTabulatedProfile"
+                   f"as the model. You have passed {type(self.model)} instead")
+            ok = isinstance(self.model, ParamTabulatedProfile) or type(self.model).__name__ == 'ParamTabulatedProfile'
+            assert ok, txt
+
+    def _catalog(self, keys):
+        cat = self.HaloLightConeCatalog.cat
+        return _lib.make_catalog_host(cat['M'], cat['z'], cat['ra'], cat['dec'], [cat[k] for k in keys])
+
+
+class BaryonifyShell(DefaultRunner):
+    """Displaces the mass of a HEALPix shell around every halo (map must be a MASS map: pixels equal
+    to 0 are treated as empty, HealpixRunner.py:231-232, :335)."""
+
+    def process(self):
+        keys = vars(self.model).get('p_keys', [])
+        self._check_keys(keys)
+        model, p_keys, keep = build_model(self, 'displacement')
+        cat, cols = self._catalog(p_keys)
+        orig_map = _lib.f8(self.LightconeShell.map)
+        nside = int(self.LightconeShell.NSIDE)
+        new_map = np.empty(orig_map.size, dtype=np.float64)
+        opts = _lib.bfgx_opts(int(self.device), int(bool(self.acc_f64)), 1, 1)
+        stats = _lib.bfgx_stats()
+        rc = _lib.load().bfgx_baryonify_shell(C.byref(cat), C.byref(model), nside, orig_map.ctypes.data,
+                                              new_map.ctypes.data, C.byref(opts), C.byref(stats))
+        _lib.check(rc)
+        self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+        del keep, cols
+        return new_map
+
+
+class PaintProfilesShell(DefaultRunner):
+    """Paints a tabulated projected profile around every halo into an empty map."""
+
+    def process(self):
+        keys = vars(self.model).get('p_keys', []) if self.model is not None else []
+        self._check_keys(keys)
+        assert self.model is not None, "You must provide a model"     # HealpixRunner.py:415
+        model, p_keys, keep = build_model(self, 'projected')
+        cat, cols = self._catalog(p_keys)
+        nside = int(self.LightconeShell.NSIDE)
+        new_map = np.empty(self.LightconeShell.map.size, dtype=np.float64)
+        acc64 = 1 if self.acc_f64 is None else int(bool(self.acc_f64))
+        opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0)
+        stats = _lib.bfgx_stats()
+        rc = _lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data,
+                                          C.byref(opts), C.byref(stats))
+        _lib.check(rc)
+        self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+        del keep, cols
+        return new_map

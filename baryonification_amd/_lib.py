@@ -1,0 +1,181 @@
+"""
+ctypes binding of libbfgx.so (C ABI declared in include/bfgx.h).
+
+The shared library is the product: if it is missing this module raises ImportError loudly --
+there is NO Python/CPU fallback for the hot path.  Build it with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C baryonification_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+BFGX_MAX_EXTRA = 2
+BFGX_MAX_DIM = 3 + BFGX_MAX_EXTRA
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbfgx.so')
+
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS = 0, -1, -2, -3, -4, -5
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class bfgx_cosmo(C.Structure):
+    _fields_ = [('Omega_m', C.c_double), ('Omega_b', C.c_double), ('h', C.c_double), ('sigma8', C.c_double),
+                ('n_s', C.c_double), ('w0', C.c_double), ('T_CMB', C.c_double), ('Neff', C.c_double)]
+
+
+class bfgx_massdef(C.Structure):
+    _fields_ = [('Delta', C.c_double), ('rho_type', C.c_int32), ('_pad', C.c_int32)]
+
+
+class bfgx_table(C.Structure):
+    _fields_ = [('ndim', C.c_int32), ('n', C.c_int32 * BFGX_MAX_DIM), ('axis', C.c_void_p * BFGX_MAX_DIM),
+                ('values', C.c_void_p), ('rdelta_sampling', C.c_int32), ('log_values', C.c_int32),
+                ('eps_model', C.c_double)]
+
+
+class bfgx_catalog(C.Structure):
+    _fields_ = [('n', C.c_int64), ('M', C.c_void_p), ('z', C.c_void_p), ('ra', C.c_void_p), ('dec', C.c_void_p),
+                ('extra', C.c_void_p * BFGX_MAX_EXTRA)]
+
+
+class bfgx_model(C.Structure):
+    _fields_ = [('table', bfgx_table), ('cosmo_runner', bfgx_cosmo), ('massdef_runner', bfgx_massdef),
+                ('cosmo_model', bfgx_cosmo), ('massdef_model', bfgx_massdef), ('eps_runner', C.c_double)]
+
+
+class bfgx_opts(C.Structure):
+    _fields_ = [('device', C.c_int32), ('acc_offsets_f64', C.c_int32), ('acc_paint_f64', C.c_int32),
+                ('check_mass', C.c_int32)]
+
+
+class bfgx_stats(C.Structure):
+    _fields_ = [('n_pairs', C.c_int64), ('sum_in', C.c_double), ('sum_out', C.c_double),
+                ('ms_h2d', C.c_double), ('ms_kernels', C.c_double), ('ms_d2h', C.c_double)]
+
+
+# every symbol include/bfgx.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    'bfgx_abi_version': (C.c_int, []),
+    'bfgx_last_error': (C.c_char_p, []),
+    'bfgx_device_count': (C.c_int, []),
+    'bfgx_cosmo_E2': (C.c_int, [_P(bfgx_cosmo), C.c_int64, C.c_void_p, C.c_void_p]),
+    'bfgx_cosmo_radius': (C.c_int, [_P(bfgx_cosmo), _P(bfgx_massdef), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_cosmo_angular_diameter_distance': (C.c_int, [_P(bfgx_cosmo), C.c_int64, C.c_void_p, C.c_void_p]),
+    'bfgx_cosmo_da_spline': (C.c_int, [_P(bfgx_cosmo), C.c_void_p, C.c_void_p]),
+    'bfgx_cosmo_da_eval': (C.c_int, [_P(bfgx_cosmo), C.c_int64, C.c_void_p, C.c_void_p]),
+    'bfgx_baryonify_shell': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_void_p, C.c_void_p,
+                                       _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_paint_shell': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_void_p,
+                                   _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_plan_create': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, _P(bfgx_model), _P(C.c_void_p)]),
+    'bfgx_plan_destroy': (None, [C.c_void_p]),
+    'bfgx_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
+    'bfgx_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
+    'bfgx_count_pairs_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int, C.c_void_p, _P(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbfgx.so once; raise ImportError (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "baryonification_amd: %s is missing. The HIP extension IS the product (no CPU fallback). "
+                "Build it with `make -C %s` (hipcc --offload-arch=gfx950)." % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)        # AttributeError here = ABI drift between header and library
+            fn.restype = res
+            fn.argtypes = args
+        if L.bfgx_abi_version() != 1:
+            raise ImportError("libbfgx.so ABI version %d != 1" % L.bfgx_abi_version())
+        _lib = L
+    return _lib
+
+
+class BfgxError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Map a bfgx_status to the exception the reference would raise on the same condition."""
+    if rc == OK:
+        return
+    msg = load().bfgx_last_error().decode('utf-8', 'replace')
+    if rc == ERR_MASS:
+        raise AssertionError(msg)                 # HealpixRunner.py:346
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ERR_NO_DEVICE:
+        raise BfgxError("bfgx: " + msg)
+    raise BfgxError("bfgx (status %d): %s" % (rc, msg))
+
+
+def f8(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def make_cosmo(d, T_CMB=-1.0, Neff=-1.0):
+    """bfgx_cosmo from the 6-key cosmology dict of io.py:79-85 (extra keys T_CMB / Neff honoured)."""
+    return bfgx_cosmo(float(d['Omega_m']), float(d['Omega_b']), float(d['h']),
+                      float(d.get('sigma8', np.nan) if d.get('sigma8') is not None else np.nan),
+                      float(d.get('n_s', np.nan) if d.get('n_s') is not None else np.nan),
+                      float(d.get('w0', -1.0)),
+                      float(d.get('T_CMB', T_CMB)), float(d.get('Neff', Neff)))
+
+
+def make_massdef(Delta=200.0, rho_type='critical'):
+    if rho_type not in ('critical', 'matter'):
+        raise NotImplementedError("mass definition rho_type %r" % (rho_type,))
+    if isinstance(Delta, str):
+        raise NotImplementedError("mass definition Delta=%r (numeric overdensities only)" % (Delta,))
+    return bfgx_massdef(float(Delta), 0 if rho_type == 'critical' else 1, 0)
+
+
+def make_table(axes, values, rdelta_sampling=False, log_values=False, eps_model=20.0):
+    """Returns (bfgx_table, keepalive) -- keepalive holds the numpy buffers the struct points into."""
+    axes = [f8(a) for a in axes]
+    values = f8(values)
+    if len(axes) > BFGX_MAX_DIM:
+        raise NotImplementedError("at most %d extra table parameters are supported" % BFGX_MAX_EXTRA)
+    if values.shape != tuple(a.size for a in axes):
+        raise ValueError("table values shape %r does not match axes %r" % (values.shape, [a.size for a in axes]))
+    t = bfgx_table()
+    t.ndim = len(axes)
+    for i, a in enumerate(axes):
+        t.n[i] = a.size
+        t.axis[i] = a.ctypes.data
+    t.values = values.ctypes.data
+    t.rdelta_sampling = int(bool(rdelta_sampling))
+    t.log_values = int(bool(log_values))
+    t.eps_model = float(eps_model)
+    return t, (axes, values)
+
+
+def make_catalog_host(M, z, ra, dec, extra=()):
+    cols = [f8(M), f8(z), f8(ra), f8(dec)] + [f8(e) for e in extra]
+    c = bfgx_catalog()
+    c.n = cols[0].size
+    c.M, c.z, c.ra, c.dec = (cols[i].ctypes.data for i in range(4))
+    for k, e in enumerate(cols[4:]):
+        c.extra[k] = e.ctypes.data
+    return c, cols
+
+
+def make_catalog_dev(n, M_ptr, z_ptr, ra_ptr, dec_ptr, extra_ptrs=()):
+    c = bfgx_catalog()
+    c.n = int(n)
+    c.M, c.z, c.ra, c.dec = int(M_ptr), int(z_ptr), int(ra_ptr), int(dec_ptr)
+    for k, e in enumerate(extra_ptrs):
+        c.extra[k] = int(e)
+    return c

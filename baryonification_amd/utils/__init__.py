@@ -1,0 +1,3 @@
+from .io import *
+from .cosmology import *
+from .Tabulate import *

@@ -1,0 +1,147 @@
+/*
+ * bfgx.h -- C ABI of libbfgx.so, the MI355X (gfx950) engine behind
+ * baryonification_amd.Runners.{BaryonifyShell,PaintProfilesShell}.process().
+ *
+ * The reference (BaryonForge, pure Python) has no FFI layer; its de-facto operator
+ * interface for this path is the runner/model protocol.  Each entry point below
+ * names the reference code it replaces (paths relative to the reference root):
+ *
+ *   bfgx_baryonify_shell   <- BaryonForge/Runners/HealpixRunner.py:240-349  BaryonifyShell.process
+ *   bfgx_paint_shell       <- BaryonForge/Runners/HealpixRunner.py:366-447  PaintProfilesShell.process
+ *   bfgx_offsets_device    <- HealpixRunner.py:291-331 (halo loop) + BaryonCorrection.py:324-390 (_readout)
+ *   bfgx_regrid_device     <- HealpixRunner.py:333-346 + regrid_pixels_hpix :13-67
+ *   bfgx_paint_device      <- HealpixRunner.py:418-445 + utils/Tabulate.py:246-294, 569-621 (_readout)
+ *   bfgx_cosmo_*           <- the pyccl calls on the path: HealpixRunner.py:268-280, :296 and
+ *                             BaryonCorrection.py:370 (ccl.Cosmology background, angular_diameter_distance,
+ *                             MassDef.get_radius)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative bfgx_status, with a thread-local message in bfgx_last_error().  "_host"
+ * pointers are caller-owned host memory (numpy); "_dev" pointers are device memory on the
+ * plan's device (e.g. a torch tensor's data_ptr()).  Nothing is retained after return
+ * except inside an explicit bfgx_plan.  All calls are blocking w.r.t. the host unless noted
+ * ("_device" entry points only enqueue on the plan's stream).
+ */
+#ifndef BFGX_H
+#define BFGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFGX_ABI_VERSION 1
+#define BFGX_MAX_EXTRA 2          /* extra (per-halo parameter) table axes, model.p_keys */
+#define BFGX_MAX_DIM (3 + BFGX_MAX_EXTRA)
+
+typedef enum bfgx_status {
+    BFGX_OK = 0,
+    BFGX_ERR_INVALID = -1,        /* bad argument (ValueError on the Python side) */
+    BFGX_ERR_HIP = -2,            /* HIP runtime error (RuntimeError) */
+    BFGX_ERR_NO_DEVICE = -3,      /* no GPU visible (RuntimeError; there is NO CPU fallback) */
+    BFGX_ERR_UNSUPPORTED = -4,    /* NotImplementedError */
+    BFGX_ERR_MASS = -5            /* mass-conservation check failed (AssertionError, HealpixRunner.py:344-346) */
+} bfgx_status;
+
+/* cosmology dict of io.py:79-85 plus the pyccl-2.x defaults the reference inherits */
+typedef struct bfgx_cosmo {
+    double Omega_m, Omega_b, h, sigma8, n_s, w0;
+    double T_CMB;                 /* <= 0 -> 2.725 K  */
+    double Neff;                  /* <  0 -> 3.046    */
+} bfgx_cosmo;
+
+/* ccl.halos.massdef.MassDef(Delta, rho_type) */
+typedef struct bfgx_massdef {
+    double  Delta;                /* e.g. 200 */
+    int32_t rho_type;             /* 0 = 'critical', 1 = 'matter' */
+    int32_t _pad;
+} bfgx_massdef;
+
+/* a tabulated model: raw_input_* of Baryonification2D/3D (BaryonCorrection.py:309-313) or of
+ * TabulatedProfile / ParamTabulatedProfile (utils/Tabulate.py:231-235, 553-558) */
+typedef struct bfgx_table {
+    int32_t ndim;                         /* 3 + number of extra axes */
+    int32_t n[BFGX_MAX_DIM];              /* points per axis */
+    const double *axis[BFGX_MAX_DIM];     /* host: ln(1+z), ln M, ln r | ln(r/R_Delta), extra params */
+    const double *values;                 /* host, C-order [n0][n1][n2]...; displacement [comoving Mpc],
+                                             or ln(projected profile * a) when log_values = 1 */
+    int32_t rdelta_sampling;              /* BaryonCorrection.py:374-379 */
+    int32_t log_values;                   /* 1: read-out returns exp(interp) (Tabulate.py:285-286) */
+    double  eps_model;                    /* model.epsilon_max (BaryonCorrection.py:381); unused for paint */
+} bfgx_table;
+
+/* HaloLightConeCatalog.cat columns (io.py:58-60): M [Msun], z, ra/dec [deg] */
+typedef struct bfgx_catalog {
+    int64_t n;
+    const double *M, *z, *ra, *dec;
+    const double *extra[BFGX_MAX_EXTRA];  /* cat[p_keys[k]], in table-axis order; NULL if unused */
+} bfgx_catalog;
+
+typedef struct bfgx_model {
+    bfgx_table   table;
+    bfgx_cosmo   cosmo_runner;            /* catalog.cosmology -> R_j, D_j (HealpixRunner.py:268-297) */
+    bfgx_massdef massdef_runner;          /* runner mass_def (HealpixRunner.py:150) */
+    bfgx_cosmo   cosmo_model;             /* model.cosmo -> R in _readout (BaryonCorrection.py:370) */
+    bfgx_massdef massdef_model;           /* model.mass_def */
+    double       eps_runner;              /* runner epsilon_max (HealpixRunner.py:305) */
+} bfgx_model;
+
+typedef struct bfgx_opts {
+    int32_t device;                       /* HIP device ordinal */
+    int32_t acc_offsets_f64;              /* pix_offsets accumulator: 0 = f32 atomics (default), 1 = f64 */
+    int32_t acc_paint_f64;                /* painted-map accumulator: 0 = f32, 1 = f64 (default for host API) */
+    int32_t check_mass;                   /* 1: enforce np.isclose(sum(new), sum(old)) like the reference */
+} bfgx_opts;
+
+typedef struct bfgx_stats {
+    int64_t n_pairs;                      /* (halo, pixel) pairs visited */
+    double  sum_in, sum_out;              /* map sums (baryonify only) */
+    double  ms_h2d, ms_kernels, ms_d2h;   /* host-API phase timings */
+} bfgx_stats;
+
+typedef struct bfgx_plan bfgx_plan;       /* opaque: device, stream, resident model + workspace */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int         bfgx_abi_version(void);
+const char *bfgx_last_error(void);
+int         bfgx_device_count(void);      /* 0 when no GPU is visible */
+
+/* ---- host-side background cosmology (pure CPU, double) ---------------------------------- */
+int bfgx_cosmo_E2(const bfgx_cosmo *c, int64_t n, const double *a, double *out);
+int bfgx_cosmo_radius(const bfgx_cosmo *c, const bfgx_massdef *md, int64_t n,
+                      const double *M, const double *a, double *out_phys_mpc);
+int bfgx_cosmo_angular_diameter_distance(const bfgx_cosmo *c, int64_t n, const double *z, double *out_mpc);
+/* D_a = CubicSpline(linspace(0,30,1000), D_A) of HealpixRunner.py:279-280 (not-a-knot):
+ * knots[1000], coef[999][4] = {c3,c2,c1,c0} of ((c3 t + c2) t + c1) t + c0, t = z - knots[i] */
+int bfgx_cosmo_da_spline(const bfgx_cosmo *c, double *knots, double *coef);
+int bfgx_cosmo_da_eval(const bfgx_cosmo *c, int64_t n, const double *z, double *out_mpc);
+
+/* ---- one-shot host API (numpy in, numpy out; copies H2D/D2H itself) --------------------- */
+int bfgx_baryonify_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside,
+                         const double *map_in_host, double *map_out_host,
+                         const bfgx_opts *opts, bfgx_stats *stats);
+int bfgx_paint_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside,
+                     double *map_out_host, const bfgx_opts *opts, bfgx_stats *stats);
+
+/* ---- resident API (inputs already in HBM; enqueue-only on `stream`) --------------------- */
+int  bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_halos,
+                      const bfgx_model *model, bfgx_plan **out);
+void bfgx_plan_destroy(bfgx_plan *p);
+/* K0 + K1: pix_offsets[npix][3] += per-halo unit-vector offsets; acc is f32 or f64 (acc_f64) */
+int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offsets_dev, int acc_f64);
+/* K2: map_out[npix] (f64, must be zeroed by the caller) += bilinear regrid of displaced pixels;
+ * sums_dev (optional, double[2], zeroed by caller) receives {sum(map_in), sum(map_out)} */
+int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
+                        double *map_out_dev, double *sums_dev);
+/* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */
+int  bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *map_out_dev, int acc_f64);
+/* pair census (same enumeration as K1/K3, no scatter): counts_dev int64[n] or NULL; fallback4 = 1
+ * counts the <4-pixel fallback of BaryonifyShell (HealpixRunner.py:309-310). Blocking. */
+int  bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int fallback4,
+                             int64_t *counts_dev, int64_t *total_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFGX_H */
