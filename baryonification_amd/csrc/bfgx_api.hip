@@ -70,16 +70,37 @@ int validate_table(const bfgx_table &t)
 struct bfgx_plan {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
     int64_t nside = 0, max_halos = 0;
     Hpx hpx;
     DevModel model;
     std::vector<void *> owned;     // device allocations freed with the plan
     HaloRec *recs = nullptr;
     int64_t *total_dev = nullptr;
+    // optional per-kernel HIP-event timing (bfgx_plan_timing_*)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[BFGX_NUM_KERNELS];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
 };
 
 namespace {
+
+// brackets one kernel launch with a pair of events on the plan's stream when timing is enabled
+struct KernelTimer {
+    bfgx_plan *p; int kind; std::pair<hipEvent_t, hipEvent_t> e{nullptr, nullptr};
+    KernelTimer(bfgx_plan *p_, int kind_) : p(p_), kind(kind_)
+    {
+        if (!p->timing) return;
+        if (!p->ev_free.empty()) { e = p->ev_free.back(); p->ev_free.pop_back(); }
+        else { (void)hipEventCreate(&e.first); (void)hipEventCreate(&e.second); }
+        (void)hipEventRecord(e.first, p->stream);
+    }
+    ~KernelTimer()
+    {
+        if (!p->timing) return;
+        (void)hipEventRecord(e.second, p->stream);
+        p->ev[kind].push_back(e);
+    }
+};
 
 static int plan_upload(bfgx_plan *p, const void *host, size_t bytes, const void **dev_out)
 {
@@ -104,6 +125,7 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c)
 {
     if (c->n == 0) return BFGX_OK;
     const unsigned grid = (unsigned)((c->n + 255) / 256);
+    KernelTimer kt(p, BFGX_K_PREP);
     hipLaunchKernelGGL(halo_prep_kernel, dim3(grid), dim3(256), 0, p->stream,
                        p->model, p->hpx, c->n, c->M, c->z, c->ra, c->dec, p->recs);
     HIP_TRY(hipGetLastError());
@@ -115,6 +137,7 @@ static int launch_scatter(bfgx_plan *p, int64_t n, ACC *out, int64_t *counts, in
 {
     if (n == 0) return BFGX_OK;
     const unsigned grid = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     hipLaunchKernelGGL((halo_scatter_kernel<MODE, ACC>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, p->stream,
                        p->model, p->hpx, n, (const HaloRec *)p->recs, out, counts, fallback4);
     HIP_TRY(hipGetLastError());
@@ -208,15 +231,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
     p->nside = nside;
     p->max_halos = max_halos;
     p->hpx = make_hpx(nside);
-    if (hip_stream) {
-        p->stream = (hipStream_t)hip_stream;
-    } else {
-        if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete p;
-            return fail(BFGX_ERR_HIP, "hipStreamCreate failed");
-        }
-        p->own_stream = true;
-    }
+    // hip_stream == NULL means the legacy default stream (what torch's default stream is), so that the
+    // plan's kernels stay ordered with the caller's own work; the plan never creates a private stream.
+    p->stream = (hipStream_t)hip_stream;
     auto bail = [&](int rc) { bfgx_plan_destroy(p); return rc; };
 
     const bfgx_table &t = model->table;
@@ -280,13 +297,42 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
     return BFGX_OK;
 }
 
+int bfgx_plan_timing_enable(bfgx_plan *p, int on)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    p->timing = on != 0;
+    return BFGX_OK;
+}
+
+int bfgx_plan_timing_read(bfgx_plan *p, double *ms_sum, int64_t *launches)
+{
+    if (!p || !ms_sum || !launches) return fail(BFGX_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int k = 0; k < BFGX_NUM_KERNELS; ++k) {
+        double tot = 0.0;
+        for (auto &e : p->ev[k]) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+            tot += ms;
+            p->ev_free.push_back(e);
+        }
+        ms_sum[k] = tot;
+        launches[k] = (int64_t)p->ev[k].size();
+        p->ev[k].clear();
+    }
+    return BFGX_OK;
+}
+
 void bfgx_plan_destroy(bfgx_plan *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamSynchronize(p->stream);
+    for (int k = 0; k < BFGX_NUM_KERNELS; ++k)
+        for (auto &e : p->ev[k]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : p->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *d : p->owned) (void)hipFree(d);
-    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
 
@@ -318,14 +364,18 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
     if (!p || !map_in_dev || !offsets_dev || !map_out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(p->device));
     const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
+    {
+    KernelTimer kt(p, BFGX_K_REGRID);
     if (acc_f64)
         hipLaunchKernelGGL(regrid_kernel<double>, dim3(grid), dim3(256), 0, p->stream, p->hpx, map_in_dev,
                            (const double *)offsets_dev, map_out_dev);
     else
         hipLaunchKernelGGL(regrid_kernel<float>, dim3(grid), dim3(256), 0, p->stream, p->hpx, map_in_dev,
                            (const float *)offsets_dev, map_out_dev);
+    }
     HIP_TRY(hipGetLastError());
     if (sums_dev) {
+        KernelTimer kt(p, BFGX_K_SUM);
         hipLaunchKernelGGL(sum2_kernel, dim3(1024), dim3(256), 0, p->stream, p->hpx.npix, map_in_dev,
                            (const double *)map_out_dev, sums_dev);
         HIP_TRY(hipGetLastError());

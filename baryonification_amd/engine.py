@@ -1,0 +1,78 @@
+"""
+Resident (inputs-already-in-HBM) front-end of the C ABI: a thin object around `bfgx_plan`.
+Pointers are plain integers (e.g. `tensor.data_ptr()`), the stream a raw hipStream_t handle
+(e.g. `torch.cuda.current_stream().cuda_stream`); this module does not import torch.
+
+Used by bench.py and by the multi-GPU driver (parallel.py); the drop-in runners use the one-shot
+host entry points instead.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class ShellPlan(object):
+
+    def __init__(self, model, keepalive, nside, max_halos, device=0, stream=0):
+        self._keep = keepalive
+        self.nside = int(nside)
+        self.npix = 12 * self.nside * self.nside
+        self.max_halos = int(max_halos)
+        h = C.c_void_p()
+        _lib.check(_lib.load().bfgx_plan_create(int(device), C.c_void_p(int(stream) or None), self.nside,
+                                               self.max_halos, C.byref(model), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            _lib.load().bfgx_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def offsets(self, cat_dev, offsets_ptr, acc_f64=False):
+        """K0 + K1 (HealpixRunner.py:291-331): offsets[npix][3] += ..."""
+        _lib.check(_lib.load().bfgx_offsets_device(self._h, C.byref(cat_dev), C.c_void_p(int(offsets_ptr)), int(acc_f64)))
+
+    def regrid(self, map_in_ptr, offsets_ptr, map_out_ptr, sums_ptr=0, acc_f64=False):
+        """K2 (HealpixRunner.py:333-346): map_out[npix] (zeroed) += regrid; sums[2] optional"""
+        _lib.check(_lib.load().bfgx_regrid_device(self._h, C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_ptr)),
+                                                 int(acc_f64), C.c_void_p(int(map_out_ptr)),
+                                                 C.c_void_p(int(sums_ptr) or None)))
+
+    def paint(self, cat_dev, map_out_ptr, acc_f64=True):
+        """K0 + K3 (HealpixRunner.py:418-445)"""
+        _lib.check(_lib.load().bfgx_paint_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_out_ptr)), int(acc_f64)))
+
+    def count_pairs(self, cat_dev, fallback4=True, counts_ptr=0):
+        tot = C.c_int64(0)
+        _lib.check(_lib.load().bfgx_count_pairs_device(self._h, C.byref(cat_dev), int(fallback4),
+                                                      C.c_void_p(int(counts_ptr) or None), C.byref(tot)))
+        return int(tot.value)
+
+    def timing_enable(self, on=True):
+        _lib.check(_lib.load().bfgx_plan_timing_enable(self._h, int(on)))
+
+    def timing_read(self):
+        """{kernel kind: (summed ms, launches)} since the last read; synchronises the stream"""
+        ms = np.zeros(len(_lib.KERNEL_KINDS))
+        n = np.zeros(len(_lib.KERNEL_KINDS), dtype=np.int64)
+        _lib.check(_lib.load().bfgx_plan_timing_read(self._h, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_lib.KERNEL_KINDS)}
+
+
+def model_from_tables(axes, values, cosmo, eps_runner, eps_model=None, rdelta_sampling=False, log_values=False,
+                      cosmo_model=None, massdef=(200.0, 'critical'), massdef_model=None):
+    """bfgx_model from raw arrays: axes = [ln(1+z), ln M, ln r], values C-order."""
+    table, keep = _lib.make_table(axes, values, rdelta_sampling, log_values,
+                                  eps_model if eps_model is not None else eps_runner)
+    m = _lib.bfgx_model()
+    m.table = table
+    m.cosmo_runner = _lib.make_cosmo(cosmo)
+    m.cosmo_model = _lib.make_cosmo(cosmo_model if cosmo_model is not None else cosmo)
+    m.massdef_runner = _lib.make_massdef(*massdef)
+    m.massdef_model = _lib.make_massdef(*(massdef_model if massdef_model is not None else massdef))
+    m.eps_runner = float(eps_runner)
+    return m, keep

@@ -100,6 +100,10 @@ typedef struct bfgx_stats {
     double  ms_h2d, ms_kernels, ms_d2h;   /* host-API phase timings */
 } bfgx_stats;
 
+/* kernel kinds reported by bfgx_plan_timing_read */
+enum { BFGX_K_PREP = 0, BFGX_K_OFFSETS = 1, BFGX_K_REGRID = 2, BFGX_K_PAINT = 3, BFGX_K_SUM = 4, BFGX_K_COUNT = 5,
+       BFGX_NUM_KERNELS = 6 };
+
 typedef struct bfgx_plan bfgx_plan;       /* opaque: device, stream, resident model + workspace */
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -124,7 +128,8 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat_host, const bfgx_model *model, 
 int bfgx_paint_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside,
                      double *map_out_host, const bfgx_opts *opts, bfgx_stats *stats);
 
-/* ---- resident API (inputs already in HBM; enqueue-only on `stream`) --------------------- */
+/* ---- resident API (inputs already in HBM; enqueue-only on `hip_stream`) ------------------
+ * hip_stream is a hipStream_t; NULL = the legacy default stream (torch's default stream). */
 int  bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_halos,
                       const bfgx_model *model, bfgx_plan **out);
 void bfgx_plan_destroy(bfgx_plan *p);
@@ -136,6 +141,12 @@ int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offs
                         double *map_out_dev, double *sums_dev);
 /* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */
 int  bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *map_out_dev, int acc_f64);
+/* optional per-kernel timing with HIP events recorded on the plan's stream around every launch.
+ * bfgx_plan_timing_read synchronises the stream, returns summed milliseconds and launch counts per
+ * kernel kind (arrays of BFGX_NUM_KERNELS) since the previous read, and resets the counters. */
+int  bfgx_plan_timing_enable(bfgx_plan *p, int on);
+int  bfgx_plan_timing_read(bfgx_plan *p, double *ms_sum, int64_t *launches);
+
 /* pair census (same enumeration as K1/K3, no scatter): counts_dev int64[n] or NULL; fallback4 = 1
  * counts the <4-pixel fallback of BaryonifyShell (HealpixRunner.py:309-310). Blocking. */
 int  bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int fallback4,
