@@ -1,3 +1,4 @@
 from .io import *
 from .cosmology import *
 from .Tabulate import *
+from .Parallelize import *

@@ -1,0 +1,69 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/bfgx.h declares; the ctypes
+binding covers exactly that set.  No compute entry point is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from baryonification_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(REPO, 'include', 'bfgx.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(bfgx_[A-Za-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = header_functions()
+    assert len(names) >= 15
+    L = _lib.load()
+    for n in names:
+        assert hasattr(L, n), "libbfgx.so does not export %s" % n
+    assert sorted(_lib.SYMBOLS) == names, "ctypes binding and header disagree"
+
+
+def test_abi_version_and_device_count_callable_without_gpu():
+    L = _lib.load()
+    assert L.bfgx_abi_version() == 1
+    assert L.bfgx_device_count() >= 0
+
+
+def test_struct_sizes_match_header_layout():
+    import ctypes as C
+    assert C.sizeof(_lib.bfgx_cosmo) == 64
+    assert C.sizeof(_lib.bfgx_massdef) == 16
+    assert C.sizeof(_lib.bfgx_table) == 4 + 4 * 5 + 8 * 5 + 8 + 4 + 4 + 8
+    assert C.sizeof(_lib.bfgx_catalog) == 8 + 4 * 8 + 2 * 8
+    assert C.sizeof(_lib.bfgx_opts) == 16
+
+
+def test_compute_fails_loudly_without_gpu():
+    """no CPU fallback: with no device the plan cannot be created"""
+    L = _lib.load()
+    if L.bfgx_device_count() > 0:
+        pytest.skip("GPU present")
+    import ctypes as C
+    from baryonification_amd import engine, synthetic as syn
+    z, M, r = np.geomspace(0.1, 0.2, 3), np.geomspace(1e13, 1e14, 3), np.geomspace(1e-2, 10, 8)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], np.zeros((3, 3, 8)), syn.COSMO, 10.0)
+    with pytest.raises(_lib.BfgxError, match="no HIP device"):
+        engine.ShellPlan(model, keep, 16, 10)
+
+
+def test_invalid_arguments_map_to_python_exceptions():
+    from baryonification_amd import engine, synthetic as syn
+    z, M, r = np.geomspace(0.1, 0.2, 3), np.geomspace(1e13, 1e14, 3), np.geomspace(1e-2, 10, 8)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    bad_axes = [axes[0][::-1].copy(), axes[1], axes[2]]
+    model, keep = engine.model_from_tables(bad_axes, np.zeros((3, 3, 8)), syn.COSMO, 10.0)
+    with pytest.raises(ValueError, match="ascending"):
+        engine.ShellPlan(model, keep, 16, 10)
+    model, keep = engine.model_from_tables(axes, np.zeros((3, 3, 8)), syn.COSMO, 10.0)
+    with pytest.raises(ValueError, match="nside"):
+        engine.ShellPlan(model, keep, 0, 10)
+    with pytest.raises(ValueError):
+        _lib.make_table(axes, np.zeros((3, 3, 7)))

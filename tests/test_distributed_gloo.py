@@ -1,0 +1,78 @@
+"""N>1 path on CPU: two gloo ranks run the product's sharding + collective logic
+(baryonification_amd.utils.Parallelize.distributed_process) with the CPU oracle injected as the per-shard
+compute; the result must equal the single-process answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from baryonification_amd.utils.Parallelize import distributed_process, shard_slices, shuffled_order
+from helpers import load_golden, oracle_run, product_runner
+
+
+def _oracle_compute(runner, kind, cols, device):
+    from oracle import oracle as O
+    g = runner._golden
+    axes = [np.log(1 + g['tab_z']), np.log(g['tab_M']), np.log(g['tab_r'])]
+    bg_r, bg_m = O.Background.from_dict(g['cosmo_runner']), O.Background.from_dict(g['cosmo_model'])
+    if kind == 'baryonify':
+        tab = O.Table(axes, g['tab_values'], g['rdelta'], g['eps_model'])
+        acc = O.baryonify_offsets(g['nside'], cols, tab, g['eps_runner'], bg_r, bg_m).reshape(-1)
+    else:
+        with np.errstate(divide='ignore'):
+            tab = O.Table(axes, np.log(g['tab_values']))
+        acc = O.paint_shell(g['nside'], cols, tab, g['eps_runner'], bg_r)
+    return torch.from_numpy(acc), None
+
+
+def _oracle_regrid(runner, ctx, acc, device):
+    from oracle import oracle as O
+    g = runner._golden
+    return O.regrid(g['nside'], g['map_in'], acc.numpy().reshape(-1, 3))
+
+
+def _worker(rank, world, port, name, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        runner = product_runner(g)
+        runner._golden = g
+        kind = 'baryonify' if g['kind'] == 'baryonify' else 'paint'
+        out = distributed_process(runner, kind, seed=42, device=rank, compute=_oracle_compute, regrid=_oracle_regrid)
+        if rank == 0:
+            np.save(out_path, out)
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_slices_cover_catalog_like_reference():
+    for n, w in ((10, 3), (1000, 8), (7, 8), (0, 2), (16, 4)):
+        sl = shard_slices(n, w)
+        idx = np.concatenate([np.arange(n)[s] for s in sl]) if n else np.zeros(0, dtype=int)
+        assert np.array_equal(idx, np.arange(n)) and len(sl) == w
+        per = int(np.ceil(n / w)) if n else 0
+        assert all((s.stop - s.start) <= per for s in sl)          # Parallelize.py:253
+    o = shuffled_order(100, 42)
+    assert np.array_equal(np.sort(o), np.arange(100))
+    assert np.array_equal(o, np.random.default_rng(42).choice(100, size=100, replace=False))
+
+
+@pytest.mark.parametrize('name', ['lowz_baryonify', 'lowz_paint'])
+def test_two_rank_gloo_equals_single_process(tmp_path, name):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / 'out.npy')
+    mp.spawn(_worker, args=(2, port, name, out_path), nprocs=2, join=True)
+    out = np.load(out_path)
+    ref = oracle_run(load_golden(name))
+    # summation order differs (shuffle + two partial sums): float64 round-off only
+    assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()

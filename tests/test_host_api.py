@@ -1,0 +1,106 @@
+"""Host logic of the drop-in layer (no GPU): containers, runner constructor contract, model protocol,
+pickling -- mirrored from BaryonForge/utils/io.py and Runners/HealpixRunner.py:149-165."""
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+import baryonification_amd as bfg
+from baryonification_amd import synthetic as syn
+from baryonification_amd.Runners._model import build_model
+from helpers import load_golden, product_runner
+
+
+def test_package_surface_matches_reference_names():
+    for name in ('BaryonifyShell', 'PaintProfilesShell', 'DefaultRunner'):
+        assert hasattr(bfg.Runners, name) and hasattr(bfg, name)
+    for name in ('HaloLightConeCatalog', 'LightconeShell', 'TabulatedProfile', 'ParamTabulatedProfile',
+                 'SplitJoinParallel', 'SimpleParallel'):
+        assert hasattr(bfg.utils, name)
+    assert hasattr(bfg.Profiles, 'Baryonification2D')
+
+
+def test_catalog_fields_pole_clip_and_slicing():
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        cat = bfg.utils.HaloLightConeCatalog(ra=np.array([1., 2., 3.]), dec=np.array([90, -90, 10]), M=np.ones(3) * 1e14,
+                                             z=np.array([.1, .2, .3]), cosmo=syn.COSMO, cdelta=np.array([4., 5., 6.]))
+        assert any('poles' in str(x.message) for x in w)
+    assert cat.cat.dtype.names == ('M', 'z', 'ra', 'dec', 'cdelta')
+    assert cat.cat['dec'][0] == 90 - 1e-8 and cat.cat['dec'][1] == -90 + 1e-8       # io.py:65-68
+    sub = cat[1:]
+    assert sub.cat.size == 2 and sub.cat['cdelta'][0] == 5. and sub.cosmology is syn.COSMO
+    with pytest.raises(ValueError):
+        bfg.utils.HaloLightConeCatalog(ra=[1.], dec=[2.], M=[1e14], z=[.1], cosmo={'Omega_m': .3})
+
+
+def test_shell_nside_and_errors():
+    sh = bfg.utils.LightconeShell(map=np.zeros(12 * 16 * 16), cosmo=syn.COSMO)
+    assert sh.NSIDE == 16 and sh.data is sh.map
+    with pytest.raises(ValueError):
+        bfg.utils.LightconeShell(cosmo=syn.COSMO)
+    with pytest.raises(ValueError):
+        bfg.utils.LightconeShell(map=np.zeros(100), cosmo=syn.COSMO)
+    with pytest.raises(ValueError):
+        bfg.utils.LightconeShell(map=np.zeros(12), cosmo={'h': .7})
+
+
+def test_runner_contract():
+    g = load_golden('lowz_baryonify')
+    r = product_runner(g)
+    for attr in ('HaloLightConeCatalog', 'LightconeShell', 'cosmo', 'model', 'mass_def', 'epsilon_max', 'use_ellipticity', 'verbose'):
+        assert hasattr(r, attr)                                   # Parallelize.py:237-243 reads these
+    assert r.cosmo is r.HaloLightConeCatalog.cosmology
+    # SplitJoinParallel re-instantiates positionally (Parallelize.py:271)
+    r2 = type(r)(r.HaloLightConeCatalog, r.LightconeShell, r.epsilon_max, r.model, r.use_ellipticity, r.mass_def, verbose=False)
+    assert r2.epsilon_max == r.epsilon_max
+    with pytest.raises(NotImplementedError):
+        bfg.Runners.BaryonifyShell(r.HaloLightConeCatalog, r.LightconeShell, 10, r.model, use_ellipticity=True)
+    pickle.loads(pickle.dumps(r))                                 # joblib/loky requirement
+
+
+def test_model_protocol_errors():
+    g = load_golden('lowz_baryonify')
+    r = product_runner(g)
+    r.model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO))
+    with pytest.raises(NameError):                                # BaryonCorrection.py:425-426
+        r.process()
+    with pytest.raises(NameError):
+        r.model.displacement(1.0, 1e14, 0.9)
+    p = product_runner(load_golden('lowz_paint'))
+    p.model = None
+    with pytest.raises(AssertionError):                           # HealpixRunner.py:415
+        p.process()
+    # property keys demand a ParamTabulatedProfile (HealpixRunner.py:284-287)
+    r = product_runner(g)
+    r.model.p_keys = ['cdelta']
+    with pytest.raises(AssertionError):
+        r.process()
+
+
+def test_build_model_struct_contents():
+    g = load_golden('rdelta_baryonify')
+    r = product_runner(g)
+    m, p_keys, keep = build_model(r, 'displacement')
+    assert p_keys == [] and m.table.ndim == 3 and m.table.rdelta_sampling == 1 and m.table.log_values == 0
+    assert [m.table.n[i] for i in range(3)] == [g['tab_z'].size, g['tab_M'].size, g['tab_r'].size]
+    assert m.eps_runner == g['eps_runner'] and m.table.eps_model == g['eps_model']
+    assert m.cosmo_runner.Omega_m == g['cosmo_runner']['Omega_m'] and m.cosmo_model.Omega_m == g['cosmo_model']['Omega_m']
+    assert np.allclose(keep[0][0], np.log(1 + g['tab_z']))
+
+
+def test_host_readouts_match_oracle_rgi():
+    """model.displacement / profile.projected (host convenience read-outs) follow the reference semantics"""
+    from oracle import oracle as O
+    g = load_golden('lowz_baryonify')
+    r = product_runner(g)
+    tab = O.Table([np.log(1 + g['tab_z']), np.log(g['tab_M']), np.log(g['tab_r'])], g['tab_values'])
+    a, M = 1 / 1.03, 3e14
+    rr = np.geomspace(5e-4, 50, 40)
+    d = r.model.displacement(rr, M, a)
+    R = O.Background.from_dict(g['cosmo_model']).get_radius(M, a) / a
+    exp = np.array([tab.eval([np.log(1 / a), np.log(M), np.log(x)]) if x < g['eps_model'] * R else 0.0 for x in rr])
+    assert np.array_equal(np.isnan(d), np.isnan(exp)) and np.isnan(d).any()
+    assert np.nanmax(np.abs(d - exp)) < 1e-15
+    assert np.ndim(r.model.displacement(1.0, M, a)) == 0
