@@ -34,6 +34,7 @@ class DefaultRunner(object):
         # engine knobs (not in the reference): plain attributes so the runner stays picklable
         self.device = 0
         self.acc_f64 = None            # None -> per-runner default
+        self.algo = 1                  # 1 = LDS tiles, 0 = per-halo global atomics
         self.last_stats = None
         if use_ellipticity:
             raise NotImplementedError("You have set use_ellipticity = True, but this not yet implemented for HealpixRunner")
@@ -72,7 +73,7 @@ class BaryonifyShell(DefaultRunner):
         orig_map = _lib.f8(self.LightconeShell.map)
         nside = int(self.LightconeShell.NSIDE)
         new_map = np.empty(orig_map.size, dtype=np.float64)
-        opts = _lib.bfgx_opts(int(self.device), int(bool(self.acc_f64)), 1, 1)
+        opts = _lib.bfgx_opts(int(self.device), int(bool(self.acc_f64)), 1, 1, int(self.algo), 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_baryonify_shell(C.byref(cat), C.byref(model), nside, orig_map.ctypes.data,
                                               new_map.ctypes.data, C.byref(opts), C.byref(stats))
@@ -94,7 +95,7 @@ class PaintProfilesShell(DefaultRunner):
         nside = int(self.LightconeShell.NSIDE)
         new_map = np.empty(self.LightconeShell.map.size, dtype=np.float64)
         acc64 = 1 if self.acc_f64 is None else int(bool(self.acc_f64))
-        opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0)
+        opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0, int(self.algo), 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data,
                                           C.byref(opts), C.byref(stats))

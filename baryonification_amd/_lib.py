@@ -12,7 +12,7 @@ import numpy as np
 
 BFGX_MAX_EXTRA = 2
 BFGX_MAX_DIM = 3 + BFGX_MAX_EXTRA
-KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count')
+KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbfgx.so')
@@ -49,7 +49,7 @@ class bfgx_model(C.Structure):
 
 class bfgx_opts(C.Structure):
     _fields_ = [('device', C.c_int32), ('acc_offsets_f64', C.c_int32), ('acc_paint_f64', C.c_int32),
-                ('check_mass', C.c_int32)]
+                ('check_mass', C.c_int32), ('algo', C.c_int32), ('_pad', C.c_int32)]
 
 
 class bfgx_stats(C.Structure):
@@ -77,6 +77,8 @@ SYMBOLS = {
     'bfgx_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
+    'bfgx_plan_set_algo': (C.c_int, [C.c_void_p, C.c_int]),
+    'bfgx_plan_status': (C.c_int, [C.c_void_p]),
     'bfgx_plan_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_timing_read': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_count_pairs_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int, C.c_void_p, _P(C.c_int64)]),

@@ -8,6 +8,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -75,7 +78,13 @@ struct bfgx_plan {
     DevModel model;
     std::vector<void *> owned;     // device allocations freed with the plan
     HaloRec *recs = nullptr;
-    int64_t *total_dev = nullptr;
+    // tile-owned accumulation (algo 1): tiling tables + halo -> tile binning workspace
+    int algo = 1;
+    bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
+    Tiling tiling;
+    int32_t *tile_count = nullptr, *tile_start = nullptr, *tile_cursor = nullptr, *entries = nullptr, *overflow = nullptr;
+    unsigned long long *pair_total = nullptr;
+    int64_t capacity = 0;
     // optional per-kernel HIP-event timing (bfgx_plan_timing_*)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[BFGX_NUM_KERNELS];
@@ -121,27 +130,110 @@ static int check_catalog(const bfgx_plan *p, const bfgx_catalog *c)
     return BFGX_OK;
 }
 
-static int launch_prep(bfgx_plan *p, const bfgx_catalog *c)
+static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool bin)
 {
     if (c->n == 0) return BFGX_OK;
     const unsigned grid = (unsigned)((c->n + 255) / 256);
     KernelTimer kt(p, BFGX_K_PREP);
     hipLaunchKernelGGL(halo_prep_kernel, dim3(grid), dim3(256), 0, p->stream,
-                       p->model, p->hpx, c->n, c->M, c->z, c->ra, c->dec, p->recs);
+                       p->model, p->hpx, c->n, c->M, c->z, c->ra, c->dec, p->recs, fallback4, p->tiling,
+                       bin ? p->tile_count : (int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
 
+// halo -> tile entry lists: zero counters, K0 (counts), scan, fill
+static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4)
+{
+    const size_t nt = (size_t)p->tiling.ntiles;
+    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * (nt + 1), p->stream));
+    HIP_TRY(hipMemsetAsync(p->tile_cursor, 0, sizeof(int32_t) * nt, p->stream));
+    if (int rc = launch_prep(p, c, fallback4, true)) return rc;
+    KernelTimer kt(p, BFGX_K_BIN);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, p->tile_count, p->tile_start);
+    HIP_TRY(hipGetLastError());
+    if (c->n > 0) {
+        const unsigned grid = (unsigned)((c->n + 255) / 256);
+        hipLaunchKernelGGL(tile_fill_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
+                           (const HaloRec *)p->recs, (const int32_t *)p->tile_start, p->tile_cursor, p->entries,
+                           p->capacity, p->overflow);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
+}
+
 template <int MODE, typename ACC>
-static int launch_scatter(bfgx_plan *p, int64_t n, ACC *out, int64_t *counts, int fallback4)
+static int launch_scatter(bfgx_plan *p, int64_t n, ACC *out, int64_t *counts)
 {
     if (n == 0) return BFGX_OK;
     const unsigned grid = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     hipLaunchKernelGGL((halo_scatter_kernel<MODE, ACC>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, p->stream,
-                       p->model, p->hpx, n, (const HaloRec *)p->recs, out, counts, fallback4);
+                       p->model, p->hpx, n, (const HaloRec *)p->recs, out, counts);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
+}
+
+template <int MODE, typename ACC>
+static int launch_tile_scatter(bfgx_plan *p, ACC *out)
+{
+    constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
+    const size_t lds = tile_lds_bytes(p->tiling.BR, p->tiling.W, NCOMP, sizeof(ACC));
+    auto kern = tile_scatter_kernel<MODE, ACC>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
+    hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kWavesPerBlock), lds, p->stream,
+                       p->model, p->hpx, p->tiling, (const HaloRec *)p->recs, (const int32_t *)p->tile_start,
+                       (const int32_t *)p->entries, p->capacity, out, p->pair_total);
+    HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
+// blocking: if the entry list overflowed, grow it to the exact size and redo the fill pass
+static int ensure_entry_capacity(bfgx_plan *p, const bfgx_catalog *c)
+{
+    int32_t ov = 0, total = 0;
+    HIP_TRY(hipMemcpyAsync(&ov, p->overflow, sizeof(ov), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(&total, p->tile_start + p->tiling.ntiles, sizeof(total), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!ov) return BFGX_OK;
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(int32_t) * ((size_t)total + 16)));
+    p->owned.push_back(d);                       // the old list is released with the plan
+    p->entries = (int32_t *)d;
+    p->capacity = (int64_t)total + 16;
+    HIP_TRY(hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream));
+    HIP_TRY(hipMemsetAsync(p->tile_cursor, 0, sizeof(int32_t) * (size_t)p->tiling.ntiles, p->stream));
+    const unsigned grid = (unsigned)((c->n + 255) / 256);
+    hipLaunchKernelGGL(tile_fill_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
+                       (const HaloRec *)p->recs, (const int32_t *)p->tile_start, p->tile_cursor, p->entries,
+                       p->capacity, p->overflow);
+    HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
+// host-side construction of the tiling tables for one nside
+static void build_tiling(int64_t nside, int &BR, int &W, std::vector<int32_t> &tile0, std::vector<int32_t> &nphi,
+                         std::vector<int32_t> &nrmin, std::vector<int32_t> &tband)
+{
+    auto pow2_floor = [](int64_t v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
+    W = std::max(16, std::min(128, pow2_floor(std::max<int64_t>(1, nside / 2))));
+    BR = std::max(4, std::min(32, pow2_floor(std::max<int64_t>(1, nside / 8))));
+    const int64_t nrings = 4 * nside - 1;
+    const int nbands = (int)((nrings + BR - 1) / BR);
+    auto rlen = [&](int64_t ring) { return 4 * (ring < nside ? ring : (ring > 3 * nside ? 4 * nside - ring : nside)); };
+    tile0.assign(nbands + 1, 0); nphi.assign(nbands, 1); nrmin.assign(nbands, 4);
+    for (int b = 0; b < nbands; ++b) {
+        const int64_t i0 = 1 + (int64_t)b * BR, i1 = std::min<int64_t>(i0 + BR, 4 * nside);
+        int64_t lmax = 0, lmin = INT64_MAX;
+        for (int64_t i = i0; i < i1; ++i) { lmax = std::max(lmax, rlen(i)); lmin = std::min(lmin, rlen(i)); }
+        nphi[b] = (int)((lmax + W - 1) / W);
+        nrmin[b] = (int)lmin;
+        tile0[b + 1] = tile0[b] + nphi[b];
+    }
+    tband.resize(tile0[nbands]);
+    for (int b = 0; b < nbands; ++b)
+        for (int t = tile0[b]; t < tile0[b + 1]; ++t) tband[t] = b;
 }
 
 }  // namespace
@@ -265,6 +357,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             if (std::fabs(g[i] - (g[0] + i * step)) > 1e-9 * std::fabs(step)) { uni = false; break; }
         m.tab.r_uniform = uni ? 1 : 0;
         m.tab.r0 = g[0];
+        m.tab.r1 = g[n - 1];
         m.tab.inv_dr = 1.0 / step;
     }
     m.bg_runner = make_background(model->cosmo_runner);
@@ -288,9 +381,38 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(halo records) failed"));
         p->owned.push_back(d);
         p->recs = (HaloRec *)d;
-        if (hipMalloc(&d, sizeof(int64_t)) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMalloc failed"));
-        p->owned.push_back(d);
-        p->total_dev = (int64_t *)d;
+    }
+    {   // tiling tables and halo -> tile binning workspace
+        int BR, W;
+        std::vector<int32_t> tile0, nphi, nrmin, tband;
+        build_tiling(nside, BR, W, tile0, nphi, nrmin, tband);
+        Tiling &T = p->tiling;
+        T.BR = BR; T.W = W; T.nbands = (int)nphi.size(); T.ntiles = (int)tband.size();
+        const void *dv = nullptr;
+        if (int rc = plan_upload(p, tile0.data(), sizeof(int32_t) * tile0.size(), &dv)) return bail(rc);
+        T.band_tile0 = (const int32_t *)dv;
+        if (int rc = plan_upload(p, nphi.data(), sizeof(int32_t) * nphi.size(), &dv)) return bail(rc);
+        T.band_nphi = (const int32_t *)dv;
+        if (int rc = plan_upload(p, nrmin.data(), sizeof(int32_t) * nrmin.size(), &dv)) return bail(rc);
+        T.band_nrmin = (const int32_t *)dv;
+        if (int rc = plan_upload(p, tband.data(), sizeof(int32_t) * tband.size(), &dv)) return bail(rc);
+        T.tile_band = (const int32_t *)dv;
+        if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
+        p->capacity = 8 * max_halos + 4096;
+        auto dalloc = [&](size_t bytes, void **ptr) {
+            if (hipMalloc(ptr, bytes) != hipSuccess) return 1;
+            p->owned.push_back(*ptr);
+            return 0;
+        };
+        void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr;
+        if (dalloc(sizeof(int32_t) * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
+            dalloc(sizeof(int32_t) * (T.ntiles + 1), &d2) || dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) ||
+            dalloc(sizeof(int32_t), &d4) || dalloc(sizeof(unsigned long long), &d5))
+            return bail(fail(BFGX_ERR_HIP, "hipMalloc(binning workspace) failed"));
+        p->tile_count = (int32_t *)d0; p->tile_start = (int32_t *)d1; p->tile_cursor = (int32_t *)d2;
+        p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
+        if (hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream) != hipSuccess)
+            return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
     }
     if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
     *out = p;
@@ -336,15 +458,40 @@ void bfgx_plan_destroy(bfgx_plan *p)
     delete p;
 }
 
+int bfgx_plan_set_algo(bfgx_plan *p, int algo)
+{
+    if (!p || (algo != 0 && algo != 1)) return fail(BFGX_ERR_INVALID, "algo must be 0 (per-halo global atomics) or 1 (LDS tiles)");
+    p->algo = algo;
+    return BFGX_OK;
+}
+
+int bfgx_plan_status(bfgx_plan *p)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    int32_t ov = 0;
+    HIP_TRY(hipMemcpyAsync(&ov, p->overflow, sizeof(ov), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (ov) return fail(BFGX_ERR_INVALID, "halo->tile entry list overflowed its capacity (%lld); results are incomplete",
+                        (long long)p->capacity);
+    return BFGX_OK;
+}
+
 int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev, int acc_f64)
 {
     if (int rc = check_catalog(p, cat)) return rc;
     if (!offsets_dev) return fail(BFGX_ERR_INVALID, "offsets pointer is NULL");
     if (p->model.tab.logv) return fail(BFGX_ERR_INVALID, "displacement read-out needs a table with log_values = 0");
     HIP_TRY(hipSetDevice(p->device));
-    if (int rc = launch_prep(p, cat)) return rc;
-    if (acc_f64) return launch_scatter<MODE_OFFSETS, double>(p, cat->n, (double *)offsets_dev, nullptr, 1);
-    return launch_scatter<MODE_OFFSETS, float>(p, cat->n, (float *)offsets_dev, nullptr, 1);
+    if (p->algo == 1) {      // tile-owned: every element of offsets is overwritten, no zero-fill needed
+        if (int rc = launch_prep_and_bin(p, cat, 1)) return rc;
+        if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
+        if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)offsets_dev);
+        return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)offsets_dev);
+    }
+    if (int rc = launch_prep(p, cat, 1, false)) return rc;
+    if (acc_f64) return launch_scatter<MODE_OFFSETS, double>(p, cat->n, (double *)offsets_dev, nullptr);
+    return launch_scatter<MODE_OFFSETS, float>(p, cat->n, (float *)offsets_dev, nullptr);
 }
 
 int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, int acc_f64)
@@ -353,9 +500,15 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
     if (!map_out_dev) return fail(BFGX_ERR_INVALID, "map pointer is NULL");
     if (!p->model.tab.logv) return fail(BFGX_ERR_INVALID, "profile painting needs a table with log_values = 1");
     HIP_TRY(hipSetDevice(p->device));
-    if (int rc = launch_prep(p, cat)) return rc;
-    if (acc_f64) return launch_scatter<MODE_PAINT, double>(p, cat->n, (double *)map_out_dev, nullptr, 0);
-    return launch_scatter<MODE_PAINT, float>(p, cat->n, (float *)map_out_dev, nullptr, 0);
+    if (p->algo == 1) {
+        if (int rc = launch_prep_and_bin(p, cat, 0)) return rc;
+        if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
+        if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)map_out_dev);
+        return launch_tile_scatter<MODE_PAINT, float>(p, (float *)map_out_dev);
+    }
+    if (int rc = launch_prep(p, cat, 0, false)) return rc;
+    if (acc_f64) return launch_scatter<MODE_PAINT, double>(p, cat->n, (double *)map_out_dev, nullptr);
+    return launch_scatter<MODE_PAINT, float>(p, cat->n, (float *)map_out_dev, nullptr);
 }
 
 int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
@@ -387,14 +540,24 @@ int bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat, int fallback4
 {
     if (int rc = check_catalog(p, cat)) return rc;
     HIP_TRY(hipSetDevice(p->device));
+    if (p->algo == 1 && !counts_dev) {       // census through the tile path (checks the binning is complete)
+        HIP_TRY(hipMemsetAsync(p->pair_total, 0, sizeof(unsigned long long), p->stream));
+        if (int rc = launch_prep_and_bin(p, cat, fallback4)) return rc;
+        if (int rc = launch_tile_scatter<MODE_COUNT, float>(p, (float *)nullptr)) return rc;
+        unsigned long long tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, p->pair_total, sizeof(tot), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (total_host) *total_host = (int64_t)tot;
+        return bfgx_plan_status(p);
+    }
     int64_t *counts = counts_dev;
     void *tmp = nullptr;
     if (!counts) {
         HIP_TRY(hipMalloc(&tmp, sizeof(int64_t) * (size_t)(cat->n > 0 ? cat->n : 1)));
         counts = (int64_t *)tmp;
     }
-    int rc = launch_prep(p, cat);
-    if (!rc) rc = launch_scatter<MODE_COUNT, float>(p, cat->n, (float *)nullptr, counts, fallback4);
+    int rc = launch_prep(p, cat, fallback4, false);
+    if (!rc) rc = launch_scatter<MODE_COUNT, float>(p, cat->n, (float *)nullptr, counts);
     if (!rc && total_host) {
         std::vector<int64_t> h((size_t)cat->n);
         if (hipMemcpyAsync(h.data(), counts, sizeof(int64_t) * (size_t)cat->n, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
@@ -453,10 +616,13 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     bfgx_opts o;
     std::memset(&o, 0, sizeof(o));
     o.check_mass = 1;
+    o.algo = 1;
     if (opts) o = *opts;
     bfgx_plan *p = nullptr;
     if (int rc = bfgx_plan_create(o.device, nullptr, nside, cat->n, model, &p)) return rc;
     struct Guard { bfgx_plan *p; ~Guard() { bfgx_plan_destroy(p); } } guard{p};
+    p->blocking_growth = true;
+    if (o.algo == 0 || o.algo == 1) p->algo = o.algo; else return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
 
     const size_t npix = (size_t)p->hpx.npix;
     const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
@@ -505,10 +671,13 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     bfgx_opts o;
     std::memset(&o, 0, sizeof(o));
     o.acc_paint_f64 = 1;
+    o.algo = 1;
     if (opts) o = *opts;
     bfgx_plan *p = nullptr;
     if (int rc = bfgx_plan_create(o.device, nullptr, nside, cat->n, model, &p)) return rc;
     struct Guard { bfgx_plan *p; ~Guard() { bfgx_plan_destroy(p); } } guard{p};
+    p->blocking_growth = true;
+    if (o.algo == 0 || o.algo == 1) p->algo = o.algo; else return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
 
     const size_t npix = (size_t)p->hpx.npix;
     DevBuf cols[4], d_out;

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "bfgx_cosmo.hpp"
+#include "bfgx_math.hpp"
 
 namespace bfgx {
 
@@ -188,6 +189,59 @@ __device__ inline void get_interpol(const Hpx &h, double theta, double phi, int6
     }
 }
 
+
+// One ring row of a disc (healpix_cxx query_disc_internal, fact = 0): pixels (lo + t) mod nr, t in [0, cnt)
+struct RowSpan {
+    int64_t start, nr;
+    int32_t lo, cnt;
+    bool shifted;
+    double z, sth;
+};
+
+__device__ inline void disc_row(const Hpx &h, int ring, double z0, double xa, double cosr, double phi0,
+                                int irmin, int irmax, RowSpan &s)
+{
+    ring_info_small(h, ring, s.start, s.nr, s.shifted);
+    ring_z_sth(h, ring, s.z, s.sth);
+    s.lo = 0; s.cnt = 0;
+    if (ring < irmin || ring > irmax) { s.cnt = (int)s.nr; return; }     // polar-cap row: whole ring inside
+    const double x = (cosr - s.z * z0) * xa;
+    const double ysq = 1.0 - s.z * s.z - x * x;
+    if (!(ysq > 0.0)) return;
+    const double dphi = atan2(sqrt(ysq), x);
+    if (!(dphi > 0.0)) return;
+    const double sh = s.shifted ? 0.5 : 0.0;
+    const double fnr = (double)s.nr * kInvTwoPi;
+    const int64_t ip_lo = (int64_t)floor(fnr * (phi0 - dphi) - sh) + 1;
+    const int64_t ip_hi = (int64_t)floor(fnr * (phi0 + dphi) - sh);
+    int64_t c = ip_hi - ip_lo + 1;
+    c = c < 0 ? 0 : (c > s.nr ? s.nr : c);
+    s.cnt = (int)c;
+    int64_t l = ip_lo;                       // ip_lo is in (-nr, 2 nr): fold without a 64-bit modulo
+    if (l < 0) l += s.nr;
+    if (l >= s.nr) l -= s.nr;
+    if (l < 0) l += s.nr;
+    s.lo = (int)l;
+}
+
+// pixels-only variant of get_interpol: the 4 neighbours as (ring, index in ring)
+__device__ inline void interp_neighbours(const Hpx &h, double theta, double phi, int32_t ring[4], int32_t k[4])
+{
+    int64_t pix[4]; double w[4];
+    get_interpol<false>(h, theta, phi, pix, w);
+    const double z = cos(theta);
+    const int64_t ir1 = ring_above(h, z), ir2 = ir1 + 1;
+    for (int q = 0; q < 4; ++q) {
+        int64_t rg = (q < 2) ? ir1 : ir2;
+        if (rg < 1) rg = 1;                                  // north-pole case: polar pixels 0..3 (ring 1)
+        if (rg > 4 * h.nside - 1) rg = 4 * h.nside - 1;      // south-pole case: last ring
+        int64_t st, nr; bool sh;
+        ring_info_small(h, rg, st, nr, sh);
+        ring[q] = (int32_t)rg;
+        k[q] = (int32_t)(pix[q] - st);
+    }
+}
+
 // ---------------------------------------------------------------------------------- device-side model
 struct DevTable {
     int32_t ndim;
@@ -197,7 +251,7 @@ struct DevTable {
     int32_t rdelta, logv;
     double eps_model;
     int32_t r_uniform;                    // ln r axis is uniform: index guess = (x - r0) * inv_dr
-    double r0, inv_dr;
+    double r0, inv_dr, r1;                // first / last node of the ln r axis
 };
 
 struct DevModel {
@@ -215,12 +269,16 @@ struct alignas(16) HaloRec {
     double cph0, sph0;                    // cos/sin(phi0)
     double cosr;                          // cos(disc radius)
     double theta, phi;                    // lonlat2thetaphi(ra, dec), for the <4-pixel fallback
-    double D, a, rcut, lnRmod;
+    double D, a, inv_a, rcut, lnoff;      // lnoff = ln(1/a) [- ln R_model when Rdelta_sampling]
     double w[kNC];                        // (z,M) corner weights in scipy corner order
     int32_t rowoff[kNC];                  // element offset of each corner's radial row in values[]
     int32_t irmin, irmax, rfirst, rlast;  // phi-tested ring range, full row range (incl. polar caps)
     int32_t oob;                          // 1: (z, M[, params]) outside the table -> NaN read-out
-    int32_t _pad[3];
+    int32_t allphi;                       // disc spans all azimuths (pole inside / touching)
+    int32_t fb;                           // 1: fewer than 4 pixels in the disc -> 4-neighbour fallback (:309-310)
+    int32_t _pad;
+    double flo, fhi;                      // azimuth range of the disc as fractions of 2 pi (unwrapped)
+    int32_t fb_ring[4], fb_k[4];          // the 4 fallback pixels as (ring, index in ring)
 };
 
 __device__ inline double dev_E2(const Background &b, double a)
@@ -249,12 +307,70 @@ __device__ inline int axis_find(const double *g, int n, double x)
     return lo;
 }
 
+// ---------------------------------------------------------------------------------- tiling
+// The sphere is cut into tiles = (band of BR consecutive rings) x (1/nphi of the azimuth).  In ring i
+// with nr pixels, tile j of the ring's band owns k in [ceil(j nr/nphi), ceil((j+1) nr/nphi)), i.e. the
+// pixels with floor(k nphi / nr) == j; at most W pixels wide.  One workgroup owns one tile's accumulators
+// in LDS, so the per-halo scatter needs no global atomics and every output pixel is stored exactly once.
+struct Tiling {
+    int32_t BR, W, nbands, ntiles;
+    const int32_t *band_tile0;            // [nbands + 1] first tile of each band
+    const int32_t *band_nphi;             // [nbands]
+    const int32_t *band_nrmin;            // [nbands] shortest ring of the band
+    const int32_t *tile_band;             // [ntiles]
+};
+
+__device__ inline int tile_ks(int j, int nr, int nphi) { return (int)(((int64_t)j * nr + nphi - 1) / nphi); }
+
+__device__ inline int ring_len(const Hpx &h, int ring)
+{
+    const int64_t n = h.nside;
+    return (int)(4 * (ring < n ? ring : (ring > 3 * n ? 4 * n - ring : n)));
+}
+
+// calls f(tile) once for every tile that may hold pixels of the halo's disc (conservative superset)
+template <typename F>
+__device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const HaloRec &r, F &&f)
+{
+    if (r.fb) {
+        int seen[4], ns = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int b = (r.fb_ring[q] - 1) / T.BR;
+            const int nphi = T.band_nphi[b];
+            const int t = T.band_tile0[b] + (int)(((int64_t)r.fb_k[q] * nphi) / ring_len(h, r.fb_ring[q]));
+            bool dup = false;
+            for (int i = 0; i < ns; ++i) dup |= (seen[i] == t);
+            if (!dup) { seen[ns++] = t; f(t); }
+        }
+        return;
+    }
+    if (r.rlast < r.rfirst) return;
+    const int b0 = (r.rfirst - 1) / T.BR, b1 = (r.rlast - 1) / T.BR;
+    for (int b = b0; b <= b1; ++b) {
+        const int nphi = T.band_nphi[b], t0 = T.band_tile0[b];
+        bool all = r.allphi || nphi == 1;
+        int jlo = 0, jhi = nphi - 1;
+        if (!all) {
+            const double margin = 2.0 * (double)nphi / (double)T.band_nrmin[b] + 1e-6;
+            jlo = (int)floor((double)nphi * r.flo - margin);
+            jhi = (int)floor((double)nphi * r.fhi + margin);
+            if (jhi - jlo + 1 >= nphi) { all = true; jlo = 0; jhi = nphi - 1; }
+        }
+        for (int jj = jlo; jj <= jhi; ++jj) {
+            int j = jj % nphi;
+            if (j < 0) j += nphi;
+            f(t0 + j);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- K0
+// thread per halo.  tile_count != nullptr: also counts the halo into every tile it may touch.
 __global__ void __launch_bounds__(256)
 halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ M, const double *__restrict__ z,
                  const double *__restrict__ ra, const double *__restrict__ dec,
-                 HaloRec *__restrict__ rec)
+                 HaloRec *__restrict__ rec, int fallback4, Tiling T, int32_t *__restrict__ tile_count)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
@@ -290,8 +406,10 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     r.D = D; r.a = a;
 
     const int64_t nl4 = 4 * h.nside;
+    bool pole = false;
     if (radius >= kPi) {
         r.cosr = -1.0; r.irmin = (int32_t)nl4; r.irmax = 0; r.rfirst = 1; r.rlast = (int32_t)(nl4 - 1);
+        pole = true;
     } else {
         r.cosr = cos(radius);
         const double rlat1 = thq - radius;
@@ -302,13 +420,23 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         r.irmin = (int32_t)irmin; r.irmax = (int32_t)irmax;
         r.rfirst = (int32_t)(((rlat1 <= 0) && (irmin > 1)) ? 1 : irmin);
         r.rlast = (int32_t)(((rlat2 >= kPi) && (irmax + 1 < nl4)) ? nl4 - 1 : irmax);
+        pole = (rlat1 <= 0) || (rlat2 >= kPi);
+    }
+    // azimuthal extent of the disc (for tile binning): half-width asin(sin r / sin theta0) when no pole inside
+    {
+        const double sr = sin(fmin(radius, kHalfPi));
+        r.allphi = (pole || radius >= kHalfPi || !(sr < 0.999 * r.s0)) ? 1 : 0;
+        const double dmax = r.allphi ? kPi : asin(sr / r.s0);
+        r.flo = (phq - dmax) * kInvTwoPi;
+        r.fhi = (phq + dmax) * kInvTwoPi;
     }
 
     // model-side radius and table coordinates (BaryonCorrection.py:364-370, Tabulate.py:279-283)
     const double Rmod = dev_radius(m.bg_model, m.md_model, M_j, a) / a;
     r.rcut = m.tab.eps_model * Rmod;
-    r.lnRmod = log(Rmod);
+    r.inv_a = 1.0 / a;
     const double x0 = log(1.0 / a), x1 = log(M_j);
+    r.lnoff = m.tab.rdelta ? (x0 - log(Rmod)) : x0;
     const int iz = axis_find(m.tab.axis[0], m.tab.n[0], x0);
     const int im = axis_find(m.tab.axis[1], m.tab.n[1], x1);
     r.oob = (iz < 0 || im < 0) ? 1 : 0;
@@ -328,79 +456,149 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     } else {
         for (int c = 0; c < kNC; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
     }
-    r._pad[0] = r._pad[1] = r._pad[2] = 0;
+
+    // <4-pixel fallback (HealpixRunner.py:309-310): only discs of a few pixels can qualify -> exact census
+    r.fb = 0; r._pad = 0;
+    for (int q = 0; q < 4; ++q) { r.fb_ring[q] = 0; r.fb_k[q] = 0; }
+    if (fallback4 && (r.rlast - r.rfirst) < 8) {
+        int total = 0;
+        for (int ring = r.rfirst; ring <= r.rlast && total < 4; ++ring) {
+            RowSpan s;
+            disc_row(h, ring, r.z0, r.xa, r.cosr, r.phi0, r.irmin, r.irmax, s);
+            total += s.cnt;
+        }
+        if (total < 4) {
+            r.fb = 1;
+            interp_neighbours(h, theta, phi, r.fb_ring, r.fb_k);
+        }
+    }
     rec[j] = r;
+    if (tile_count) for_each_tile(h, T, r, [&](int t) { atomicAdd(tile_count + t, 1); });
 }
 
-// ---------------------------------------------------------------------------------- K1 / K3
+// exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total
+__global__ void __launch_bounds__(1024)
+tile_scan_kernel(int ntiles, const int32_t *__restrict__ count, int32_t *__restrict__ start)
+{
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (ntiles + 1023) / 1024;
+    const int lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
+    int32_t s = 0;
+    for (int i = lo; i < hi; ++i) s += count[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int32_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+    if (tid == 1023) start[ntiles] = part[1023];
+}
+
+// thread per halo: writes the halo index into the entry list of every tile it may touch
+__global__ void __launch_bounds__(256)
+tile_fill_kernel(Hpx h, Tiling T, int64_t nhalo, const HaloRec *__restrict__ rec, const int32_t *__restrict__ start,
+                 int32_t *__restrict__ cursor, int32_t *__restrict__ entries, int64_t capacity, int32_t *__restrict__ overflow)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nhalo) return;
+    const HaloRec r = rec[j];
+    for_each_tile(h, T, r, [&](int t) {
+        const int64_t pos = (int64_t)start[t] + atomicAdd(cursor + t, 1);
+        if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1;
+    });
+}
+
+// ---------------------------------------------------------------------------------- per-pair math
 template <typename ACC> __device__ inline void atomic_accumulate(ACC *p, double v) { atomicAdd(p, (ACC)v); }
 
 // linear read-out along ln r of the 4 (z,M)-corner rows; NaN outside the axis (scipy RGI semantics)
-__device__ inline double radial_readout(const DevTable &t, const HaloRec &r, double lx)
+__device__ inline double radial_readout(const DevTable &t, const int32_t *rowoff, const double *w, double lx)
 {
-    const double *g = t.axis[2];
     const int n = t.n[2];
-    if (!(lx >= g[0]) || !(lx <= g[n - 1])) return __builtin_nan("");
+    if (!(lx >= t.r0) || !(lx <= t.r1)) return __builtin_nan("");
     int i;
-    if (t.r_uniform) {
-        i = (int)((lx - t.r0) * t.inv_dr);
-        i = max(0, min(i, n - 2));
-        while (i > 0 && lx < g[i]) --i;
-        while (i < n - 2 && lx >= g[i + 1]) ++i;
+    double tr;
+    if (t.r_uniform) {        // uniform ln r axis: O(1) index, fraction from the same affine map
+        const double u = (lx - t.r0) * t.inv_dr;
+        i = min((int)u, n - 2);
+        tr = u - (double)i;
     } else {
+        const double *g = t.axis[2];
         int lo = 0, hi = n - 1;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lx >= g[mid]) lo = mid; else hi = mid; }
         i = lo;
+        tr = (lx - g[i]) / (g[i + 1] - g[i]);
     }
-    const double tr = (lx - g[i]) / (g[i + 1] - g[i]);
+    const double t0 = 1.0 - tr;
     double val = 0.0;
 #pragma unroll
     for (int c = 0; c < kNC; ++c) {
-        const double *row = t.values + r.rowoff[c] + i;
-        val = val + row[0] * (r.w[c] * (1.0 - tr));
-        val = val + row[1] * (r.w[c] * tr);
+        const double *row = t.values + rowoff[c] + i;
+        val = val + row[0] * (w[c] * t0);
+        val = val + row[1] * (w[c] * tr);
     }
     return val;
 }
 
-template <int MODE, typename ACC>
-__device__ inline void process_pair(const DevModel &m, const HaloRec &r, int64_t pix,
-                                    double z, double sth, double phi_pix, ACC *__restrict__ out)
+// halo fields the pair phase needs (a view: scalar registers in the halo-centric kernel, LDS in the tiled one)
+struct PairHalo {
+    double z0, s0, phi0, cph0, sph0, D, a, inv_a, rcut;
+    double lnoff;                         // ln(1/a) [- ln R_model when Rdelta_sampling]: ln r axis coordinate offset
+    double w[kNC];
+    int32_t rowoff[kNC];
+    int32_t oob, hidx;
+};
+
+__device__ inline void load_pair_halo(PairHalo &p, const HaloRec &r, int hidx)
+{
+    p.z0 = r.z0; p.s0 = r.s0; p.phi0 = r.phi0; p.cph0 = r.cph0; p.sph0 = r.sph0;
+    p.D = r.D; p.a = r.a; p.inv_a = r.inv_a; p.rcut = r.rcut; p.lnoff = r.lnoff;
+    for (int c = 0; c < kNC; ++c) { p.w[c] = r.w[c]; p.rowoff[c] = r.rowoff[c]; }
+    p.oob = r.oob; p.hidx = hidx;
+}
+
+// One (halo, pixel) pair.  Returns false when the pair contributes nothing.
+//   MODE_OFFSETS: v[0..2] = nw_vec - vec (HealpixRunner.py:314-328);  MODE_PAINT: v[0] = Paint (:441-442)
+template <int MODE>
+__device__ inline bool pair_value(const DevTable &tab, const PairHalo &r, double z, double sth, double phi_pix, double v[3])
 {
     // pixel unit vector in the frame rotated by -phi0 about the polar axis: halo at (s0, 0, z0)
     double sd, cd;
-    sincos(phi_pix - r.phi0, &sd, &cd);
+    sincos_dphi(phi_pix - r.phi0, sd, cd);
     const double vx = sth * cd, vy = sth * sd, vz = z;
     const double dx = r.D * (vx - r.s0), dy = r.D * vy, dz = r.D * (vz - r.z0);   // :314-316
-    const double r_sep = sqrt(dx * dx + dy * dy + dz * dz);                         // :317
-    const double r_com = r_sep / r.a;                                               // :321
-    const double lx = m.tab.rdelta ? (log(r_com) - r.lnRmod) : log(r_com);
-    double d = r.oob ? __builtin_nan("") : radial_readout(m.tab, r, lx);
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    if (!(r2 > 0.0)) return false;                 // r_sep = 0: diff/r_sep is NaN -> 0 (:322-323); ln 0 -> NaN paint
+    const double inv_r = fast_rsq(r2);
+    const double r_sep = r2 * inv_r;                                                // :317
+    const double r_com = r_sep * r.inv_a;                                           // :321 (r_sep / a)
+    const double lx = __builtin_fma(0.5, fast_log(r2), r.lnoff);                    // ln(r_sep/a) [- ln R when Rdelta]
+    double d = r.oob ? __builtin_nan("") : radial_readout(tab, r.rowoff, r.w, lx);
     if (MODE == MODE_PAINT) {
         const double paint = exp(d);                                                // Tabulate.py:286
-        if (isfinite(paint) && paint != 0.0) atomic_accumulate(out + pix, paint);   // :442, :445
-        return;
+        v[0] = paint;
+        return isfinite(paint) && paint != 0.0;                                     // :442
     }
     if (!(r_com < r.rcut)) d = 0.0;                                                 // BaryonCorrection.py:381-382
-    d *= r.a;                                                                       // :321
-    const double inv_r = 1.0 / r_sep;
-    double ox = d * (dx * inv_r), oy = d * (dy * inv_r), oz = d * (dz * inv_r);     // :322
-    if (!isfinite(ox)) ox = 0.0;                                                    // :323
-    if (!isfinite(oy)) oy = 0.0;
-    if (!isfinite(oz)) oz = 0.0;
-    if (ox == 0.0 && oy == 0.0 && oz == 0.0) return;       // reference adds ~1e-17 rounding noise here
-    const double nx = r.D * vx + ox, ny = r.D * vy + oy, nz = r.D * vz + oz;        // :326
-    const double inv_n = 1.0 / sqrt(nx * nx + ny * ny + nz * nz);                   // :327
-    const double ex = nx * inv_n - vx, ey = ny * inv_n - vy, ez = nz * inv_n - vz;  // :328
-    // rotate back by +phi0
-    const double gx = ex * r.cph0 - ey * r.sph0;
-    const double gy = ex * r.sph0 + ey * r.cph0;
-    ACC *o = out + 3 * pix;
-    atomic_accumulate(o + 0, gx);                                                   // :331
-    atomic_accumulate(o + 1, gy);
-    atomic_accumulate(o + 2, ez);
+    if (!isfinite(d) || d == 0.0) return false;    // non-finite -> 0 (:323); the reference then adds ~1e-17 noise
+    d *= r.a * inv_r;                                                               // :321-322
+    const double ox = d * dx, oy = d * dy, oz = d * dz;
+    const double nx = __builtin_fma(r.D, vx, ox), ny = __builtin_fma(r.D, vy, oy), nz = __builtin_fma(r.D, vz, oz);   // :326
+    const double inv_n = fast_rsq(nx * nx + ny * ny + nz * nz);                     // :327
+    const double ex = __builtin_fma(nx, inv_n, -vx), ey = __builtin_fma(ny, inv_n, -vy);   // :328
+    v[2] = __builtin_fma(nz, inv_n, -vz);
+    v[0] = ex * r.cph0 - ey * r.sph0;                                               // rotate back by +phi0
+    v[1] = ex * r.sph0 + ey * r.cph0;
+    return true;
 }
 
+// ---------------------------------------------------------------------------------- K1 / K3, halo-centric
+// (algo 0: one wave per halo, global float atomics; kept as the simple reference implementation)
 struct RowLds {                      // one wave's 64 ring rows
     int32_t prefix[kWave];           // exclusive prefix of pixel counts
     int32_t nr[kWave];               // pixels in ring
@@ -409,10 +607,20 @@ struct RowLds {                      // one wave's 64 ring rows
     double z[kWave], sth[kWave], shift[kWave];
 };
 
+__device__ inline int wave_scan_incl(int v, int lane)
+{
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) {
+        const int u = __shfl_up(v, s, kWave);
+        if (lane >= s) v += u;
+    }
+    return v;
+}
+
 template <int MODE, typename ACC>
 __global__ void __launch_bounds__(kWave * kWavesPerBlock)
 halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict__ recs,
-                    ACC *__restrict__ out, int64_t *__restrict__ counts, int fallback4)
+                    ACC *__restrict__ out, int64_t *__restrict__ counts)
 {
     __shared__ RowLds lds[kWavesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
@@ -420,83 +628,241 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
     const int64_t j = (int64_t)blockIdx.x * kWavesPerBlock + wid;
     if (j >= nhalo) return;                      // whole wave exits together
     RowLds &L = lds[wid];
-    const HaloRec r = recs[j];
+    const HaloRec &r = recs[j];
+    PairHalo ph;
+    load_pair_halo(ph, r, (int)j);
+    constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
 
     int64_t npairs = 0;
-    for (int rbase = r.rfirst; rbase <= r.rlast; rbase += kWave) {
-        const int ring = rbase + lane;
-        int cnt = 0, lo = 0;
-        int64_t start = 0, nr = 1; bool shifted = false;
-        double z = 0.0, sth = 0.0;
-        if (ring <= r.rlast) {
-            ring_info_small(h, ring, start, nr, shifted);
-            ring_z_sth(h, ring, z, sth);
-            if (ring < r.irmin || ring > r.irmax) {
-                cnt = (int)nr;                   // polar cap rows: whole ring inside the disc
-            } else {
-                const double x = (r.cosr - z * r.z0) * r.xa;
-                const double ysq = 1.0 - z * z - x * x;
-                if (ysq > 0.0) {
-                    const double dphi = atan2(sqrt(ysq), x);
-                    if (dphi > 0.0) {
-                        const double sh = shifted ? 0.5 : 0.0;
-                        const int64_t ip_lo = (int64_t)floor((double)nr * kInvTwoPi * (r.phi0 - dphi) - sh) + 1;
-                        const int64_t ip_hi = (int64_t)floor((double)nr * kInvTwoPi * (r.phi0 + dphi) - sh);
-                        int64_t c = ip_hi - ip_lo + 1;
-                        c = c < 0 ? 0 : (c > nr ? nr : c);
-                        cnt = (int)c;
-                        int64_t l = ip_lo % nr; if (l < 0) l += nr;
-                        lo = (int)l;
+    if (r.fb) {                                                           // HealpixRunner.py:309-310
+        npairs = 4;
+        if (MODE != MODE_COUNT && lane < 4) {
+            int64_t st, nr; bool sh; double z, sth, v[3];
+            ring_info_small(h, r.fb_ring[lane], st, nr, sh);
+            ring_z_sth(h, r.fb_ring[lane], z, sth);
+            const double phi_pix = ((double)r.fb_k[lane] + (sh ? 0.5 : 0.0)) * (kTwoPi / (double)nr);
+            if (pair_value<MODE>(m.tab, ph, z, sth, phi_pix, v)) {
+                ACC *o = out + NCOMP * (st + r.fb_k[lane]);
+                for (int c = 0; c < NCOMP; ++c) atomic_accumulate(o + c, v[c]);
+            }
+        }
+    } else {
+        for (int rbase = r.rfirst; rbase <= r.rlast; rbase += kWave) {
+            const int ring = rbase + lane;
+            RowSpan s;
+            s.cnt = 0; s.lo = 0; s.start = 0; s.nr = 1; s.shifted = false; s.z = 0.0; s.sth = 0.0;
+            if (ring <= r.rlast) disc_row(h, ring, r.z0, r.xa, r.cosr, r.phi0, r.irmin, r.irmax, s);
+            const int incl = wave_scan_incl(s.cnt, lane);
+            const int total = __shfl(incl, kWave - 1, kWave);
+            L.prefix[lane] = incl - s.cnt;
+            L.nr[lane] = (int)s.nr; L.lo[lane] = s.lo; L.start[lane] = s.start;
+            L.z[lane] = s.z; L.sth[lane] = s.sth; L.shift[lane] = s.shifted ? 0.5 : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            npairs += total;
+            if (MODE != MODE_COUNT) {
+                for (int t = lane; t < total; t += kWave) {
+                    int row = 0;                      // largest row with prefix[row] <= t
+#pragma unroll
+                    for (int st = kWave >> 1; st > 0; st >>= 1)
+                        if (L.prefix[row + st] <= t) row += st;
+                    const int nrr = L.nr[row];
+                    int k = L.lo[row] + (t - L.prefix[row]);
+                    if (k >= nrr) k -= nrr;
+                    const double phi_pix = ((double)k + L.shift[row]) * (kTwoPi / (double)nrr);
+                    double v[3];
+                    if (pair_value<MODE>(m.tab, ph, L.z[row], L.sth[row], phi_pix, v)) {
+                        ACC *o = out + NCOMP * (L.start[row] + k);
+                        for (int c = 0; c < NCOMP; ++c) atomic_accumulate(o + c, v[c]);
                     }
                 }
             }
-        }
-        // wave-wide inclusive scan of cnt
-        int incl = cnt;
-#pragma unroll
-        for (int s = 1; s < kWave; s <<= 1) {
-            const int v = __shfl_up(incl, s, kWave);
-            if (lane >= s) incl += v;
-        }
-        const int total = __shfl(incl, kWave - 1, kWave);
-        L.prefix[lane] = incl - cnt;
-        L.nr[lane] = (int)nr; L.lo[lane] = lo; L.start[lane] = start;
-        L.z[lane] = z; L.sth[lane] = sth; L.shift[lane] = shifted ? 0.5 : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): LDS writes visible to the wave
-
-        const bool single_chunk = (rbase == r.rfirst) && (r.rfirst + kWave > r.rlast);
-        if (fallback4 && single_chunk && total < 4) break;      // -> 4-neighbour fallback below
-        npairs += total;
-
-        if (MODE != MODE_COUNT) {
-            for (int t = lane; t < total; t += kWave) {
-                int row = 0;                      // largest row with prefix[row] <= t
-#pragma unroll
-                for (int s = kWave >> 1; s > 0; s >>= 1)
-                    if (L.prefix[row + s] <= t) row += s;
-                const int nrr = L.nr[row];
-                int k = L.lo[row] + (t - L.prefix[row]);
-                if (k >= nrr) k -= nrr;
-                const double phi_pix = ((double)k + L.shift[row]) * (kTwoPi / (double)nrr);
-                process_pair<MODE, ACC>(m, r, L.start[row] + k, L.z[row], L.sth[row], phi_pix, out);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    if (fallback4 && npairs < 4 && (r.rlast - r.rfirst < kWave)) {      // HealpixRunner.py:309-310
-        npairs = 4;
-        if (MODE != MODE_COUNT && lane < 4) {
-            int64_t pix[4]; double wdummy[4];
-            get_interpol<false>(h, r.theta, r.phi, pix, wdummy);
-            const int64_t p = pix[lane];
-            double z, sth, phi_pix;
-            pix2loc(h, p, z, sth, phi_pix);
-            process_pair<MODE, ACC>(m, r, p, z, sth, phi_pix, out);
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (counts && lane == 0) counts[j] = npairs;
+}
+
+// ---------------------------------------------------------------------------------- K1 / K3, tiled
+// (algo 1, default) one workgroup per tile: accumulators live in LDS, entries (halos touching the tile) are
+// taken 16 at a time by each wave: lanes = entries -> lanes = ring rows (clipped to the tile) -> lanes = pairs.
+constexpr int kChunk = 16;
+
+struct RingSlot {                    // ring-phase view of one entry
+    double z0, xa, cosr, phi0;
+    int32_t irmin, irmax, ring_lo, prefix, fb;
+    int32_t fb_ring[4], fb_k[4];
+    int32_t _pad;
+};
+
+struct TileWaveLds {
+    PairHalo pair[kChunk];
+    RingSlot ring[kChunk];
+    int32_t prefix[kWave], firstA[kWave], cntA[kWave], firstB[kWave], nr[kWave], ldsbase[kWave], eslot[kWave];
+    double z[kWave], sth[kWave], shift[kWave];
+};
+
+__host__ __device__ inline size_t tile_lds_bytes(int BR, int W, int ncomp, size_t acc_size)
+{
+    size_t a = (size_t)BR * W * ncomp * acc_size;
+    a = (a + 15) & ~(size_t)15;
+    return a + sizeof(TileWaveLds) * kWavesPerBlock + 16;
+}
+
+template <int MODE, typename ACC>
+__global__ void __launch_bounds__(kWave * kWavesPerBlock)
+tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ recs,
+                    const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
+                    ACC *__restrict__ out, unsigned long long *__restrict__ pair_total)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
+    const int tile = blockIdx.x;
+    const int band = T.tile_band[tile];
+    const int nphi = T.band_nphi[band];
+    const int tj = tile - T.band_tile0[band];
+    const int i0 = 1 + band * T.BR;
+    const int i1 = min(i0 + T.BR, (int)(4 * h.nside));            // exclusive
+    const int acc_n = T.BR * T.W * NCOMP;
+    ACC *acc = reinterpret_cast<ACC *>(smem);
+    size_t acc_bytes = ((size_t)acc_n * sizeof(ACC) + 15) & ~(size_t)15;
+    TileWaveLds *wl = reinterpret_cast<TileWaveLds *>(smem + acc_bytes);
+    int *next_chunk = reinterpret_cast<int *>(wl + kWavesPerBlock);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (MODE != MODE_COUNT)
+        for (int i = tid; i < acc_n; i += kWave * kWavesPerBlock) acc[i] = (ACC)0;
+    if (tid == 0) *next_chunk = 0;
+    __syncthreads();
+
+    const int64_t e0 = tile_start[tile];
+    int64_t e1 = tile_start[tile + 1];
+    if (e1 > capacity) e1 = capacity;
+    const int ne = (int)(e1 > e0 ? e1 - e0 : 0);
+    const int nchunks = (ne + kChunk - 1) / kChunk;
+    TileWaveLds &L = wl[wid];
+    unsigned long long npairs = 0;
+
+    while (true) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(next_chunk, 1);
+        c = __shfl(c, 0, kWave);
+        if (c >= nchunks) break;
+
+        // ---- lanes = entries of this chunk
+        int nrows = 0;
+        if (lane < kChunk && c * kChunk + lane < ne) {
+            const int hidx = entries[e0 + c * kChunk + lane];
+            const HaloRec &r = recs[hidx];
+            RingSlot rs;
+            rs.z0 = r.z0; rs.xa = r.xa; rs.cosr = r.cosr; rs.phi0 = r.phi0;
+            rs.irmin = r.irmin; rs.irmax = r.irmax; rs.fb = r.fb; rs._pad = 0;
+            for (int q = 0; q < 4; ++q) { rs.fb_ring[q] = r.fb_ring[q]; rs.fb_k[q] = r.fb_k[q]; }
+            if (r.fb) { nrows = 4; rs.ring_lo = 0; }
+            else {
+                const int lo = max(r.rfirst, i0), hi = min(r.rlast, i1 - 1);
+                nrows = max(0, hi - lo + 1);
+                rs.ring_lo = lo;
+            }
+            rs.prefix = 0;
+            L.ring[lane] = rs;
+            load_pair_halo(L.pair[lane], r, hidx);
+        }
+        const int incl_e = wave_scan_incl(nrows, lane);
+        const int total_rows = __shfl(incl_e, kWave - 1, kWave);
+        if (lane < kChunk) L.ring[lane].prefix = incl_e - nrows;
+        __builtin_amdgcn_wave_barrier();
+
+        for (int rb = 0; rb < total_rows; rb += kWave) {
+            // ---- lanes = ring rows (clipped to this tile)
+            const int R = rb + lane;
+            int firstA = 0, cntA = 0, firstB = 0, cntB = 0, nr = 1, ldsbase = 0, es = 0;
+            double z = 0.0, sth = 0.0, shift = 0.0;
+            if (R < total_rows) {
+                int e = 0;                                        // largest entry with prefix <= R
+#pragma unroll
+                for (int st = kChunk >> 1; st > 0; st >>= 1)
+                    if (L.ring[e + st].prefix <= R) e += st;
+                es = e;
+                const RingSlot &rs = L.ring[e];
+                const int q = R - rs.prefix;
+                if (rs.fb) {
+                    const int ring = rs.fb_ring[q];
+                    if (ring >= i0 && ring < i1) {
+                        int64_t st, n64; bool shf;
+                        ring_info_small(h, ring, st, n64, shf);
+                        ring_z_sth(h, ring, z, sth);
+                        nr = (int)n64; shift = shf ? 0.5 : 0.0;
+                        const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
+                        if (rs.fb_k[q] >= ks && rs.fb_k[q] < ke) { firstA = rs.fb_k[q]; cntA = 1; }
+                        ldsbase = (ring - i0) * T.W - ks;
+                    }
+                } else {
+                    const int ring = rs.ring_lo + q;
+                    RowSpan s;
+                    disc_row(h, ring, rs.z0, rs.xa, rs.cosr, rs.phi0, rs.irmin, rs.irmax, s);
+                    nr = (int)s.nr; z = s.z; sth = s.sth; shift = s.shifted ? 0.5 : 0.0;
+                    const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
+                    const int endA = min(s.lo + s.cnt, nr);
+                    firstA = max(s.lo, ks);
+                    cntA = max(0, min(endA, ke) - firstA);
+                    const int endB = s.lo + s.cnt - nr;           // > 0 when the row wraps past phi = 2 pi
+                    firstB = ks;                                  // max(0, ks)
+                    cntB = max(0, min(endB, ke) - firstB);
+                    ldsbase = (ring - i0) * T.W - ks;
+                }
+            }
+            const int cnt = cntA + cntB;
+            const int incl = wave_scan_incl(cnt, lane);
+            const int total = __shfl(incl, kWave - 1, kWave);
+            L.prefix[lane] = incl - cnt;
+            L.firstA[lane] = firstA; L.cntA[lane] = cntA; L.firstB[lane] = firstB;
+            L.nr[lane] = nr; L.ldsbase[lane] = ldsbase; L.eslot[lane] = es;
+            L.z[lane] = z; L.sth[lane] = sth; L.shift[lane] = shift;
+            __builtin_amdgcn_wave_barrier();
+            npairs += (unsigned long long)total;
+
+            // ---- lanes = (halo, pixel) pairs
+            if (MODE != MODE_COUNT) {
+                for (int t = lane; t < total; t += kWave) {
+                    int row = 0;
+#pragma unroll
+                    for (int st = kWave >> 1; st > 0; st >>= 1)
+                        if (L.prefix[row + st] <= t) row += st;
+                    const int jj = t - L.prefix[row];
+                    const int ca = L.cntA[row];
+                    const int k = (jj < ca) ? (L.firstA[row] + jj) : (L.firstB[row] + (jj - ca));
+                    const int nrr = L.nr[row];
+                    const double phi_pix = ((double)k + L.shift[row]) * (kTwoPi / (double)nrr);
+                    double v[3];
+                    if (pair_value<MODE>(m.tab, L.pair[L.eslot[row]], L.z[row], L.sth[row], phi_pix, v)) {
+                        ACC *o = acc + NCOMP * (L.ldsbase[row] + k);
+                        for (int cc = 0; cc < NCOMP; ++cc) atomic_accumulate(o + cc, v[cc]);   // ds_add_f32 / f64
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+
+    if (MODE == MODE_COUNT) {
+        if (lane == 0 && npairs) atomicAdd(pair_total, npairs);
+        return;
+    }
+    // ---- flush: every pixel of the tile is stored exactly once (plain, row-contiguous stores)
+    for (int rr = wid; rr < i1 - i0; rr += kWavesPerBlock) {
+        const int ring = i0 + rr;
+        int64_t st, n64; bool shf;
+        ring_info_small(h, ring, st, n64, shf);
+        const int nr = (int)n64;
+        const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
+        const int n = (ke - ks) * NCOMP;
+        ACC *dst = out + NCOMP * (st + ks);
+        const ACC *src = acc + NCOMP * rr * T.W;
+        for (int x = lane; x < n; x += kWave) dst[x] = src[x];
+    }
 }
 
 // ---------------------------------------------------------------------------------- K2

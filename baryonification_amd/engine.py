@@ -27,7 +27,10 @@ class ShellPlan(object):
 
     def close(self):
         if getattr(self, '_h', None):
-            _lib.load().bfgx_plan_destroy(self._h)
+            try:
+                _lib.load().bfgx_plan_destroy(self._h)
+            except Exception:          # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     __del__ = close
@@ -51,6 +54,13 @@ class ShellPlan(object):
         _lib.check(_lib.load().bfgx_count_pairs_device(self._h, C.byref(cat_dev), int(fallback4),
                                                       C.c_void_p(int(counts_ptr) or None), C.byref(tot)))
         return int(tot.value)
+
+    def set_algo(self, algo):
+        """1 = tile-owned LDS accumulators (default), 0 = one wave per halo + global float atomics"""
+        _lib.check(_lib.load().bfgx_plan_set_algo(self._h, int(algo)))
+
+    def status(self):
+        _lib.check(_lib.load().bfgx_plan_status(self._h))
 
     def timing_enable(self, on=True):
         _lib.check(_lib.load().bfgx_plan_timing_enable(self._h, int(on)))

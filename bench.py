@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--nside', type=int, default=1024)
     ap.add_argument('--eps', type=float, default=10.0)
     ap.add_argument('--acc-f64', action='store_true', help='fp64 pix_offsets accumulators instead of fp32')
+    ap.add_argument('--algo', type=int, default=1, help='1 = LDS tiles (default), 0 = per-halo global atomics')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample')
     return ap.parse_args()
@@ -102,10 +103,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     plan = engine.ShellPlan(model, keep, nside, args.halos, device=local_rank, stream=stream)
     cat_dev = _lib.make_catalog_dev(args.halos, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
+    plan.set_algo(args.algo)
     n_pairs = plan.count_pairs(cat_dev, fallback4=True)
+    plan.status()
 
     def step():
-        d_off.zero_(); d_out.zero_(); d_sums.zero_()
+        if args.algo == 0:
+            d_off.zero_()                      # algo 1 stores every element of pix_offsets exactly once
+        d_out.zero_(); d_sums.zero_()
         plan.offsets(cat_dev, d_off.data_ptr(), acc_f64=args.acc_f64)
         if world > 1:
             dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318 counterpart, before the regrid
@@ -143,6 +148,7 @@ def main():
         acc_b = 8 if args.acc_f64 else 4
         alg = {'offsets': n_pairs * 3 * acc_b + args.halos * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8)}
         dom = max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
+        names = {"offsets": "tile_scatter_kernel<OFFSETS>" if args.algo == 1 else "halo_scatter_kernel<OFFSETS>", "regrid": "regrid_kernel"}
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
         out = {
             "metric": "halos/sec for BaryonifyShell NSIDE=%d (1e6-halo synthetic catalog per GPU)" % nside,
@@ -158,8 +164,8 @@ def main():
             "map_pixels_per_s": npix / elapsed * args.steps,
             "kernel_ms": kernels,
             "mass_conserved": bool(np.isclose(sums[1], sums[0])),
-            "roofline": {"kernel": {"offsets": "halo_scatter_kernel<OFFSETS>", "regrid": "regrid_kernel"}[dom],
-                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": names[dom],
+                         "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg[dom],
                          "note": "scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "

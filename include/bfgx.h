@@ -92,6 +92,8 @@ typedef struct bfgx_opts {
     int32_t acc_offsets_f64;              /* pix_offsets accumulator: 0 = f32 atomics (default), 1 = f64 */
     int32_t acc_paint_f64;                /* painted-map accumulator: 0 = f32, 1 = f64 (default for host API) */
     int32_t check_mass;                   /* 1: enforce np.isclose(sum(new), sum(old)) like the reference */
+    int32_t algo;                         /* 1 = LDS tiles (default), 0 = per-halo global atomics */
+    int32_t _pad;
 } bfgx_opts;
 
 typedef struct bfgx_stats {
@@ -102,7 +104,7 @@ typedef struct bfgx_stats {
 
 /* kernel kinds reported by bfgx_plan_timing_read */
 enum { BFGX_K_PREP = 0, BFGX_K_OFFSETS = 1, BFGX_K_REGRID = 2, BFGX_K_PAINT = 3, BFGX_K_SUM = 4, BFGX_K_COUNT = 5,
-       BFGX_NUM_KERNELS = 6 };
+       BFGX_K_BIN = 6, BFGX_NUM_KERNELS = 7 };
 
 typedef struct bfgx_plan bfgx_plan;       /* opaque: device, stream, resident model + workspace */
 
@@ -133,6 +135,12 @@ int bfgx_paint_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int6
 int  bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_halos,
                       const bfgx_model *model, bfgx_plan **out);
 void bfgx_plan_destroy(bfgx_plan *p);
+/* accumulation algorithm of K1/K3: 1 (default) = tile-owned LDS accumulators, plain stores, every output
+ * element written exactly once (no zero-fill needed); 0 = one wave per halo with global float atomics
+ * (output must be zeroed by the caller) */
+int  bfgx_plan_set_algo(bfgx_plan *p, int algo);
+/* blocking health check of the plan's workspace (entry-list capacity); call outside timed regions */
+int  bfgx_plan_status(bfgx_plan *p);
 /* K0 + K1: pix_offsets[npix][3] += per-halo unit-vector offsets; acc is f32 or f64 (acc_f64) */
 int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offsets_dev, int acc_f64);
 /* K2: map_out[npix] (f64, must be zeroed by the caller) += bilinear regrid of displaced pixels;
