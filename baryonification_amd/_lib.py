@@ -15,7 +15,7 @@ BFGX_MAX_DIM = 3 + BFGX_MAX_EXTRA
 KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libbfgx.so')
+LIB_PATH = os.environ.get('BFGX_LIB', os.path.join(_HERE, 'csrc', 'libbfgx.so'))   # BFGX_LIB: ablation builds only
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS = 0, -1, -2, -3, -4, -5
 

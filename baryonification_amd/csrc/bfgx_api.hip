@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -178,7 +179,7 @@ template <int MODE, typename ACC>
 static int launch_tile_scatter(bfgx_plan *p, ACC *out)
 {
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    const size_t lds = tile_lds_bytes(p->tiling.BR, p->tiling.W, NCOMP, sizeof(ACC));
+    const size_t lds = tile_lds_bytes(p->tiling.BR, p->tiling.W, NCOMP);
     auto kern = tile_scatter_kernel<MODE, ACC>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
@@ -217,8 +218,10 @@ static void build_tiling(int64_t nside, int &BR, int &W, std::vector<int32_t> &t
                          std::vector<int32_t> &nrmin, std::vector<int32_t> &tband)
 {
     auto pow2_floor = [](int64_t v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
-    W = std::max(16, std::min(128, pow2_floor(std::max<int64_t>(1, nside / 2))));
+    W = std::max(16, std::min(64, pow2_floor(std::max<int64_t>(1, nside / 2))));
     BR = std::max(4, std::min(32, pow2_floor(std::max<int64_t>(1, nside / 8))));
+    if (const char *e = std::getenv("BFGX_TILE_W")) W = std::max(4, std::min(128, std::atoi(e)));     // tuning knobs
+    if (const char *e = std::getenv("BFGX_TILE_BR")) BR = std::max(1, std::min(64, std::atoi(e)));
     const int64_t nrings = 4 * nside - 1;
     const int nbands = (int)((nrings + BR - 1) / BR);
     auto rlen = [&](int64_t ring) { return 4 * (ring < nside ? ring : (ring > 3 * nside ? 4 * nside - ring : nside)); };
@@ -516,15 +519,25 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
 {
     if (!p || !map_in_dev || !offsets_dev || !map_out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(p->device));
-    const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
     {
     KernelTimer kt(p, BFGX_K_REGRID);
-    if (acc_f64)
-        hipLaunchKernelGGL(regrid_kernel<double>, dim3(grid), dim3(256), 0, p->stream, p->hpx, map_in_dev,
-                           (const double *)offsets_dev, map_out_dev);
-    else
-        hipLaunchKernelGGL(regrid_kernel<float>, dim3(grid), dim3(256), 0, p->stream, p->hpx, map_in_dev,
-                           (const float *)offsets_dev, map_out_dev);
+    if (p->algo == 1) {
+        const size_t lds = regrid_lds_bytes(p->tiling.BR, p->tiling.W);
+        if (acc_f64)
+            hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
+                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev);
+        else
+            hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
+                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev);
+    } else {
+        const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
+        if (acc_f64)
+            hipLaunchKernelGGL(regrid_kernel<double>, dim3(grid), dim3(256), 0, p->stream, p->hpx, map_in_dev,
+                               (const double *)offsets_dev, map_out_dev);
+        else
+            hipLaunchKernelGGL(regrid_kernel<float>, dim3(grid), dim3(256), 0, p->stream, p->hpx, map_in_dev,
+                               (const float *)offsets_dev, map_out_dev);
+    }
     }
     HIP_TRY(hipGetLastError());
     if (sums_dev) {

@@ -17,6 +17,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef BFGX_ABLATE
+#define BFGX_ABLATE 0      // >0: timing-only ablation builds (scripts/ablate.sh); never shipped
+#endif
 #include "bfgx_cosmo.hpp"
 #include "bfgx_math.hpp"
 
@@ -597,6 +600,59 @@ __device__ inline bool pair_value(const DevTable &tab, const PairHalo &r, double
     return true;
 }
 
+// Branch-free (fully predicated) variant for the common case: uniform ln r axis and |dphi| <= 0.5, so that two
+// pairs per lane can be interleaved by the scheduler.  x = azimuth difference already folded to (-pi, pi].
+template <int MODE>
+__device__ inline bool pair_value_fast(const DevTable &tab, const PairHalo &r, double z, double sth, double x, double v[3])
+{
+    double sd, cd;
+    sincos_small(x, sd, cd);
+    const double vx = sth * cd, vy = sth * sd, vz = z;
+    const double dx = r.D * (vx - r.s0), dy = r.D * vy, dz = r.D * (vz - r.z0);   // :314-316
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    bool ok = (r2 > 0.0) && !r.oob;
+    const double r2s = (r2 > 0.0) ? r2 : 1.0;
+    const double inv_r = fast_rsq(r2s);
+    const double r_com = r2s * inv_r * r.inv_a;                                     // :317, :321
+    const double lx = __builtin_fma(0.5, fast_log(r2s), r.lnoff);
+    ok = ok && (lx >= tab.r0) && (lx <= tab.r1);                                    // RGI fill_value = nan
+    const double u = (lx - tab.r0) * tab.inv_dr;
+    const int i = max(0, min((int)u, tab.n[2] - 2));
+    const double tr = u - (double)i, t0 = 1.0 - tr;
+    double d = 0.0;
+#if BFGX_ABLATE == 1      // timing-only build: no table loads
+    d = tr * r.w[0] + t0 * r.w[1] + 1e-3;
+#else
+#pragma unroll
+    for (int c = 0; c < kNC; ++c) {
+        const double *row = tab.values + r.rowoff[c] + i;
+        d = d + row[0] * (r.w[c] * t0);
+        d = d + row[1] * (r.w[c] * tr);
+    }
+#endif
+    if (MODE == MODE_PAINT) {
+        const double paint = exp(d);                                                // Tabulate.py:286
+        v[0] = paint;
+        return ok && isfinite(paint) && paint != 0.0;                               // :442
+    }
+    ok = ok && (r_com < r.rcut) && isfinite(d) && d != 0.0;                         // BaryonCorrection.py:381-382, :323
+    d *= r.a * inv_r;                                                               // :321-322
+    const double ox = d * dx, oy = d * dy, oz = d * dz;
+    const double nx = __builtin_fma(r.D, vx, ox), ny = __builtin_fma(r.D, vy, oy), nz = __builtin_fma(r.D, vz, oz);   // :326
+    const double inv_n = fast_rsq(nx * nx + ny * ny + nz * nz);                     // :327
+    const double ex = __builtin_fma(nx, inv_n, -vx), ey = __builtin_fma(ny, inv_n, -vy);   // :328
+    v[2] = __builtin_fma(nz, inv_n, -vz);
+    v[0] = ex * r.cph0 - ey * r.sph0;
+    v[1] = ex * r.sph0 + ey * r.cph0;
+    return ok;
+}
+
+__device__ inline double fold_dphi(double x)
+{
+    x = (x > kPi) ? x - kTwoPi : x;
+    return (x < -kPi) ? x + kTwoPi : x;
+}
+
 // ---------------------------------------------------------------------------------- K1 / K3, halo-centric
 // (algo 0: one wave per halo, global float atomics; kept as the simple reference implementation)
 struct RowLds {                      // one wave's 64 ring rows
@@ -686,6 +742,7 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
 // (algo 1, default) one workgroup per tile: accumulators live in LDS, entries (halos touching the tile) are
 // taken 16 at a time by each wave: lanes = entries -> lanes = ring rows (clipped to the tile) -> lanes = pairs.
 constexpr int kChunk = 16;
+constexpr int kMaskWords = 130;          // 64 rows x up to 128 pixels = 8192 pairs -> 128 words (+2 spare)
 
 struct RingSlot {                    // ring-phase view of one entry
     double z0, xa, cosr, phi0;
@@ -697,13 +754,15 @@ struct RingSlot {                    // ring-phase view of one entry
 struct TileWaveLds {
     PairHalo pair[kChunk];
     RingSlot ring[kChunk];
+    // rows of the current block, compacted to the non-empty ones
     int32_t prefix[kWave], firstA[kWave], cntA[kWave], firstB[kWave], nr[kWave], ldsbase[kWave], eslot[kWave];
     double z[kWave], sth[kWave], shift[kWave];
+    unsigned long long mask[kMaskWords];  // bit t set <=> pair t is the first pair of a row
 };
 
-__host__ __device__ inline size_t tile_lds_bytes(int BR, int W, int ncomp, size_t acc_size)
+__host__ __device__ inline size_t tile_lds_bytes(int BR, int W, int ncomp)
 {
-    size_t a = (size_t)BR * W * ncomp * acc_size;
+    size_t a = (size_t)BR * W * ncomp * sizeof(double);
     a = (a + 15) & ~(size_t)15;
     return a + sizeof(TileWaveLds) * kWavesPerBlock + 16;
 }
@@ -723,8 +782,10 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
     const int i0 = 1 + band * T.BR;
     const int i1 = min(i0 + T.BR, (int)(4 * h.nside));            // exclusive
     const int acc_n = T.BR * T.W * NCOMP;
-    ACC *acc = reinterpret_cast<ACC *>(smem);
-    size_t acc_bytes = ((size_t)acc_n * sizeof(ACC) + 15) & ~(size_t)15;
+    // LDS accumulators are always fp64: on gfx950 ds_add_f64 runs at ~7 lanes/clk/CU while ds_add_f32 manages
+    // only ~0.3 (scripts/ubench/lds_atomics.hip); ACC is only the type of the global output.
+    double *acc = reinterpret_cast<double *>(smem);
+    size_t acc_bytes = ((size_t)acc_n * sizeof(double) + 15) & ~(size_t)15;
     TileWaveLds *wl = reinterpret_cast<TileWaveLds *>(smem + acc_bytes);
     int *next_chunk = reinterpret_cast<int *>(wl + kWavesPerBlock);
 
@@ -732,7 +793,7 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
     const int lane = tid & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
     if (MODE != MODE_COUNT)
-        for (int i = tid; i < acc_n; i += kWave * kWavesPerBlock) acc[i] = (ACC)0;
+        for (int i = tid; i < acc_n; i += kWave * kWavesPerBlock) acc[i] = 0.0;
     if (tid == 0) *next_chunk = 0;
     __syncthreads();
 
@@ -816,30 +877,80 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
             const int cnt = cntA + cntB;
             const int incl = wave_scan_incl(cnt, lane);
             const int total = __shfl(incl, kWave - 1, kWave);
-            L.prefix[lane] = incl - cnt;
-            L.firstA[lane] = firstA; L.cntA[lane] = cntA; L.firstB[lane] = firstB;
-            L.nr[lane] = nr; L.ldsbase[lane] = ldsbase; L.eslot[lane] = es;
-            L.z[lane] = z; L.sth[lane] = sth; L.shift[lane] = shift;
-            __builtin_amdgcn_wave_barrier();
             npairs += (unsigned long long)total;
+            if (MODE != MODE_COUNT && total > 0) {
+                // compact the non-empty rows and mark each row's first pair in a bit mask
+                const int nwords = (total + kWave - 1) / kWave + 2;
+                for (int wI = lane; wI < nwords; wI += kWave) L.mask[wI] = 0ull;
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long ne = __ballot(cnt > 0);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                if (cnt > 0) {
+                    const int slot = __popcll(ne & lt);
+                    const int pre = incl - cnt;
+                    L.prefix[slot] = pre;
+                    L.firstA[slot] = firstA; L.cntA[slot] = cntA; L.firstB[slot] = firstB;
+                    L.nr[slot] = nr; L.ldsbase[slot] = ldsbase; L.eslot[slot] = es;
+                    L.z[slot] = z; L.sth[slot] = sth; L.shift[slot] = shift;
+                    atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
+                }
+                __builtin_amdgcn_wave_barrier();
 
-            // ---- lanes = (halo, pixel) pairs
-            if (MODE != MODE_COUNT) {
-                for (int t = lane; t < total; t += kWave) {
-                    int row = 0;
-#pragma unroll
-                    for (int st = kWave >> 1; st > 0; st >>= 1)
-                        if (L.prefix[row + st] <= t) row += st;
-                    const int jj = t - L.prefix[row];
-                    const int ca = L.cntA[row];
-                    const int k = (jj < ca) ? (L.firstA[row] + jj) : (L.firstB[row] + (jj - ca));
-                    const int nrr = L.nr[row];
-                    const double phi_pix = ((double)k + L.shift[row]) * (kTwoPi / (double)nrr);
-                    double v[3];
-                    if (pair_value<MODE>(m.tab, L.pair[L.eslot[row]], L.z[row], L.sth[row], phi_pix, v)) {
-                        ACC *o = acc + NCOMP * (L.ldsbase[row] + k);
-                        for (int cc = 0; cc < NCOMP; ++cc) atomic_accumulate(o + cc, v[cc]);   // ds_add_f32 / f64
+                // ---- lanes = (halo, pixel) pairs, two per lane per trip
+                const unsigned long long le = lt | (1ull << lane);
+                const bool fastok = m.tab.r_uniform != 0;
+                int base = 0;                                      // rows started before the current 64 pairs
+                for (int T0 = 0; T0 < (BFGX_ABLATE == 4 ? 0 : total); T0 += 2 * kWave) {
+                    const unsigned long long mA = L.mask[T0 >> 6], mB = L.mask[(T0 >> 6) + 1];
+                    const int tA = T0 + lane, tB = T0 + kWave + lane;
+                    const bool actA = tA < total, actB = tB < total;
+                    const int rowA = actA ? base + __popcll(mA & le) - 1 : 0;
+                    base += __popcll(mA);
+                    const int rowB = actB ? base + __popcll(mB & le) - 1 : 0;
+                    base += __popcll(mB);
+                    int kA, kB; double xA, xB;
+                    {
+                        const int jj = tA - L.prefix[rowA], ca = L.cntA[rowA];
+                        kA = (jj < ca) ? (L.firstA[rowA] + jj) : (L.firstB[rowA] + (jj - ca));
+                        const int esA = L.eslot[rowA];
+                        xA = fold_dphi(((double)kA + L.shift[rowA]) * (kTwoPi / (double)L.nr[rowA]) - L.pair[esA].phi0);
                     }
+                    {
+                        const int jj = tB - L.prefix[rowB], ca = L.cntA[rowB];
+                        kB = (jj < ca) ? (L.firstA[rowB] + jj) : (L.firstB[rowB] + (jj - ca));
+                        const int esB = L.eslot[rowB];
+                        xB = fold_dphi(((double)kB + L.shift[rowB]) * (kTwoPi / (double)L.nr[rowB]) - L.pair[esB].phi0);
+                    }
+                    const PairHalo &hA = L.pair[L.eslot[rowA]], &hB = L.pair[L.eslot[rowB]];
+                    double vA[3], vB[3];
+                    bool okA, okB;
+                    const bool small = (!actA || fabs(xA) <= 0.5) && (!actB || fabs(xB) <= 0.5);
+#if BFGX_ABLATE == 3 || BFGX_ABLATE == 6 || BFGX_ABLATE == 7     // timing-only build: no per-pair math at all
+                    if (true) { okA = okB = true; vA[0] = vA[1] = vA[2] = xA; vB[0] = vB[1] = vB[2] = xB; } else
+#endif
+                    if (fastok && __all(small)) {
+                        okA = pair_value_fast<MODE>(m.tab, hA, L.z[rowA], L.sth[rowA], xA, vA);
+                        okB = pair_value_fast<MODE>(m.tab, hB, L.z[rowB], L.sth[rowB], xB, vB);
+                    } else {
+                        okA = pair_value<MODE>(m.tab, hA, L.z[rowA], L.sth[rowA], xA + hA.phi0, vA);
+                        okB = pair_value<MODE>(m.tab, hB, L.z[rowB], L.sth[rowB], xB + hB.phi0, vB);
+                    }
+#if BFGX_ABLATE == 7      // timing-only: plain LDS stores instead of atomics
+                    if (actA && okA) { double *o = acc + NCOMP * (L.ldsbase[rowA] + kA); for (int cc = 0; cc < NCOMP; ++cc) o[cc] = vA[cc]; }
+                    if (actB && okB) { double *o = acc + NCOMP * (L.ldsbase[rowB] + kB); for (int cc = 0; cc < NCOMP; ++cc) o[cc] = vB[cc]; }
+#elif BFGX_ABLATE == 2 || BFGX_ABLATE == 6     // timing-only build: no LDS accumulation (keep the values alive)
+                    if (actA && okA && vA[0] == 1.2345e300) acc[0] = vA[1] + vA[2];
+                    if (actB && okB && vB[0] == 1.2345e300) acc[1] = vB[1] + vB[2];
+#else
+                    if (actA && okA) {
+                        double *o = acc + NCOMP * (L.ldsbase[rowA] + kA);
+                        for (int cc = 0; cc < NCOMP; ++cc) atomicAdd(o + cc, vA[cc]);           // ds_add_f64
+                    }
+                    if (actB && okB) {
+                        double *o = acc + NCOMP * (L.ldsbase[rowB] + kB);
+                        for (int cc = 0; cc < NCOMP; ++cc) atomicAdd(o + cc, vB[cc]);
+                    }
+#endif
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -860,8 +971,8 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
         const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
         const int n = (ke - ks) * NCOMP;
         ACC *dst = out + NCOMP * (st + ks);
-        const ACC *src = acc + NCOMP * rr * T.W;
-        for (int x = lane; x < n; x += kWave) dst[x] = src[x];
+        const double *src = acc + NCOMP * rr * T.W;
+        for (int x = lane; x < (BFGX_ABLATE == 5 ? 0 : n); x += kWave) dst[x] = (ACC)src[x];
     }
 }
 
@@ -893,6 +1004,162 @@ regrid_kernel(Hpx h, const double *__restrict__ map_in, const ACC *__restrict__ 
     get_interpol<true>(h, th2, ph2, cp, w);
 #pragma unroll
     for (int k = 0; k < 4; ++k) atomicAdd(map_out + cp[k], w[k] * val);  // :64
+}
+
+// colatitude of a ring centre exactly as get_interpol uses it (healpix_cxx get_ring_info2)
+__device__ inline double ring_theta(const Hpx &h, int ring)
+{
+    int64_t st, nr; double th; bool sh;
+    ring_info2(h, ring, st, nr, th, sh);
+    return th;
+}
+
+// ---------------------------------------------------------------------------------- K2, tiled
+// One workgroup per tile of SOURCE pixels.  Displacements are a small fraction of a pixel, so almost every
+// target pixel lies in the tile or within a thin apron around it: contributions are summed in LDS (fp64
+// ds_add) and flushed as row-contiguous fp64 atomics (full-rate shape); the rare far target goes straight
+// to a global atomic.  map_out must be zeroed by the caller.
+constexpr int kApronR = 2;     // apron rings above / below the band
+constexpr int kApronK = 4;     // apron pixels left / right of the tile's azimuth range
+
+__host__ __device__ inline size_t regrid_lds_bytes(int BR, int W)
+{
+    return ((size_t)(BR + 2 * kApronR) * (W + 2 * kApronK) + (BR + 2 * kApronR + 2)) * sizeof(double);
+}
+
+template <typename ACC>
+__global__ void __launch_bounds__(256)
+tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
+                   double *__restrict__ map_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int LR = T.BR + 2 * kApronR, LW = T.W + 2 * kApronK;
+    double *acc = reinterpret_cast<double *>(smem);            // [LR][LW]
+    double *rth = acc + LR * LW;                               // colatitudes of rings i0-A-1 .. i1+A
+    const int tile = blockIdx.x;
+    const int band = T.tile_band[tile];
+    const int nphi = T.band_nphi[band];
+    const int tj = tile - T.band_tile0[band];
+    const int nl4 = (int)(4 * h.nside);
+    const int i0 = 1 + band * T.BR;
+    const int i1 = min(i0 + T.BR, nl4);                        // exclusive
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LR * LW; i += 256) acc[i] = 0.0;
+    if (tid < LR + 2) {
+        const int ring = i0 - kApronR - 1 + tid;
+        rth[tid] = (ring >= 1 && ring <= nl4 - 1) ? ring_theta(h, ring) : 0.0;
+    }
+    __syncthreads();
+    const int rth0 = i0 - kApronR - 1;
+
+    auto add_target = [&](int ring_t, int k_t, double v) {
+        int64_t st_t, nr64; bool sh_t;
+        ring_info_small(h, ring_t, st_t, nr64, sh_t);
+        const int nr_t = (int)nr64;
+        const int rr = ring_t - (i0 - kApronR);
+        if (rr >= 0 && rr < LR) {
+            int dk = k_t - tile_ks(tj, nr_t, nphi);
+            if (dk >= LW - kApronK) dk -= nr_t;
+            if (dk < -kApronK) dk += nr_t;
+            if (dk >= -kApronK && dk < LW - kApronK) { atomicAdd(acc + rr * LW + dk + kApronK, v); return; }
+        }
+        atomicAdd(map_out + st_t + k_t, v);                    // far target (rare)
+    };
+
+    for (int idx = tid; idx < T.BR * T.W; idx += 256) {
+        const int r = idx / T.W, x = idx - r * T.W;
+        const int ring = i0 + r;
+        if (ring >= i1) continue;
+        int64_t st, nr64; bool shf;
+        ring_info_small(h, ring, st, nr64, shf);
+        const int nr = (int)nr64;
+        const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
+        if (x >= ke - ks) continue;
+        const int k = ks + x;
+        const int64_t p = st + k;
+        const double val = map_in[p];
+        if (!(val > 0.0)) continue;                                          // HealpixRunner.py:335
+        double z, sth;
+        ring_z_sth(h, ring, z, sth);
+        const double phi = ((double)k + (shf ? 0.5 : 0.0)) * (kTwoPi / (double)nr);
+        double s, c;
+        sincos(phi, &s, &c);
+        const double nx = sth * c + (double)offsets[3 * p + 0];              // :333
+        const double ny = sth * s + (double)offsets[3 * p + 1];
+        const double nz = z + (double)offsets[3 * p + 2];
+        const double dnorm = sqrt(nx * nx + ny * ny + nz * nz);              // :334 vec2ang
+        const double theta = acos(nz / dnorm);
+        double ph = atan2(ny, nx);
+        if (ph < 0) ph += kTwoPi;
+        // get_interp_weights (:337): healpix_cxx get_interpol with ring colatitudes from the LDS table
+        const double zc = cos(theta);
+        const int ir1 = (int)ring_above(h, zc), ir2 = ir1 + 1;
+        int tr[4] = {0, 0, 0, 0}, tk[4] = {0, 0, 0, 0};
+        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        double theta1 = 0.0, theta2 = 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int ir = half ? ir2 : ir1;
+            if (half ? (ir < nl4) : (ir > 0)) {
+                int64_t sp, n64; bool sh2;
+                ring_info_small(h, ir, sp, n64, sh2);
+                const int n2 = (int)n64;
+                const double dphi = kTwoPi / (double)n2;
+                const double shd = sh2 ? 0.5 : 0.0;
+                const double tmp = ph / dphi - shd;
+                int j1 = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
+                const double w1 = (ph - ((double)j1 + shd) * dphi) / dphi;
+                int j2 = j1 + 1;
+                if (j1 < 0) j1 += n2;
+                if (j2 >= n2) j2 -= n2;
+                tr[2 * half] = ir; tr[2 * half + 1] = ir;
+                tk[2 * half] = j1; tk[2 * half + 1] = j2;
+                w[2 * half] = 1.0 - w1; w[2 * half + 1] = w1;
+                const int ti = ir - rth0;
+                const double th = (ti >= 0 && ti < LR + 2) ? rth[ti] : ring_theta(h, ir);
+                if (half) theta2 = th; else theta1 = th;
+            }
+        }
+        if (ir1 == 0) {                                    // north pole: missing ring -> the 4 polar pixels
+            const double wtheta = theta / theta2;
+            w[2] *= wtheta; w[3] *= wtheta;
+            const double fac = (1.0 - wtheta) * 0.25;
+            w[0] = fac; w[1] = fac; w[2] += fac; w[3] += fac;
+            tr[0] = 1; tr[1] = 1; tk[0] = (tk[2] + 2) & 3; tk[1] = (tk[3] + 2) & 3;
+        } else if (ir2 == nl4) {                           // south pole
+            const double wtheta = (theta - theta1) / (kPi - theta1);
+            w[0] *= (1.0 - wtheta); w[1] *= (1.0 - wtheta);
+            const double fac = wtheta * 0.25;
+            w[0] += fac; w[1] += fac; w[2] = fac; w[3] = fac;
+            tr[2] = nl4 - 1; tr[3] = nl4 - 1; tk[2] = (tk[0] + 2) & 3; tk[3] = (tk[1] + 2) & 3;
+        } else {
+            const double wtheta = (theta - theta1) / (theta2 - theta1);
+            w[0] *= (1.0 - wtheta); w[1] *= (1.0 - wtheta);
+            w[2] *= wtheta; w[3] *= wtheta;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) add_target(tr[q], tk[q], w[q] * val);    // regrid_pixels_hpix :64
+    }
+    __syncthreads();
+
+    // flush: row-contiguous fp64 atomics
+    const int lane = tid & (kWave - 1), wid = tid / kWave;
+    for (int rr = wid; rr < LR; rr += 256 / kWave) {
+        const int ring_t = i0 - kApronR + rr;
+        if (ring_t < 1 || ring_t > nl4 - 1) continue;
+        int64_t st_t, nr64; bool sh_t;
+        ring_info_small(h, ring_t, st_t, nr64, sh_t);
+        const int nr_t = (int)nr64;
+        const int k0 = tile_ks(tj, nr_t, nphi) - kApronK;
+        for (int xx = lane; xx < LW; xx += kWave) {
+            const double v = acc[rr * LW + xx];
+            if (v != 0.0) {
+                int k = (k0 + xx) % nr_t;
+                if (k < 0) k += nr_t;
+                atomicAdd(map_out + st_t + k, v);
+            }
+        }
+    }
 }
 
 // sums[0] += sum(a), sums[1] += sum(b)
