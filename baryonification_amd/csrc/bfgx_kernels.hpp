@@ -287,7 +287,8 @@ struct alignas(16) HaloRec {
 __device__ inline double dev_E2(const Background &b, double a)
 {
     const double a3 = a * a * a;
-    return b.Omega_m / a3 + b.Omega_l * pow(a, -3.0 * (1.0 + b.w0)) + b.Omega_r / (a3 * a);
+    const double de = (b.w0 == -1.0) ? b.Omega_l : b.Omega_l * pow(a, -3.0 * (1.0 + b.w0));   // LCDM: no pow()
+    return b.Omega_m / a3 + de + b.Omega_r / (a3 * a);
 }
 
 __device__ inline double dev_radius(const Background &b, const bfgx_massdef &md, double M, double a)
@@ -932,8 +933,18 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
                         okA = pair_value_fast<MODE>(m.tab, hA, L.z[rowA], L.sth[rowA], xA, vA);
                         okB = pair_value_fast<MODE>(m.tab, hB, L.z[rowB], L.sth[rowB], xB, vB);
                     } else {
-                        okA = pair_value<MODE>(m.tab, hA, L.z[rowA], L.sth[rowA], xA + hA.phi0, vA);
-                        okB = pair_value<MODE>(m.tab, hB, L.z[rowB], L.sth[rowB], xB + hB.phi0, vB);
+                        // generic path (non-uniform ln r axis or a wide azimuth span): one pair per pass of a
+                        // deliberately rolled loop so that its code and registers exist only once
+                        okA = okB = false;
+#pragma unroll 1
+                        for (int pass = 0; pass < 2; ++pass) {
+                            const PairHalo &hh = pass ? hB : hA;
+                            const int rw = pass ? rowB : rowA;
+                            double vv[3] = {0.0, 0.0, 0.0};
+                            const bool ok = pair_value<MODE>(m.tab, hh, L.z[rw], L.sth[rw], (pass ? xB : xA) + hh.phi0, vv);
+                            if (pass) { okB = ok; vB[0] = vv[0]; vB[1] = vv[1]; vB[2] = vv[2]; }
+                            else { okA = ok; vA[0] = vv[0]; vA[1] = vv[1]; vA[2] = vv[2]; }
+                        }
                     }
 #if BFGX_ABLATE == 7      // timing-only: plain LDS stores instead of atomics
                     if (actA && okA) { double *o = acc + NCOMP * (L.ldsbase[rowA] + kA); for (int cc = 0; cc < NCOMP; ++cc) o[cc] = vA[cc]; }
@@ -1027,6 +1038,14 @@ __host__ __device__ inline size_t regrid_lds_bytes(int BR, int W)
     return ((size_t)(BR + 2 * kApronR) * (W + 2 * kApronK) + (BR + 2 * kApronR + 2)) * sizeof(double);
 }
 
+// colatitude of a ring centre without libm (atan2 of the ring's sin/cos), for the tiled regrid
+__device__ inline double ring_theta_nolibm(const Hpx &h, int ring)
+{
+    double z, sth;
+    ring_z_sth(h, ring, z, sth);
+    return atan2_generic(sth, z);
+}
+
 template <typename ACC>
 __global__ void __launch_bounds__(256)
 tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
@@ -1047,7 +1066,7 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     for (int i = tid; i < LR * LW; i += 256) acc[i] = 0.0;
     if (tid < LR + 2) {
         const int ring = i0 - kApronR - 1 + tid;
-        rth[tid] = (ring >= 1 && ring <= nl4 - 1) ? ring_theta(h, ring) : 0.0;
+        rth[tid] = (ring >= 1 && ring <= nl4 - 1) ? ring_theta_nolibm(h, ring) : 0.0;
     }
     __syncthreads();
     const int rth0 = i0 - kApronR - 1;
@@ -1081,18 +1100,34 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
         if (!(val > 0.0)) continue;                                          // HealpixRunner.py:335
         double z, sth;
         ring_z_sth(h, ring, z, sth);
-        const double phi = ((double)k + (shf ? 0.5 : 0.0)) * (kTwoPi / (double)nr);
+        const double dphi0 = kTwoPi / (double)nr;
+        const double phi = ((double)k + (shf ? 0.5 : 0.0)) * dphi0;
         double s, c;
-        sincos(phi, &s, &c);
+        sincos_bounded(phi, s, c);
         const double nx = sth * c + (double)offsets[3 * p + 0];              // :333
         const double ny = sth * s + (double)offsets[3 * p + 1];
         const double nz = z + (double)offsets[3 * p + 2];
-        const double dnorm = sqrt(nx * nx + ny * ny + nz * nz);              // :334 vec2ang
-        const double theta = acos(nz / dnorm);
-        double ph = atan2(ny, nx);
+        // (theta, phi) of the displaced pixel (:334) as small corrections to the pixel's own angles:
+        //   in the frame rotated by -phi:  x' = n.e_r, y' = n.e_phi;  dphi = atan2(y', x');
+        //   sin(dtheta) = sin(theta_n) z - cos(theta_n) sin(theta)
+        const double xr = nx * c + ny * s, yr = ny * c - nx * s;
+        const double inv = fast_rsq(nx * nx + ny * ny + nz * nz);
+        const double zc = nz * inv;                                          // cos(theta_new)
+        const double tq = yr * fast_rcp(xr);
+        const double sn = fast_sqrt(xr * xr + yr * yr) * inv;                // sin(theta_new)
+        const double q = sn * z - zc * sth;
+        const double th_pix = rth[ring - rth0];
+        double theta, ph;
+        if (xr > 0.0 && fabs(tq) <= 0.1 && fabs(q) <= 0.05) {
+            ph = phi + atan_small(tq);
+            theta = th_pix + asin_small(q);
+        } else {                                                             // large displacement: libm
+            theta = atan2_generic(sn, zc);
+            ph = atan2_generic(ny, nx);
+        }
         if (ph < 0) ph += kTwoPi;
+        if (ph >= kTwoPi) ph -= kTwoPi;
         // get_interp_weights (:337): healpix_cxx get_interpol with ring colatitudes from the LDS table
-        const double zc = cos(theta);
         const int ir1 = (int)ring_above(h, zc), ir2 = ir1 + 1;
         int tr[4] = {0, 0, 0, 0}, tk[4] = {0, 0, 0, 0};
         double w[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1101,14 +1136,12 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
         for (int half = 0; half < 2; ++half) {
             const int ir = half ? ir2 : ir1;
             if (half ? (ir < nl4) : (ir > 0)) {
-                int64_t sp, n64; bool sh2;
-                ring_info_small(h, ir, sp, n64, sh2);
-                const int n2 = (int)n64;
-                const double dphi = kTwoPi / (double)n2;
+                const int n2 = ring_len(h, ir);
+                const bool sh2 = (ir < h.nside) || (ir >= 3 * h.nside) || (((ir - (int)h.nside) & 1) == 0);
                 const double shd = sh2 ? 0.5 : 0.0;
-                const double tmp = ph / dphi - shd;
-                int j1 = (tmp < 0) ? (int)tmp - 1 : (int)tmp;
-                const double w1 = (ph - ((double)j1 + shd) * dphi) / dphi;
+                const double tmp = ph * ((double)n2 * kInvTwoPi) - shd;
+                int j1 = (int)floor(tmp);
+                const double w1 = tmp - (double)j1;
                 int j2 = j1 + 1;
                 if (j1 < 0) j1 += n2;
                 if (j2 >= n2) j2 -= n2;
@@ -1116,7 +1149,7 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
                 tk[2 * half] = j1; tk[2 * half + 1] = j2;
                 w[2 * half] = 1.0 - w1; w[2 * half + 1] = w1;
                 const int ti = ir - rth0;
-                const double th = (ti >= 0 && ti < LR + 2) ? rth[ti] : ring_theta(h, ir);
+                const double th = (ti >= 0 && ti < LR + 2) ? rth[ti] : ring_theta_nolibm(h, ir);
                 if (half) theta2 = th; else theta1 = th;
             }
         }
@@ -1133,12 +1166,12 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
             w[0] += fac; w[1] += fac; w[2] = fac; w[3] = fac;
             tr[2] = nl4 - 1; tr[3] = nl4 - 1; tk[2] = (tk[0] + 2) & 3; tk[3] = (tk[1] + 2) & 3;
         } else {
-            const double wtheta = (theta - theta1) / (theta2 - theta1);
+            const double wtheta = (theta - theta1) * fast_rcp(theta2 - theta1);
             w[0] *= (1.0 - wtheta); w[1] *= (1.0 - wtheta);
             w[2] *= wtheta; w[3] *= wtheta;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) add_target(tr[q], tk[q], w[q] * val);    // regrid_pixels_hpix :64
+        for (int q4 = 0; q4 < 4; ++q4) add_target(tr[q4], tk[q4], w[q4] * val);    // regrid_pixels_hpix :64
     }
     __syncthreads();
 

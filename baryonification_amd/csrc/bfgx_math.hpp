@@ -78,14 +78,102 @@ __device__ inline void sincos_small(double x, double &s, double &c)
     c = __builtin_fma(u, pc, 1.0);
 }
 
-// sin/cos of an azimuth difference in (-2 pi, 2 pi): fold to (-pi, pi], Taylor when small, libm otherwise
+// sin/cos for |x| <~ 1e3: Cody-Waite reduction by pi/2 (two-term, FMA) + Taylor on [-pi/4, pi/4]; branch-free
+__device__ inline void sincos_bounded(double x, double &s, double &c)
+{
+    const double k = __builtin_rint(x * 0.63661977236758134308);           // 2/pi
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    const double u = r * r;
+    double ps = -1.0 / 121645100408832000.0;                               // r^19
+    ps = __builtin_fma(ps, u, 1.0 / 355687428096000.0);
+    ps = __builtin_fma(ps, u, -1.0 / 1307674368000.0);
+    ps = __builtin_fma(ps, u, 1.0 / 6227020800.0);
+    ps = __builtin_fma(ps, u, -1.0 / 39916800.0);
+    ps = __builtin_fma(ps, u, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, u, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, u, 1.0 / 120.0);
+    ps = __builtin_fma(ps, u, -1.0 / 6.0);
+    const double sr = __builtin_fma(r * u, ps, r);
+    double pc = 1.0 / 2432902008176640000.0;                               // r^20
+    pc = __builtin_fma(pc, u, -1.0 / 6402373705728000.0);
+    pc = __builtin_fma(pc, u, 1.0 / 20922789888000.0);
+    pc = __builtin_fma(pc, u, -1.0 / 87178291200.0);
+    pc = __builtin_fma(pc, u, 1.0 / 479001600.0);
+    pc = __builtin_fma(pc, u, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, u, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, u, -1.0 / 720.0);
+    pc = __builtin_fma(pc, u, 1.0 / 24.0);
+    pc = __builtin_fma(pc, u, -0.5);
+    const double cr = __builtin_fma(u, pc, 1.0);
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// sin/cos of an azimuth difference in (-2 pi, 2 pi): fold to (-pi, pi], Taylor when small, Cody-Waite otherwise
 __device__ inline void sincos_dphi(double x, double &s, double &c)
 {
     constexpr double kPi_ = 3.141592653589793238462643383279502884197;
     x = (x > kPi_) ? x - 2.0 * kPi_ : x;
     x = (x < -kPi_) ? x + 2.0 * kPi_ : x;
     if (__builtin_expect(fabs(x) <= 0.5, 1)) sincos_small(x, s, c);
-    else sincos(x, &s, &c);
+    else sincos_bounded(x, s, c);
+}
+
+// atan(t) for |t| <= 0.1 (series to t^15: truncation < 6e-18)
+__device__ inline double atan_small(double t)
+{
+    const double u = t * t;
+    double p = -1.0 / 15.0;
+    p = __builtin_fma(p, u, 1.0 / 13.0);
+    p = __builtin_fma(p, u, -1.0 / 11.0);
+    p = __builtin_fma(p, u, 1.0 / 9.0);
+    p = __builtin_fma(p, u, -1.0 / 7.0);
+    p = __builtin_fma(p, u, 1.0 / 5.0);
+    p = __builtin_fma(p, u, -1.0 / 3.0);
+    return __builtin_fma(t * u, p, t);
+}
+
+// asin(q) for |q| <= 0.05 (series to q^11: truncation < 2e-18)
+__device__ inline double asin_small(double q)
+{
+    const double u = q * q;
+    double p = 63.0 / 2816.0;
+    p = __builtin_fma(p, u, 35.0 / 1152.0);
+    p = __builtin_fma(p, u, 5.0 / 112.0);
+    p = __builtin_fma(p, u, 3.0 / 40.0);
+    p = __builtin_fma(p, u, 1.0 / 6.0);
+    return __builtin_fma(q * u, p, q);
+}
+
+// atan2(y, x) for finite arguments, not both zero: octant reduction, tangent half-angle steps down to
+// |t| <= 0.1, then the series.  Register-light (no libm); used on rare paths only.
+__device__ inline double atan2_generic(double y, double x)
+{
+    const double ay = fabs(y), ax = fabs(x);
+    const bool swap = ay > ax;
+    const double num = swap ? ax : ay, den = swap ? ay : ax;
+    double t = (den > 0.0) ? num * fast_rcp(den) : 0.0;                     // in [0, 1]
+    double scale = 1.0;
+    for (int it = 0; it < 4 && t > 0.1; ++it) {                             // atan t = 2 atan(t / (1 + sqrt(1 + t^2)))
+        const double hyp = 1.0 + t * t;
+        t = t * fast_rcp(1.0 + hyp * fast_rsq(hyp));
+        scale *= 2.0;
+    }
+    double a = scale * atan_small(t);
+    a = swap ? 1.570796326794896619231321691639751442099 - a : a;
+    a = (x < 0.0) ? 3.141592653589793238462643383279502884197 - a : a;
+    return (y < 0.0) ? -a : a;
+}
+
+// sqrt(x) for normal x > 0 via the rsq seed; returns 0 for x <= 0
+__device__ inline double fast_sqrt(double x)
+{
+    const double xs = x > 0.0 ? x : 1.0;
+    const double r = xs * fast_rsq(xs);
+    return x > 0.0 ? r : 0.0;
 }
 
 }  // namespace bfgx
