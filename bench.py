@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--eps', type=float, default=10.0)
     ap.add_argument('--acc-f64', action='store_true', help='fp64 pix_offsets accumulators instead of fp32')
     ap.add_argument('--algo', type=int, default=1, help='1 = LDS tiles (default), 0 = per-halo global atomics')
+    ap.add_argument('--mode', choices=['baryonify', 'paint'], default='baryonify',
+                    help="'paint' = PaintProfilesShell (BASELINE config 3 with --nside 2048); not the headline metric")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample')
     return ap.parse_args()
@@ -89,10 +91,12 @@ def main():
         z, M, r = syn.table_grid(cat)                    # README.md:78-80: edges = catalog min/max
     else:                                                # shards differ: analytic support of the catalog
         z, M, r = np.geomspace(0.2, 0.3, 10), np.geomspace(1e12, 1e15, 10), np.geomspace(1e-3, 3e2, 500)
-    table = syn.displacement_table(z, M, r)
+    paint = args.mode == 'paint'
+    table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
     axes = [np.log(1 + z), np.log(M), np.log(r)]
-    hmap = syn.make_map(nside)
-    model, keep = engine.model_from_tables(axes, table, syn.COSMO, args.eps, args.eps)
+    hmap = np.zeros(npix) if paint else syn.make_map(nside)
+    model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, args.eps, args.eps,
+                                           log_values=paint)
 
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}
     d_map = torch.from_numpy(hmap).to(dev)
@@ -104,10 +108,19 @@ def main():
     plan = engine.ShellPlan(model, keep, nside, args.halos, device=local_rank, stream=stream)
     cat_dev = _lib.make_catalog_dev(args.halos, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
     plan.set_algo(args.algo)
-    n_pairs = plan.count_pairs(cat_dev, fallback4=True)
+    n_pairs = plan.count_pairs(cat_dev, fallback4=not paint)
     plan.status()
 
+    def step_paint():
+        if args.algo == 0:
+            d_out.zero_()
+        plan.paint(cat_dev, d_out.data_ptr(), acc_f64=True)
+        if world > 1:
+            dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318
+
     def step():
+        if paint:
+            return step_paint()
         if args.algo == 0:
             d_off.zero_()                      # algo 1 stores every element of pix_offsets exactly once
         d_out.zero_(); d_sums.zero_()
@@ -146,24 +159,29 @@ def main():
         # algorithmic bytes per launch: K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo;
         # K2 60 B per map pixel
         acc_b = 8 if args.acc_f64 else 4
-        alg = {'offsets': n_pairs * 3 * acc_b + args.halos * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8)}
-        dom = max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
-        names = {"offsets": "tile_scatter_kernel<OFFSETS>" if args.algo == 1 else "halo_scatter_kernel<OFFSETS>", "regrid": "regrid_kernel"}
+        alg = {'offsets': n_pairs * 3 * acc_b + args.halos * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8),
+               'paint': n_pairs * 8 + args.halos * 32 + npix * 8}
+        dom = 'paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
+        names = {"offsets": "tile_scatter_kernel<OFFSETS>" if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
+                 "regrid": "tile_regrid_kernel" if args.algo == 1 else "regrid_kernel",
+                 "paint": "tile_scatter_kernel<PAINT>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
         out = {
-            "metric": "halos/sec for BaryonifyShell NSIDE=%d (1e6-halo synthetic catalog per GPU)" % nside,
+            "metric": "halos/sec for %s NSIDE=%d (1e6-halo synthetic catalog per GPU)" % ("PaintProfilesShell" if paint else "BaryonifyShell", nside),
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d-halo synthetic catalog per GPU (SURVEY 8d seeds), BaryonifyShell, "
-                                   "NSIDE=%d shell, epsilon_max=%g, 10x10x500 closed-form displacement table" % (args.halos, nside, args.eps),
+            "config": {"workload": "BASELINE config %d: %d-halo synthetic catalog per GPU (SURVEY 8d seeds), %s, "
+                                   "NSIDE=%d shell, epsilon_max=%g, 10x10x500 closed-form %s table" % (
+                                       3 if paint else 2, args.halos, "PaintProfilesShell" if paint else "BaryonifyShell", nside, args.eps,
+                                       "profile" if paint else "displacement"),
                        "halos_per_gpu": args.halos, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
-                       "accumulators": "f64" if args.acc_f64 else "f32 offsets / f64 map",
+                       "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
                        "parallelism": "halo shards x%d + RCCL reduce(pix_offsets)->rank0 regrid" % world if world > 1 else "single GPU"},
             "map_pixels_per_s": npix / elapsed * args.steps,
             "kernel_ms": kernels,
-            "mass_conserved": bool(np.isclose(sums[1], sums[0])),
+            "mass_conserved": None if paint else bool(np.isclose(sums[1], sums[0])),
             "roofline": {"kernel": names[dom],
                          "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -171,7 +189,7 @@ def main():
                          "note": "scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "
                                  "(gfx950 memory-side float atomics), not the 8 TB/s stream peak"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not paint:
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
         print(json.dumps(out), flush=True)
     plan.close()
