@@ -81,6 +81,12 @@ SYMBOLS = {
     'bfgx_plan_status': (C.c_int, [C.c_void_p]),
     'bfgx_plan_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_timing_read': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_project_profile': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p]),
+    'bfgx_enclosed_mass_2d': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p,
+                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_enclosed_mass_from_sigma': (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_displacement_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_pressure_profile': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
     'bfgx_count_pairs_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int, C.c_void_p, _P(C.c_int64)]),
 }
 

@@ -19,6 +19,7 @@
 #include "../../include/bfgx.h"
 #include "bfgx_cosmo.hpp"
 #include "bfgx_kernels.hpp"
+#include "bfgx_tables.hpp"
 
 using namespace bfgx;
 
@@ -720,6 +721,132 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
         stats->ms_h2d = ms_h2d; stats->ms_kernels = ms_k; stats->ms_d2h = ms_d2h;
         stats->n_pairs = -1;
     }
+    return BFGX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ table builders (a6-a8)
+namespace {
+
+struct DevArr {
+    void *p = nullptr;
+    ~DevArr() { if (p) (void)hipFree(p); }
+    int up(const void *host, size_t bytes)
+    {
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return 1;
+        if (host && bytes && hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        return 0;
+    }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+int tables_begin(int device)
+{
+    if (bfgx_device_count() <= 0) return fail(BFGX_ERR_NO_DEVICE, "no HIP device visible: libbfgx has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    return BFGX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bfgx_project_profile(int device, int64_t nrows, int32_t nl, const double *l, const double *rho,
+                         int64_t nr, const double *r, double scale, double *sigma_out)
+{
+    if (!l || !rho || !r || !sigma_out) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (nrows < 1 || nrows > 65535 || nl < 2 || nl > 2048 || nr < 1) return fail(BFGX_ERR_INVALID, "bad sizes (1 <= nrows <= 65535, 2 <= nl <= 2048)");
+    if (int rc = tables_begin(device)) return rc;
+    DevArr dl, drho, dr, dout;
+    if (dl.up(l, sizeof(double) * nl) || drho.up(rho, sizeof(double) * nrows * nl) || dr.up(r, sizeof(double) * nr) ||
+        dout.up(nullptr, sizeof(double) * nrows * nr))
+        return fail(BFGX_ERR_HIP, "device allocation/copy failed");
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)((nr + 255) / 256), (unsigned)nrows), dim3(256), 3 * sizeof(double) * nl, 0,
+                       nl, dl.as<double>(), drho.as<double>(), nr, dr.as<double>(), scale, dout.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(sigma_out, dout.p, sizeof(double) * nrows * nr, hipMemcpyDeviceToHost));
+    return BFGX_OK;
+}
+
+int bfgx_enclosed_mass_from_sigma(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *Sigma,
+                                  int32_t nr, const double *r, double *M_f)
+{
+    if (!r_int || !Sigma || !r || !M_f) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (nrows < 1 || n_int < 3 || nr < 1) return fail(BFGX_ERR_INVALID, "bad sizes");
+    if (int rc = tables_begin(device)) return rc;
+    DevArr dri, dS, dr, dcx, dcy, dM;
+    if (dri.up(r_int, sizeof(double) * n_int) || dS.up(Sigma, sizeof(double) * nrows * n_int) || dr.up(r, sizeof(double) * nr) ||
+        dcx.up(nullptr, sizeof(double) * nrows * n_int) || dcy.up(nullptr, sizeof(double) * nrows * n_int) ||
+        dM.up(nullptr, sizeof(double) * nrows * nr))
+        return fail(BFGX_ERR_HIP, "device allocation/copy failed");
+    hipLaunchKernelGGL(enclosed_mass_kernel, dim3((unsigned)nrows), dim3(kTabThreads), 0, 0, n_int, dri.as<double>(),
+                       dS.as<double>(), nr, dr.as<double>(), dcx.as<double>(), dcy.as<double>(), dM.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(M_f, dM.p, sizeof(double) * nrows * nr, hipMemcpyDeviceToHost));
+    return BFGX_OK;
+}
+
+int bfgx_enclosed_mass_2d(int device, int64_t nrows, int32_t nl, const double *l, const double *rho, double a,
+                          int64_t n_int, const double *r_int, int32_t nr, const double *r, double *M_f)
+{
+    if (!l || !rho || !r_int || !r || !M_f) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (nrows < 1 || nrows > 65535 || nl < 2 || nl > 2048 || n_int < 3 || nr < 1) return fail(BFGX_ERR_INVALID, "bad sizes");
+    if (int rc = tables_begin(device)) return rc;
+    DevArr dl, drho, dri, dS, dr, dcx, dcy, dM;
+    if (dl.up(l, sizeof(double) * nl) || drho.up(rho, sizeof(double) * nrows * nl) || dri.up(r_int, sizeof(double) * n_int) ||
+        dS.up(nullptr, sizeof(double) * nrows * n_int) || dr.up(r, sizeof(double) * nr) ||
+        dcx.up(nullptr, sizeof(double) * nrows * n_int) || dcy.up(nullptr, sizeof(double) * nrows * n_int) ||
+        dM.up(nullptr, sizeof(double) * nrows * nr))
+        return fail(BFGX_ERR_HIP, "device allocation/copy failed");
+    // Sigma = model.projected(r_int) * a   (BaryonCorrection.py:646), then the prefix sum + log-log PCHIP
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)((n_int + 255) / 256), (unsigned)nrows), dim3(256), 3 * sizeof(double) * nl, 0,
+                       nl, dl.as<double>(), drho.as<double>(), n_int, dri.as<double>(), a, dS.as<double>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(enclosed_mass_kernel, dim3((unsigned)nrows), dim3(kTabThreads), 0, 0, n_int, dri.as<double>(),
+                       dS.as<double>(), nr, dr.as<double>(), dcx.as<double>(), dcy.as<double>(), dM.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(M_f, dM.p, sizeof(double) * nrows * nr, hipMemcpyDeviceToHost));
+    return BFGX_OK;
+}
+
+int bfgx_displacement_rows(int device, int64_t nrows, int32_t nr, const double *r, const double *M_dmo, const double *M_dmb,
+                           double *d_out, int32_t *status)
+{
+    if (!r || !M_dmo || !M_dmb || !d_out || !status) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (nrows < 1 || nr < 3 || nr > kMaxNR) return fail(BFGX_ERR_INVALID, "N_samples_R must be in [3, %d]", kMaxNR);
+    if (int rc = tables_begin(device)) return rc;
+    DevArr dr, da, db, dd, ds;
+    if (dr.up(r, sizeof(double) * nr) || da.up(M_dmo, sizeof(double) * nrows * nr) || db.up(M_dmb, sizeof(double) * nrows * nr) ||
+        dd.up(nullptr, sizeof(double) * nrows * nr) || ds.up(nullptr, sizeof(int32_t) * nrows))
+        return fail(BFGX_ERR_HIP, "device allocation/copy failed");
+    const size_t lds = sizeof(double) * 7 * nr + sizeof(int) * 2 * nr;
+    HIP_TRY(hipFuncSetAttribute((const void *)displacement_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(displacement_kernel, dim3((unsigned)nrows), dim3(256), lds, 0, nr, dr.as<double>(), da.as<double>(),
+                       db.as<double>(), dd.as<double>(), ds.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(d_out, dd.p, sizeof(double) * nrows * nr, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status, ds.p, sizeof(int32_t) * nrows, hipMemcpyDeviceToHost));
+    return BFGX_OK;
+}
+
+int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const double *rho_tot, const double *rho_gas,
+                          int32_t nr_out, const double *r_out, double cutoff, double *P_out)
+{
+    if (!r500 || !rho_tot || !rho_gas || !r_out || !P_out) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (nrows < 1 || nr_out < 1) return fail(BFGX_ERR_INVALID, "bad sizes");
+    if (int rc = tables_begin(device)) return rc;
+    DevArr dg, dt, dgas, dr, dP;
+    if (dg.up(r500, sizeof(double) * kPressureN) || dt.up(rho_tot, sizeof(double) * nrows * kPressureN) ||
+        dgas.up(rho_gas, sizeof(double) * nrows * kPressureN) || dr.up(r_out, sizeof(double) * nr_out) ||
+        dP.up(nullptr, sizeof(double) * nrows * nr_out))
+        return fail(BFGX_ERR_HIP, "device allocation/copy failed");
+    const double G = kGnewt / (kMpcToMeter * kMpcToMeter * kMpcToMeter) * kSolarMass;       // Thermodynamic.py:11
+    const double unit = (kSolarMass * 1e3) / (kMpcToMeter * 1e2);                           // :265
+    hipLaunchKernelGGL(pressure_kernel, dim3((unsigned)nrows), dim3(256), 0, 0, dg.as<double>(), dt.as<double>(),
+                       dgas.as<double>(), nr_out, dr.as<double>(), G, unit, cutoff, dP.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(P_out, dP.p, sizeof(double) * nrows * nr_out, hipMemcpyDeviceToHost));
     return BFGX_OK;
 }
 

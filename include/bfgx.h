@@ -160,6 +160,29 @@ int  bfgx_plan_timing_read(bfgx_plan *p, double *ms_sum, int64_t *launches);
 int  bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int fallback4,
                              int64_t *counts_dev, int64_t *total_host);
 
+/* ---- table builders: host arrays in, host arrays out, run once per model ----
+ * The profile physics stays on the host: these take 3-D densities SAMPLED on the radial grids the
+ * reference uses.  All double.  Replaces:
+ *   bfgx_project_profile          SchneiderProfiles._projected_realspace, Profiles/Schneider19.py:245-252
+ *                                 sigma[row][j] = scale * 2 trapz(interp(sqrt(l^2 + r_j^2), l, rho_row), l)
+ *   bfgx_enclosed_mass_2d         Baryonification2D.get_masses, Profiles/BaryonCorrection.py:639-661
+ *                                 (projection onto r_int times a, Sigma<0 -> 0, prefix sum, log-log PCHIP at r)
+ *   bfgx_enclosed_mass_from_sigma the same from a projected profile the caller computed some other way
+ *   bfgx_displacement_rows        setup_interpolator's per-mass loop body, BaryonCorrection.py:226-301;
+ *                                 status[row]: 0 ok, 1 mass profile nearly constant (iterate > 30),
+ *                                 2 fewer than 5 usable points -- both give d = 0 and warrant the reference's warning
+ *   bfgx_pressure_profile         Pressure._real, Profiles/Thermodynamic.py:240-271 (cgs), r500 = geomspace(1e-6,1e3,500) */
+int bfgx_project_profile(int device, int64_t nrows, int32_t nl, const double *l, const double *rho,
+                         int64_t nr, const double *r, double scale, double *sigma_out);
+int bfgx_enclosed_mass_2d(int device, int64_t nrows, int32_t nl, const double *l, const double *rho, double a,
+                          int64_t n_int, const double *r_int, int32_t nr, const double *r, double *M_f);
+int bfgx_enclosed_mass_from_sigma(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *Sigma,
+                                  int32_t nr, const double *r, double *M_f);
+int bfgx_displacement_rows(int device, int64_t nrows, int32_t nr, const double *r, const double *M_dmo,
+                           const double *M_dmb, double *d_out, int32_t *status);
+int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const double *rho_tot, const double *rho_gas,
+                          int32_t nr_out, const double *r_out, double cutoff, double *P_out);
+
 #ifdef __cplusplus
 }
 #endif
