@@ -1,1 +1,3 @@
 from .BaryonCorrection import *
+from .Schneider19 import *
+from .Thermodynamic import *

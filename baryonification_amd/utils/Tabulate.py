@@ -44,9 +44,30 @@ class _TabulatedBase(object):
             self.interp2D = interpolate.RegularGridInterpolator(grid, np.log(self.raw_input_2D), bounds_error=False)
         return self
 
-    def setup_interpolator(self, *args, **kwargs):
-        raise NotImplementedError("table construction from a profile model is not part of this build yet; "
-                                  "load a table with set_table()")
+    def setup_interpolator(self, z_min=1e-2, z_max=5, N_samples_z=30, z_linear_sampling=False,
+                           M_min=1e12, M_max=1e16, N_samples_Mass=30, R_min=1e-3, R_max=1e2, N_samples_R=100,
+                           other_params={}, verbose=True, N_samples_M=None):
+        """Tabulates model.real and model.projected * a on (z, M, r[, params]) (Tabulate.py:160-243, :468-566).
+        Profiles from baryonification_amd.Profiles project on the GPU (line-of-sight kernel)."""
+        from itertools import product
+        if N_samples_M is not None:
+            N_samples_Mass = N_samples_M
+        M_range = np.geomspace(M_min, M_max, N_samples_Mass)
+        r = np.geomspace(R_min, R_max, N_samples_R)
+        z_range = np.linspace(z_min, z_max, N_samples_z) if z_linear_sampling else np.geomspace(z_min, z_max, N_samples_z)
+        other_params = {k: np.asarray(v, dtype=np.float64) for k, v in other_params.items()}
+        p_keys = list(other_params.keys())
+        shape = [z_range.size, M_range.size, r.size] + [other_params[k].size for k in p_keys]
+        t3, t2 = np.full(shape, np.nan), np.full(shape, np.nan)
+        for j in range(z_range.size):
+            a_j = 1 / (1 + z_range[j])
+            for c in product(*[np.arange(other_params[k].size) for k in p_keys]):
+                for k_i, key in enumerate(p_keys):
+                    self.model.set_parameter(key, other_params[key][c[k_i]])
+                index = tuple([j, slice(None), slice(None)] + list(c))
+                t3[index] = self.model.real(self.cosmo, r, M_range, a_j)
+                t2[index] = self.model.projected(self.cosmo, r, M_range, a_j) * a_j
+        return _TabulatedBase.set_table(self, z_range, M_range, r, t2, t3, other_params)
 
     def _readout(self, r, M, a, table, **kwargs):
         r_use, M_use = np.atleast_1d(r), np.atleast_1d(M)

@@ -15,6 +15,10 @@ from .. import _lib
 
 __all__ = ['Cosmology', 'MassDef', 'cosmo_to_dict', 'massdef_to_tuple']
 
+# pyccl.physical_constants (CCL 2.x) used on the host side
+GNEWT, SOLAR_MASS, MPC_TO_METER = 6.67408e-11, 1.9884754153381438e30, 3.085677581491367399198952281e22
+RHO_CRITICAL = ((3 * 100 * 100) / (8 * np.pi * GNEWT)) * (1000 * 1000 * MPC_TO_METER / SOLAR_MASS)   # h^2 Msun / Mpc^3
+
 
 def cosmo_to_dict(cosmo):
     """6-key cosmology dict from: a dict, our Cosmology, or a pyccl Cosmology (cosmo['Omega_m'] API)."""
