@@ -55,7 +55,6 @@ int validate_cosmo(const bfgx_cosmo &c)
 int validate_table(const bfgx_table &t)
 {
     if (t.ndim < 3 || t.ndim > BFGX_MAX_DIM) return fail(BFGX_ERR_INVALID, "table ndim must be in [3, %d]", BFGX_MAX_DIM);
-    if (t.ndim != 3) return fail(BFGX_ERR_UNSUPPORTED, "extra-parameter table axes (p_keys) are not implemented yet");
     if (!t.values) return fail(BFGX_ERR_INVALID, "table values pointer is NULL");
     for (int d = 0; d < t.ndim; ++d) {
         if (t.n[d] < 2) return fail(BFGX_ERR_INVALID, "table axis %d needs >= 2 points", d);
@@ -80,6 +79,8 @@ struct bfgx_plan {
     DevModel model;
     std::vector<void *> owned;     // device allocations freed with the plan
     HaloRec *recs = nullptr;
+    RowSetX *rowsx = nullptr;      // corner rows when the table has extra parameter axes (NC > 4)
+    int NC = 4;
     // tile-owned accumulation (algo 1): tiling tables + halo -> tile binning workspace
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
@@ -129,6 +130,8 @@ static int check_catalog(const bfgx_plan *p, const bfgx_catalog *c)
     if (c->n < 0 || c->n > p->max_halos) return fail(BFGX_ERR_INVALID, "catalog size %lld exceeds plan max_halos %lld",
                                                      (long long)c->n, (long long)p->max_halos);
     if (c->n > 0 && (!c->M || !c->z || !c->ra || !c->dec)) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
+    for (int k = 0; k < p->model.tab.ndim - 3; ++k)
+        if (c->n > 0 && !c->extra[k]) return fail(BFGX_ERR_INVALID, "catalog is missing the column of table parameter axis %d", k);
     return BFGX_OK;
 }
 
@@ -137,9 +140,14 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
     if (c->n == 0) return BFGX_OK;
     const unsigned grid = (unsigned)((c->n + 255) / 256);
     KernelTimer kt(p, BFGX_K_PREP);
-    hipLaunchKernelGGL(halo_prep_kernel, dim3(grid), dim3(256), 0, p->stream,
-                       p->model, p->hpx, c->n, c->M, c->z, c->ra, c->dec, p->recs, fallback4, p->tiling,
-                       bin ? p->tile_count : (int32_t *)nullptr);
+    int32_t *tc = bin ? p->tile_count : (int32_t *)nullptr;
+#define BFGX_PREP(NCV)                                                                                              \
+    hipLaunchKernelGGL(halo_prep_kernel<NCV>, dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
+                       c->ra, c->dec, c->extra[0], c->extra[1], p->recs, p->rowsx, fallback4, p->tiling, tc)
+    if (p->NC == 4) BFGX_PREP(4);
+    else if (p->NC == 8) BFGX_PREP(8);
+    else BFGX_PREP(16);
+#undef BFGX_PREP
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -176,19 +184,28 @@ static int launch_scatter(bfgx_plan *p, int64_t n, ACC *out, int64_t *counts)
     return BFGX_OK;
 }
 
-template <int MODE, typename ACC>
-static int launch_tile_scatter(bfgx_plan *p, ACC *out)
+template <int MODE, typename ACC, int NC>
+static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out)
 {
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    const size_t lds = tile_lds_bytes(p->tiling.BR, p->tiling.W, NCOMP);
-    auto kern = tile_scatter_kernel<MODE, ACC>;
+    const size_t lds = tile_lds_bytes<NC>(p->tiling.BR, p->tiling.W, NCOMP);
+    auto kern = tile_scatter_kernel<MODE, ACC, NC>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kWavesPerBlock), lds, p->stream,
-                       p->model, p->hpx, p->tiling, (const HaloRec *)p->recs, (const int32_t *)p->tile_start,
-                       (const int32_t *)p->entries, p->capacity, out, p->pair_total);
+                       p->model, p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
+                       (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
+}
+
+template <int MODE, typename ACC>
+static int launch_tile_scatter(bfgx_plan *p, ACC *out)
+{
+    if (p->NC == 4) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out);
+    if (MODE == MODE_COUNT) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out);      // census never reads the rows
+    if (p->NC == 8) return launch_tile_scatter_nc<MODE, ACC, 8>(p, out);
+    return launch_tile_scatter_nc<MODE, ACC, 16>(p, out);
 }
 
 // blocking: if the entry list overflowed, grow it to the exact size and redo the fill pass
@@ -345,9 +362,22 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         m.tab.axis[d] = (const double *)dv;
     }
     {
+        // device layout [z][M][p0][p1][r]: the radial row of every (z, M, params) corner is contiguous
+        std::vector<double> tr;
+        const double *src = t.values;
+        if (t.ndim > 3) {
+            const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2], np0 = t.n[3], np1 = t.ndim > 4 ? t.n[4] : 1;
+            tr.resize(nvals);
+            for (size_t iz = 0; iz < nz; ++iz) for (size_t im = 0; im < nm; ++im) for (size_t ir = 0; ir < nr; ++ir)
+                for (size_t a0 = 0; a0 < np0; ++a0) for (size_t a1 = 0; a1 < np1; ++a1)
+                    tr[((((iz * nm + im) * np0 + a0) * np1 + a1) * nr) + ir] = t.values[((((iz * nm + im) * nr + ir) * np0 + a0) * np1) + a1];
+            src = tr.data();
+        }
         const void *dv = nullptr;
-        if (int rc = plan_upload(p, t.values, sizeof(double) * nvals, &dv)) return bail(rc);
+        if (int rc = plan_upload(p, src, sizeof(double) * nvals, &dv)) return bail(rc);
         m.tab.values = (const double *)dv;
+        if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
+        p->NC = 4 << (t.ndim - 3);
     }
     m.tab.rdelta = t.rdelta_sampling;
     m.tab.logv = t.log_values;
@@ -385,6 +415,12 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(halo records) failed"));
         p->owned.push_back(d);
         p->recs = (HaloRec *)d;
+        if (p->NC > 4) {
+            if (hipMalloc(&d, sizeof(RowSetX) * (size_t)(max_halos > 0 ? max_halos : 1)) != hipSuccess)
+                return bail(fail(BFGX_ERR_HIP, "hipMalloc(corner rows) failed"));
+            p->owned.push_back(d);
+            p->rowsx = (RowSetX *)d;
+        }
     }
     {   // tiling tables and halo -> tile binning workspace
         int BR, W;
@@ -493,6 +529,7 @@ int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev
         if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)offsets_dev);
         return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)offsets_dev);
     }
+    if (p->NC != 4) return fail(BFGX_ERR_UNSUPPORTED, "tables with extra parameter axes need algo 1 (LDS tiles)");
     if (int rc = launch_prep(p, cat, 1, false)) return rc;
     if (acc_f64) return launch_scatter<MODE_OFFSETS, double>(p, cat->n, (double *)offsets_dev, nullptr);
     return launch_scatter<MODE_OFFSETS, float>(p, cat->n, (float *)offsets_dev, nullptr);
@@ -510,6 +547,7 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
         if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)map_out_dev);
         return launch_tile_scatter<MODE_PAINT, float>(p, (float *)map_out_dev);
     }
+    if (p->NC != 4) return fail(BFGX_ERR_UNSUPPORTED, "tables with extra parameter axes need algo 1 (LDS tiles)");
     if (int rc = launch_prep(p, cat, 0, false)) return rc;
     if (acc_f64) return launch_scatter<MODE_PAINT, double>(p, cat->n, (double *)map_out_dev, nullptr);
     return launch_scatter<MODE_PAINT, float>(p, cat->n, (float *)map_out_dev, nullptr);
@@ -606,10 +644,11 @@ struct Timer {
     double stop(hipStream_t s) { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 };
 
-int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[4], bfgx_catalog *d)
+int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[4 + BFGX_MAX_EXTRA], bfgx_catalog *d)
 {
-    const double *src[4] = {h->M, h->z, h->ra, h->dec};
-    for (int i = 0; i < 4; ++i) {
+    const int nex = p->model.tab.ndim - 3;
+    const double *src[4 + BFGX_MAX_EXTRA] = {h->M, h->z, h->ra, h->dec, h->extra[0], h->extra[1]};
+    for (int i = 0; i < 4 + nex; ++i) {
         if (h->n > 0 && !src[i]) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
         if (cols[i].alloc(sizeof(double) * (size_t)h->n)) return fail(BFGX_ERR_HIP, "hipMalloc(catalog) failed");
         if (h->n > 0) HIP_TRY(hipMemcpyAsync(cols[i].p, src[i], sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, p->stream));
@@ -618,6 +657,7 @@ int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[4], bfgx_cat
     d->n = h->n;
     d->M = (const double *)cols[0].p; d->z = (const double *)cols[1].p;
     d->ra = (const double *)cols[2].p; d->dec = (const double *)cols[3].p;
+    for (int k = 0; k < nex; ++k) d->extra[k] = (const double *)cols[4 + k].p;
     return BFGX_OK;
 }
 
@@ -640,7 +680,7 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
 
     const size_t npix = (size_t)p->hpx.npix;
     const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
-    DevBuf cols[4], d_in, d_out, d_off, d_sums;
+    DevBuf cols[4 + BFGX_MAX_EXTRA], d_in, d_out, d_off, d_sums;
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);
@@ -694,7 +734,7 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     if (o.algo == 0 || o.algo == 1) p->algo = o.algo; else return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
 
     const size_t npix = (size_t)p->hpx.npix;
-    DevBuf cols[4], d_out;
+    DevBuf cols[4 + BFGX_MAX_EXTRA], d_out;
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);

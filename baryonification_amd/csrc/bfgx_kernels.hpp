@@ -266,6 +266,13 @@ struct DevModel {
     double da_step;
 };
 
+// corner rows of a table with extra parameter axes (p_keys): 4 * 2^K rows per halo, K = 1 or 2
+constexpr int kNCmax = 16;
+struct RowSetX {
+    double w[kNCmax];
+    int32_t rowoff[kNCmax];
+};
+
 // per-halo record written by K0, read (wave-uniformly) by K1/K3
 struct alignas(16) HaloRec {
     double z0, xa, s0, phi0;              // query_disc pointing: cos/sin colatitude, azimuth in [0, 2pi)
@@ -370,11 +377,15 @@ __device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const HaloRe
 
 // ---------------------------------------------------------------------------------- K0
 // thread per halo.  tile_count != nullptr: also counts the halo into every tile it may touch.
+// NC = 4 * 2^K corner rows (K extra parameter axes): for NC > 4 the rows go to rowsx[j] instead of the record.
+template <int NC>
 __global__ void __launch_bounds__(256)
 halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ M, const double *__restrict__ z,
                  const double *__restrict__ ra, const double *__restrict__ dec,
-                 HaloRec *__restrict__ rec, int fallback4, Tiling T, int32_t *__restrict__ tile_count)
+                 const double *__restrict__ ex0, const double *__restrict__ ex1,
+                 HaloRec *__restrict__ rec, RowSetX *__restrict__ rowsx, int fallback4, Tiling T,
+                 int32_t *__restrict__ tile_count)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
@@ -443,22 +454,51 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     r.lnoff = m.tab.rdelta ? (x0 - log(Rmod)) : x0;
     const int iz = axis_find(m.tab.axis[0], m.tab.n[0], x0);
     const int im = axis_find(m.tab.axis[1], m.tab.n[1], x1);
-    r.oob = (iz < 0 || im < 0) ? 1 : 0;
-    if (!r.oob) {
+    constexpr int K = (NC == 4) ? 0 : (NC == 8 ? 1 : 2);
+    int ip[2] = {0, 0};
+    double tp[2] = {0.0, 0.0};
+    bool oob = (iz < 0 || im < 0);
+    if (K >= 1) {
+        const double xe = ex0[j];
+        ip[0] = axis_find(m.tab.axis[3], m.tab.n[3], xe);
+        oob = oob || ip[0] < 0;
+        if (ip[0] >= 0) tp[0] = (xe - m.tab.axis[3][ip[0]]) / (m.tab.axis[3][ip[0] + 1] - m.tab.axis[3][ip[0]]);
+    }
+    if (K >= 2) {
+        const double xe = ex1[j];
+        ip[1] = axis_find(m.tab.axis[4], m.tab.n[4], xe);
+        oob = oob || ip[1] < 0;
+        if (ip[1] >= 0) tp[1] = (xe - m.tab.axis[4][ip[1]]) / (m.tab.axis[4][ip[1] + 1] - m.tab.axis[4][ip[1]]);
+    }
+    r.oob = oob ? 1 : 0;
+    double wv[NC];
+    int32_t ro[NC];
+    if (!oob) {
         const double *gz = m.tab.axis[0], *gm = m.tab.axis[1];
         const double tz = (x0 - gz[iz]) / (gz[iz + 1] - gz[iz]);
         const double tm = (x1 - gm[im]) / (gm[im + 1] - gm[im]);
         const int nr = m.tab.n[2];
-        r.w[0] = (1.0 * (1.0 - tz)) * (1.0 - tm);
-        r.w[1] = (1.0 * (1.0 - tz)) * tm;
-        r.w[2] = (1.0 * tz) * (1.0 - tm);
-        r.w[3] = (1.0 * tz) * tm;
-        r.rowoff[0] = (iz * m.tab.n[1] + im) * nr;
-        r.rowoff[1] = (iz * m.tab.n[1] + im + 1) * nr;
-        r.rowoff[2] = ((iz + 1) * m.tab.n[1] + im) * nr;
-        r.rowoff[3] = ((iz + 1) * m.tab.n[1] + im + 1) * nr;
+        const int np0 = (K >= 1) ? m.tab.n[3] : 1, np1 = (K >= 2) ? m.tab.n[4] : 1;
+        // device layout of the table: [z][M][p0][p1][r] (r innermost); corner order = scipy's product order
+        for (int c = 0; c < NC; ++c) {
+            const int bz = (c >> (K + 1)) & 1, bm = (c >> K) & 1;
+            const int b0 = (K >= 1) ? ((c >> (K - 1)) & 1) : 0, b1 = (K >= 2) ? (c & 1) : 0;
+            double w = (1.0 * (bz ? tz : 1.0 - tz)) * (bm ? tm : 1.0 - tm);
+            if (K >= 1) w *= (b0 ? tp[0] : 1.0 - tp[0]);
+            if (K >= 2) w *= (b1 ? tp[1] : 1.0 - tp[1]);
+            wv[c] = w;
+            ro[c] = ((((iz + bz) * m.tab.n[1] + im + bm) * np0 + ip[0] + b0) * np1 + ip[1] + b1) * nr;
+        }
     } else {
-        for (int c = 0; c < kNC; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
+        for (int c = 0; c < NC; ++c) { wv[c] = 0.0; ro[c] = 0; }
+    }
+    if (NC == 4) {
+        for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
+    } else {
+        for (int c = 0; c < 4; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
+        RowSetX rx;
+        for (int c = 0; c < kNCmax; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
+        rowsx[j] = rx;
     }
 
     // <4-pixel fallback (HealpixRunner.py:309-310): only discs of a few pixels can qualify -> exact census
@@ -521,6 +561,7 @@ tile_fill_kernel(Hpx h, Tiling T, int64_t nhalo, const HaloRec *__restrict__ rec
 template <typename ACC> __device__ inline void atomic_accumulate(ACC *p, double v) { atomicAdd(p, (ACC)v); }
 
 // linear read-out along ln r of the 4 (z,M)-corner rows; NaN outside the axis (scipy RGI semantics)
+template <int NC>
 __device__ inline double radial_readout(const DevTable &t, const int32_t *rowoff, const double *w, double lx)
 {
     const int n = t.n[2];
@@ -541,7 +582,7 @@ __device__ inline double radial_readout(const DevTable &t, const int32_t *rowoff
     const double t0 = 1.0 - tr;
     double val = 0.0;
 #pragma unroll
-    for (int c = 0; c < kNC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const double *row = t.values + rowoff[c] + i;
         val = val + row[0] * (w[c] * t0);
         val = val + row[1] * (w[c] * tr);
@@ -550,26 +591,34 @@ __device__ inline double radial_readout(const DevTable &t, const int32_t *rowoff
 }
 
 // halo fields the pair phase needs (a view: scalar registers in the halo-centric kernel, LDS in the tiled one)
-struct PairHalo {
+template <int NC>
+struct PairHaloT {
     double z0, s0, phi0, cph0, sph0, D, a, inv_a, rcut;
     double lnoff;                         // ln(1/a) [- ln R_model when Rdelta_sampling]: ln r axis coordinate offset
-    double w[kNC];
-    int32_t rowoff[kNC];
+    double w[NC];
+    int32_t rowoff[NC];
     int32_t oob, hidx;
 };
+using PairHalo = PairHaloT<kNC>;
 
-__device__ inline void load_pair_halo(PairHalo &p, const HaloRec &r, int hidx)
+template <int NC>
+__device__ inline void load_pair_halo(PairHaloT<NC> &p, const HaloRec &r, int hidx, const RowSetX *rowsx = nullptr)
 {
     p.z0 = r.z0; p.s0 = r.s0; p.phi0 = r.phi0; p.cph0 = r.cph0; p.sph0 = r.sph0;
     p.D = r.D; p.a = r.a; p.inv_a = r.inv_a; p.rcut = r.rcut; p.lnoff = r.lnoff;
-    for (int c = 0; c < kNC; ++c) { p.w[c] = r.w[c]; p.rowoff[c] = r.rowoff[c]; }
+    if (NC == kNC) {
+        for (int c = 0; c < kNC; ++c) { p.w[c] = r.w[c]; p.rowoff[c] = r.rowoff[c]; }
+    } else {
+        const RowSetX &x = rowsx[hidx];
+        for (int c = 0; c < NC; ++c) { p.w[c] = x.w[c]; p.rowoff[c] = x.rowoff[c]; }
+    }
     p.oob = r.oob; p.hidx = hidx;
 }
 
 // One (halo, pixel) pair.  Returns false when the pair contributes nothing.
 //   MODE_OFFSETS: v[0..2] = nw_vec - vec (HealpixRunner.py:314-328);  MODE_PAINT: v[0] = Paint (:441-442)
-template <int MODE>
-__device__ inline bool pair_value(const DevTable &tab, const PairHalo &r, double z, double sth, double phi_pix, double v[3])
+template <int MODE, int NC>
+__device__ inline bool pair_value(const DevTable &tab, const PairHaloT<NC> &r, double z, double sth, double phi_pix, double v[3])
 {
     // pixel unit vector in the frame rotated by -phi0 about the polar axis: halo at (s0, 0, z0)
     double sd, cd;
@@ -582,7 +631,7 @@ __device__ inline bool pair_value(const DevTable &tab, const PairHalo &r, double
     const double r_sep = r2 * inv_r;                                                // :317
     const double r_com = r_sep * r.inv_a;                                           // :321 (r_sep / a)
     const double lx = __builtin_fma(0.5, fast_log(r2), r.lnoff);                    // ln(r_sep/a) [- ln R when Rdelta]
-    double d = r.oob ? __builtin_nan("") : radial_readout(tab, r.rowoff, r.w, lx);
+    double d = r.oob ? __builtin_nan("") : radial_readout<NC>(tab, r.rowoff, r.w, lx);
     if (MODE == MODE_PAINT) {
         const double paint = exp(d);                                                // Tabulate.py:286
         v[0] = paint;
@@ -603,8 +652,8 @@ __device__ inline bool pair_value(const DevTable &tab, const PairHalo &r, double
 
 // Branch-free (fully predicated) variant for the common case: uniform ln r axis and |dphi| <= 0.5, so that two
 // pairs per lane can be interleaved by the scheduler.  x = azimuth difference already folded to (-pi, pi].
-template <int MODE>
-__device__ inline bool pair_value_fast(const DevTable &tab, const PairHalo &r, double z, double sth, double x, double v[3])
+template <int MODE, int NC>
+__device__ inline bool pair_value_fast(const DevTable &tab, const PairHaloT<NC> &r, double z, double sth, double x, double v[3])
 {
     double sd, cd;
     sincos_small(x, sd, cd);
@@ -625,7 +674,7 @@ __device__ inline bool pair_value_fast(const DevTable &tab, const PairHalo &r, d
     d = tr * r.w[0] + t0 * r.w[1] + 1e-3;
 #else
 #pragma unroll
-    for (int c = 0; c < kNC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const double *row = tab.values + r.rowoff[c] + i;
         d = d + row[0] * (r.w[c] * t0);
         d = d + row[1] * (r.w[c] * tr);
@@ -698,7 +747,7 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
             ring_info_small(h, r.fb_ring[lane], st, nr, sh);
             ring_z_sth(h, r.fb_ring[lane], z, sth);
             const double phi_pix = ((double)r.fb_k[lane] + (sh ? 0.5 : 0.0)) * (kTwoPi / (double)nr);
-            if (pair_value<MODE>(m.tab, ph, z, sth, phi_pix, v)) {
+            if (pair_value<MODE, kNC>(m.tab, ph, z, sth, phi_pix, v)) {
                 ACC *o = out + NCOMP * (st + r.fb_k[lane]);
                 for (int c = 0; c < NCOMP; ++c) atomic_accumulate(o + c, v[c]);
             }
@@ -727,7 +776,7 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
                     if (k >= nrr) k -= nrr;
                     const double phi_pix = ((double)k + L.shift[row]) * (kTwoPi / (double)nrr);
                     double v[3];
-                    if (pair_value<MODE>(m.tab, ph, L.z[row], L.sth[row], phi_pix, v)) {
+                    if (pair_value<MODE, kNC>(m.tab, ph, L.z[row], L.sth[row], phi_pix, v)) {
                         ACC *o = out + NCOMP * (L.start[row] + k);
                         for (int c = 0; c < NCOMP; ++c) atomic_accumulate(o + c, v[c]);
                     }
@@ -752,8 +801,9 @@ struct RingSlot {                    // ring-phase view of one entry
     int32_t _pad;
 };
 
-struct TileWaveLds {
-    PairHalo pair[kChunk];
+template <int NC>
+struct TileWaveLdsT {
+    PairHaloT<NC> pair[kChunk];
     RingSlot ring[kChunk];
     // rows of the current block, compacted to the non-empty ones
     int32_t prefix[kWave], firstA[kWave], cntA[kWave], firstB[kWave], nr[kWave], ldsbase[kWave], eslot[kWave];
@@ -761,16 +811,17 @@ struct TileWaveLds {
     unsigned long long mask[kMaskWords];  // bit t set <=> pair t is the first pair of a row
 };
 
+template <int NC>
 __host__ __device__ inline size_t tile_lds_bytes(int BR, int W, int ncomp)
 {
     size_t a = (size_t)BR * W * ncomp * sizeof(double);
     a = (a + 15) & ~(size_t)15;
-    return a + sizeof(TileWaveLds) * kWavesPerBlock + 16;
+    return a + sizeof(TileWaveLdsT<NC>) * kWavesPerBlock + 16;
 }
 
-template <int MODE, typename ACC>
+template <int MODE, typename ACC, int NC>
 __global__ void __launch_bounds__(kWave * kWavesPerBlock)
-tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ recs,
+tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ recs, const RowSetX *__restrict__ rowsx,
                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total)
 {
@@ -787,6 +838,8 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
     // only ~0.3 (scripts/ubench/lds_atomics.hip); ACC is only the type of the global output.
     double *acc = reinterpret_cast<double *>(smem);
     size_t acc_bytes = ((size_t)acc_n * sizeof(double) + 15) & ~(size_t)15;
+    using TileWaveLds = TileWaveLdsT<NC>;
+    using PairH = PairHaloT<NC>;
     TileWaveLds *wl = reinterpret_cast<TileWaveLds *>(smem + acc_bytes);
     int *next_chunk = reinterpret_cast<int *>(wl + kWavesPerBlock);
 
@@ -829,7 +882,7 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
             }
             rs.prefix = 0;
             L.ring[lane] = rs;
-            load_pair_halo(L.pair[lane], r, hidx);
+            load_pair_halo<NC>(L.pair[lane], r, hidx, rowsx);
         }
         const int incl_e = wave_scan_incl(nrows, lane);
         const int total_rows = __shfl(incl_e, kWave - 1, kWave);
@@ -922,7 +975,7 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
                         const int esB = L.eslot[rowB];
                         xB = fold_dphi(((double)kB + L.shift[rowB]) * (kTwoPi / (double)L.nr[rowB]) - L.pair[esB].phi0);
                     }
-                    const PairHalo &hA = L.pair[L.eslot[rowA]], &hB = L.pair[L.eslot[rowB]];
+                    const PairH &hA = L.pair[L.eslot[rowA]], &hB = L.pair[L.eslot[rowB]];
                     double vA[3], vB[3];
                     bool okA, okB;
                     const bool small = (!actA || fabs(xA) <= 0.5) && (!actB || fabs(xB) <= 0.5);
@@ -930,18 +983,18 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
                     if (true) { okA = okB = true; vA[0] = vA[1] = vA[2] = xA; vB[0] = vB[1] = vB[2] = xB; } else
 #endif
                     if (fastok && __all(small)) {
-                        okA = pair_value_fast<MODE>(m.tab, hA, L.z[rowA], L.sth[rowA], xA, vA);
-                        okB = pair_value_fast<MODE>(m.tab, hB, L.z[rowB], L.sth[rowB], xB, vB);
+                        okA = pair_value_fast<MODE, NC>(m.tab, hA, L.z[rowA], L.sth[rowA], xA, vA);
+                        okB = pair_value_fast<MODE, NC>(m.tab, hB, L.z[rowB], L.sth[rowB], xB, vB);
                     } else {
                         // generic path (non-uniform ln r axis or a wide azimuth span): one pair per pass of a
                         // deliberately rolled loop so that its code and registers exist only once
                         okA = okB = false;
 #pragma unroll 1
                         for (int pass = 0; pass < 2; ++pass) {
-                            const PairHalo &hh = pass ? hB : hA;
+                            const PairH &hh = pass ? hB : hA;
                             const int rw = pass ? rowB : rowA;
                             double vv[3] = {0.0, 0.0, 0.0};
-                            const bool ok = pair_value<MODE>(m.tab, hh, L.z[rw], L.sth[rw], (pass ? xB : xA) + hh.phi0, vv);
+                            const bool ok = pair_value<MODE, NC>(m.tab, hh, L.z[rw], L.sth[rw], (pass ? xB : xA) + hh.phi0, vv);
                             if (pass) { okB = ok; vB[0] = vv[0]; vB[1] = vv[1]; vB[2] = vv[2]; }
                             else { okA = ok; vA[0] = vv[0]; vA[1] = vv[1]; vA[2] = vv[2]; }
                         }

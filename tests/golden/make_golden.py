@@ -74,6 +74,42 @@ def ref_tabulated_profile(z, M, r, P_table, cosmo_dict):
     return prof
 
 
+def ref_param_profile(z, M, r, P_table, p_axes, cosmo_dict):
+    """reference ParamTabulatedProfile with the attributes set at Tabulate.py:551-561"""
+    prof = bfg.utils.ParamTabulatedProfile(model=None, cosmo=ccl_cosmo(cosmo_dict))
+    prof.p_keys = list(p_axes.keys())
+    grid = tuple([np.log(1 + z), np.log(M), np.log(r)] + [p_axes[k] for k in prof.p_keys])
+    prof.raw_input_3D = P_table
+    prof.raw_input_2D = P_table
+    prof.raw_input_z_range, prof.raw_input_M_range, prof.raw_input_r_range = grid[:3]
+    for k in prof.p_keys:
+        setattr(prof, 'raw_input_%s_range' % k, p_axes[k])
+    prof.interp3D = interpolate.RegularGridInterpolator(grid, np.log(P_table), bounds_error=False)
+    prof.interp2D = interpolate.RegularGridInterpolator(grid, np.log(P_table), bounds_error=False)
+    return prof
+
+
+def run_param_paint(name, nside, cat, eps_runner, z, M, r, p_axes, P_table, cosmo=syn.COSMO):
+    """PaintProfilesShell with per-halo property columns (HealpixRunner.py:407-425, Tabulate.py:569-621)"""
+    extra = {k: cat[k] for k in p_axes}
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=cosmo, **extra)
+    cat_used = {k: np.array(Catalog.cat[k]) for k in Catalog.cat.dtype.names}
+    Shell = bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=cosmo)
+    model = ref_param_profile(z, M, r, P_table, p_axes, cosmo)
+    out = bfg.Runners.PaintProfilesShell(Catalog, Shell, eps_runner, model, verbose=False).process()
+    otab = O.Table([np.log(1 + z), np.log(M), np.log(r)] + [p_axes[k] for k in p_axes], np.log(P_table), p_keys=list(p_axes))
+    oout = O.paint_shell(nside, cat_used, otab, eps_runner, O.Background.from_dict(cosmo))
+    print(f"{name:14s} paint     nside={nside:4d} N={cat['M'].size:5d} p_keys={list(p_axes)}  "
+          f"max|oracle-ref|/max|ref| = {np.abs(oout - out).max() / np.abs(out).max():.3e}  nonzero px = {int((out != 0).sum())}")
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), kind='paint', nside=nside, eps_runner=eps_runner, eps_model=0.0,
+                        rdelta=False, cat_M=cat_used['M'], cat_z=cat_used['z'], cat_ra=cat_used['ra'], cat_dec=cat_used['dec'],
+                        tab_z=z, tab_M=M, tab_r=r, tab_values=P_table, map_in=np.zeros(0, dtype=np.uint8),
+                        cosmo_runner=np.array([cosmo[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+                        cosmo_model=np.array([cosmo[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+                        p_keys=np.array(list(p_axes)), **{'p_axis_' + k: v for k, v in p_axes.items()},
+                        **{'cat_' + k: cat_used[k] for k in p_axes}, expected=out)
+
+
 def special_catalog(N, seed, z_lo, z_hi, logM_lo, logM_hi):
     cat = syn.make_catalog(N, seed=seed, z_lo=z_lo, z_hi=z_hi, logM_lo=logM_lo, logM_hi=logM_hi)
     # hand-placed halos: poles (exact -> clipped by the catalog class), near-pole, ra wrap-around
@@ -156,5 +192,25 @@ def main():
     run_case('c1_paint', 'paint', 128, cat, 10.0, 0.0, ax, syn.paint_table(*ax))
 
 
+def main_params():
+    pad = 1e-9
+    rng = np.random.default_rng(99)
+    cat = special_catalog(250, 21, 0.01, 0.06, 13.0, 15.3)
+    cat['cdelta'] = rng.uniform(3.0, 9.0, 250)
+    cat['cdelta'][:3] = [3.0, 9.0, 9.5]                      # on both axis ends, and outside (-> NaN -> paints nothing)
+    cat['fgas'] = rng.uniform(0.05, 0.15, 250)
+    z, M, r = syn.table_grid(cat, Nz=4, NM=5, NR=70, pad=pad)
+    base = syn.paint_table(z, M, r)
+    c_ax = np.array([3.0, 5.0, 9.0])
+    f_ax = np.linspace(0.05, 0.15, 4)
+    P4 = base[..., None] * (1 + 0.1 * (c_ax - 5.0))[None, None, None, :]
+    run_param_paint('param1_paint', 64, cat, 8.0, z, M, r, {'cdelta': c_ax}, P4)
+    P5 = P4[..., None] * (f_ax / 0.1)[None, None, None, None, :] ** 1.5
+    run_param_paint('param2_paint', 64, cat, 8.0, z, M, r, {'cdelta': c_ax, 'fgas': f_ax}, P5)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'params':
+        main_params()
+    else:
+        main()

@@ -20,6 +20,8 @@ ALGOS = [1, 0]       # 1 = tile-owned LDS accumulation (default), 0 = per-halo g
 
 
 def run(g, acc_f64=None, algo=1):
+    if algo == 0 and g['p_keys']:
+        pytest.skip("tables with property axes (p_keys) run on the tiled path only")
     r = product_runner(g, acc_f64=acc_f64)
     r.algo = algo
     return r.process()
