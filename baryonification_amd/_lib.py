@@ -93,6 +93,26 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One process must use ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as
+    the system one); if libbfgx pulled in /opt/rocm's copy first, a later `import torch` would mix the two stacks
+    and find no GPU.  So when torch is installed (not necessarily imported) its runtime is loaded first and the
+    dynamic linker resolves libbfgx's dependency to it."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load libbfgx.so once; raise ImportError (never fall back) if it is not built."""
     global _lib
@@ -101,6 +121,7 @@ def load():
             raise ImportError(
                 "baryonification_amd: %s is missing. The HIP extension IS the product (no CPU fallback). "
                 "Build it with `make -C %s` (hipcc --offload-arch=gfx950)." % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)        # AttributeError here = ABI drift between header and library

@@ -1,0 +1,122 @@
+"""BASELINE.json full-size configurations on the GPU: config 2 (1e6 halos, NSIDE 1024, BaryonifyShell) against the
+CPU oracle on the FULL input, and size-independent properties (mass conservation, linearity over catalog splits,
+shuffle invariance, agreement of the two accumulation algorithms) for configs 2 and 3 (PaintProfilesShell, NSIDE 2048)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(N, nside, paint, pad=1e-9):
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    cat = syn.make_catalog(N)
+    z, M, r = syn.table_grid(cat, pad=pad)
+    table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, 10.0, 10.0, log_values=paint)
+    dev = torch.device('cuda', 0)
+    plan = engine.ShellPlan(model, keep, nside, N, 0, torch.cuda.current_stream().cuda_stream)
+    return torch, _lib, syn, cat, axes, table, plan, dev
+
+
+def _cat_dev(torch, _lib, dev, cat, idx=None):
+    cols = {k: torch.from_numpy(np.ascontiguousarray(v if idx is None else v[idx])).to(dev) for k, v in cat.items()}
+    n = cols['M'].numel()
+    return _lib.make_catalog_dev(n, cols['M'].data_ptr(), cols['z'].data_ptr(), cols['ra'].data_ptr(), cols['dec'].data_ptr()), cols
+
+
+def test_config2_full_size_vs_oracle_and_properties(gpu):
+    N, nside = 1_000_000, 1024
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    npix = 12 * nside * nside
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+
+    def offsets(cd, acc_f64, algo):
+        plan.set_algo(algo)
+        off = torch.zeros(npix * 3, dtype=torch.float64 if acc_f64 else torch.float32, device=dev)
+        plan.offsets(cd, off.data_ptr(), acc_f64)
+        return off
+
+    def regrid(off, acc_f64):
+        out = torch.zeros(npix, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.regrid(d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), sums.cpu().numpy()
+
+    cd, keep1 = _cat_dev(torch, _lib, dev, cat)
+    off64 = offsets(cd, True, 1)
+    plan.status()
+    new_map, sums = regrid(off64, True)
+    assert np.isclose(sums[1], sums[0]) and np.isclose(new_map.sum(), hmap.sum())          # HealpixRunner.py:344-346
+
+    # (a) the CPU oracle on the full 1e6-halo input
+    from oracle import oracle as O
+    tab = O.Table(axes, table, False, 10.0)
+    ora = O.baryonify_shell(nside, hmap, cat, tab, 10.0, O.Background.from_dict(syn.COSMO))
+    assert np.abs(new_map - ora).max() <= 1e-10 * np.abs(ora).max()
+    # default accumulators (f32 pix_offsets): the stated 1e-6 * mean(map) tolerance
+    new32, s32 = regrid(offsets(cd, False, 1), False)
+    assert np.abs(new32 - ora).max() <= 1e-6 * ora.mean() and np.isclose(s32[1], s32[0])
+
+    # (b) the two accumulation algorithms agree.  pix_offsets are differences of unit vectors, so the rounding
+    # floor is absolute (~1e-16 per contribution), not relative to the ~5e-5 offsets
+    ATOL = 2e-14
+    off_a0 = offsets(cd, True, 0)
+    torch.cuda.synchronize()
+    assert (off_a0 - off64).abs().max().item() <= ATOL
+
+    # (c) linearity over a catalog split and invariance under a shuffle
+    idx = np.random.default_rng(5).permutation(N)
+    cdA, kA = _cat_dev(torch, _lib, dev, cat, idx[: N // 3])
+    cdB, kB = _cat_dev(torch, _lib, dev, cat, idx[N // 3:])
+    lin = offsets(cdA, True, 1) + offsets(cdB, True, 1)
+    torch.cuda.synchronize()
+    assert (lin - off64).abs().max().item() <= ATOL
+    cdS, kS = _cat_dev(torch, _lib, dev, cat, idx)
+    sh = offsets(cdS, True, 1)
+    torch.cuda.synchronize()
+    assert (sh - off64).abs().max().item() <= ATOL
+    # pair census: tile path == per-halo path == number of (halo, pixel) pairs the oracle visits on a sample
+    plan.set_algo(1); n1 = plan.count_pairs(cd, True)
+    plan.set_algo(0); n0 = plan.count_pairs(cd, True)
+    assert n0 == n1 > 5e7
+    plan.close()
+
+
+def test_config3_paint_full_size_properties(gpu):
+    N, nside = 1_000_000, 2048
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=True)
+    npix = 12 * nside * nside
+
+    def paint(cd, algo, acc_f64=True):
+        plan.set_algo(algo)
+        out = torch.zeros(npix, dtype=torch.float64 if acc_f64 else torch.float32, device=dev)
+        plan.paint(cd, out.data_ptr(), acc_f64)
+        return out
+
+    cd, keep1 = _cat_dev(torch, _lib, dev, cat)
+    full = paint(cd, 1)
+    plan.status()
+    torch.cuda.synchronize()
+    scale = full.abs().max().item()
+    assert scale > 0 and torch.isfinite(full).all().item() and full.min().item() >= 0
+    assert (paint(cd, 0) - full).abs().max().item() <= 1e-12 * scale                       # algorithms agree
+    idx = np.random.default_rng(6).permutation(N)
+    cdA, kA = _cat_dev(torch, _lib, dev, cat, idx[: N // 2])
+    cdB, kB = _cat_dev(torch, _lib, dev, cat, idx[N // 2:])
+    assert (paint(cdA, 1) + paint(cdB, 1) - full).abs().max().item() <= 1e-12 * scale       # linearity (Parallelize.py:318)
+    f32 = paint(cd, 1, acc_f64=False)
+    assert (f32.double() - full).abs().max().item() <= 1e-5 * scale                         # stated fp32 tolerance
+    # oracle on a 20 000-halo sample of the same catalog
+    from oracle import oracle as O
+    sub = {k: v[:20000] for k, v in cat.items()}
+    with np.errstate(divide='ignore'):
+        tab = O.Table(axes, np.log(table))
+    ora = O.paint_shell(nside, sub, tab, 10.0, O.Background.from_dict(syn.COSMO))
+    cdS, kS = _cat_dev(torch, _lib, dev, cat, np.arange(20000))
+    got = paint(cdS, 1).cpu().numpy()
+    assert np.abs(got - ora).max() <= 1e-10 * np.abs(ora).max()
+    plan.close()
