@@ -238,7 +238,7 @@ static void build_tiling(int64_t nside, int &BR, int &W, std::vector<int32_t> &t
     auto pow2_floor = [](int64_t v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
     W = std::max(16, std::min(64, pow2_floor(std::max<int64_t>(1, nside / 2))));
     BR = std::max(4, std::min(32, pow2_floor(std::max<int64_t>(1, nside / 8))));
-    if (const char *e = std::getenv("BFGX_TILE_W")) W = std::max(4, std::min(128, std::atoi(e)));     // tuning knobs
+    if (const char *e = std::getenv("BFGX_TILE_W")) W = std::max(4, std::min(64, std::atoi(e)));      // tuning knobs (W <= 64: kMaskWords)
     if (const char *e = std::getenv("BFGX_TILE_BR")) BR = std::max(1, std::min(64, std::atoi(e)));
     const int64_t nrings = 4 * nside - 1;
     const int nbands = (int)((nrings + BR - 1) / BR);

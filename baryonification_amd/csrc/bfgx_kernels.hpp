@@ -331,7 +331,8 @@ struct Tiling {
     const int32_t *tile_band;             // [ntiles]
 };
 
-__device__ inline int tile_ks(int j, int nr, int nphi) { return (int)(((int64_t)j * nr + nphi - 1) / nphi); }
+// first ring-local pixel of azimuth slice j: ceil(j nr / nphi); j nr < 2^31 for nside <= 8192
+__device__ inline int tile_ks(int j, int nr, int nphi) { return (int)(((unsigned)j * (unsigned)nr + (unsigned)nphi - 1u) / (unsigned)nphi); }
 
 __device__ inline int ring_len(const Hpx &h, int ring)
 {
@@ -792,7 +793,7 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
 // (algo 1, default) one workgroup per tile: accumulators live in LDS, entries (halos touching the tile) are
 // taken 16 at a time by each wave: lanes = entries -> lanes = ring rows (clipped to the tile) -> lanes = pairs.
 constexpr int kChunk = 16;
-constexpr int kMaskWords = 130;          // 64 rows x up to 128 pixels = 8192 pairs -> 128 words (+2 spare)
+constexpr int kMaskWords = 66;           // 64 rows x up to 64 pixels (W <= 64) = 4096 pairs -> 64 words (+2 spare)
 
 struct RingSlot {                    // ring-phase view of one entry
     double z0, xa, cosr, phi0;

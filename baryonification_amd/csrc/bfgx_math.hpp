@@ -168,6 +168,34 @@ __device__ inline double atan2_generic(double y, double x)
     return (y < 0.0) ? -a : a;
 }
 
+// acos(c) for |c| <= 1, branch-free: fdlibm's rational approximation of asin on [0, 0.5] with the
+// half-angle identity acos(c) = 2 asin(sqrt((1 - c) / 2)) beyond (a few ulp)
+__device__ inline double acos_fast(double c)
+{
+    const double ac = fabs(c);
+    const bool big = ac > 0.5;
+    const double z = big ? 0.5 * (1.0 - ac) : c * c;
+    double p = 3.47933107596021167570e-05;
+    p = __builtin_fma(p, z, 7.91534994289814532176e-04);
+    p = __builtin_fma(p, z, -4.00555345006794114027e-02);
+    p = __builtin_fma(p, z, 2.01212532134862925881e-01);
+    p = __builtin_fma(p, z, -3.25565818622400915405e-01);
+    p = __builtin_fma(p, z, 1.66666666666666657415e-01);
+    double q = 7.70381505559019352791e-02;
+    q = __builtin_fma(q, z, -6.88283971605453293030e-01);
+    q = __builtin_fma(q, z, 2.02094576023350569471e+00);
+    q = __builtin_fma(q, z, -2.40339491173441421878e+00);
+    q = __builtin_fma(q, z, 1.0);
+    const double R = z * p * fast_rcp(q);
+    const double zs = z > 0.0 ? z : 1.0;
+    const double s = big ? zs * fast_rsq(zs) : c;                           // sqrt(z) or c
+    const double as = __builtin_fma(s, R, s);                               // asin(s)
+    const double kHalfPi_ = 1.570796326794896619231321691639751442099, kPi_ = 3.141592653589793238462643383279502884197;
+    const double r_small = kHalfPi_ - as;
+    const double r_big = (c > 0.0) ? 2.0 * as : kPi_ - 2.0 * as;
+    return big ? ((z > 0.0) ? r_big : (c > 0.0 ? 0.0 : kPi_)) : r_small;
+}
+
 // sqrt(x) for normal x > 0 via the rsq seed; returns 0 for x <= 0
 __device__ inline double fast_sqrt(double x)
 {

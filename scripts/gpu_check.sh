@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick GPU loop: parity tests, then bench lines (both algos optional)
-python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; tail -4 gpurun_out/pytest_gpu.log
+if [ -z "$NOTEST" ]; then python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; tail -4 gpurun_out/pytest_gpu.log; fi
 for ARGS in "$@"; do
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline $ARGS 2>&1 | grep -v amdgpu.ids | python -c "
 import sys,json
