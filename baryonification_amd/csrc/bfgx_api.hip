@@ -232,12 +232,13 @@ static int ensure_entry_capacity(bfgx_plan *p, const bfgx_catalog *c)
 }
 
 // host-side construction of the tiling tables for one nside
-static void build_tiling(int64_t nside, int &BR, int &W, std::vector<int32_t> &tile0, std::vector<int32_t> &nphi,
+static void build_tiling(int64_t nside, bool paint, int &BR, int &W, std::vector<int32_t> &tile0, std::vector<int32_t> &nphi,
                          std::vector<int32_t> &nrmin, std::vector<int32_t> &tband)
 {
     auto pow2_floor = [](int64_t v) { int p = 1; while (2 * p <= v) p *= 2; return p; };
     W = std::max(16, std::min(64, pow2_floor(std::max<int64_t>(1, nside / 2))));
-    BR = std::max(4, std::min(32, pow2_floor(std::max<int64_t>(1, nside / 8))));
+    // the painted map needs 8 B of LDS per pixel, pix_offsets 24 B: taller tiles for painting (fewer duplicated ring phases)
+    BR = std::max(4, std::min(paint ? 64 : 32, pow2_floor(std::max<int64_t>(1, nside / 8))));
     if (const char *e = std::getenv("BFGX_TILE_W")) W = std::max(4, std::min(64, std::atoi(e)));      // tuning knobs (W <= 64: kMaskWords)
     if (const char *e = std::getenv("BFGX_TILE_BR")) BR = std::max(1, std::min(64, std::atoi(e)));
     const int64_t nrings = 4 * nside - 1;
@@ -425,7 +426,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
     {   // tiling tables and halo -> tile binning workspace
         int BR, W;
         std::vector<int32_t> tile0, nphi, nrmin, tband;
-        build_tiling(nside, BR, W, tile0, nphi, nrmin, tband);
+        build_tiling(nside, t.log_values != 0, BR, W, tile0, nphi, nrmin, tband);
         Tiling &T = p->tiling;
         T.BR = BR; T.W = W; T.nbands = (int)nphi.size(); T.ntiles = (int)tband.size();
         const void *dv = nullptr;
