@@ -400,6 +400,8 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
     m.md_runner = model->massdef_runner;
     m.md_model = model->massdef_model;
     m.eps_runner = model->eps_runner;
+    m.same_model = (std::memcmp(&m.bg_runner, &m.bg_model, sizeof(Background)) == 0 && m.md_runner.Delta == m.md_model.Delta &&
+                    m.md_runner.rho_type == m.md_model.rho_type) ? 1 : 0;
     {
         std::vector<double> knots, coef;
         da_spline(m.bg_runner, knots, coef);

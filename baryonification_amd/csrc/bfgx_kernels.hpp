@@ -262,6 +262,7 @@ struct DevModel {
     Background bg_runner, bg_model;
     bfgx_massdef md_runner, md_model;
     double eps_runner;
+    int32_t same_model;                   // model cosmology / mass definition identical to the runner's
     const double *da_coef;                // device, [kDaKnots-1][4]
     double da_step;
 };
@@ -404,34 +405,41 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     }
     const double radius = R * m.eps_runner / D;                           // :305
 
-    // hp.ang2vec(ra, dec, lonlat=True)  (:303)
+    // hp.ang2vec(ra, dec, lonlat=True) (:303) followed by query_disc's pointing(vec) (:306): the pointing of the unit
+    // vector (sin t cos p, sin t sin p, cos t) is (t, p mod 2 pi) again, so the two atan2 of the round trip are skipped
+    // (they return theta and phi to within an ulp)
     const double theta = kHalfPi - dec[j] * kDeg2Rad;
     const double phi = ra[j] * kDeg2Rad;
-    const double st = sin(theta);
-    const double vx = st * cos(phi), vy = st * sin(phi), vz = cos(theta);
-    // query_disc's pointing(vec) (:306)
-    const double thq = atan2(sqrt(vx * vx + vy * vy), vz);
-    double phq = (vx == 0.0 && vy == 0.0) ? 0.0 : atan2(vy, vx);
-    if (phq < 0) phq += kTwoPi;
-    r.z0 = cos(thq);
-    r.s0 = sin(thq);
+    double st, ct, sp, cp;
+    sincos(theta, &st, &ct);
+    sincos(phi, &sp, &cp);
+    const double thq = theta;
+    double phq = phi - kTwoPi * floor(phi * kInvTwoPi);
+    if (phq >= kTwoPi) phq -= kTwoPi;
+    if (st == 0.0) phq = 0.0;
+    r.z0 = ct;
+    r.s0 = st;
     r.xa = 1.0 / sqrt((1.0 - r.z0) * (1.0 + r.z0));
     r.phi0 = phq;
-    r.cph0 = cos(phq); r.sph0 = sin(phq);
+    r.cph0 = cp; r.sph0 = sp;
     r.theta = theta; r.phi = phi;
     r.D = D; r.a = a;
 
     const int64_t nl4 = 4 * h.nside;
     bool pole = false;
+    double sr_ = 0.0;
     if (radius >= kPi) {
         r.cosr = -1.0; r.irmin = (int32_t)nl4; r.irmax = 0; r.rfirst = 1; r.rlast = (int32_t)(nl4 - 1);
         pole = true;
     } else {
-        r.cosr = cos(radius);
+        double cr_;
+        sincos(radius, &sr_, &cr_);
+        r.cosr = cr_;
         const double rlat1 = thq - radius;
-        int64_t irmin = ring_above(h, cos(rlat1)) + 1;
         const double rlat2 = thq + radius;
-        int64_t irmax = ring_above(h, cos(rlat2));
+        // cos(theta -+ radius) by the addition theorem (no further libm calls)
+        int64_t irmin = ring_above(h, ct * cr_ + st * sr_) + 1;
+        int64_t irmax = ring_above(h, ct * cr_ - st * sr_);
         if (irmax > nl4 - 1) irmax = nl4 - 1;
         r.irmin = (int32_t)irmin; r.irmax = (int32_t)irmax;
         r.rfirst = (int32_t)(((rlat1 <= 0) && (irmin > 1)) ? 1 : irmin);
@@ -440,7 +448,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     }
     // azimuthal extent of the disc (for tile binning): half-width asin(sin r / sin theta0) when no pole inside
     {
-        const double sr = sin(fmin(radius, kHalfPi));
+        const double sr = (radius >= kHalfPi) ? 1.0 : sr_;
         r.allphi = (pole || radius >= kHalfPi || !(sr < 0.999 * r.s0)) ? 1 : 0;
         const double dmax = r.allphi ? kPi : asin(sr / r.s0);
         r.flo = (phq - dmax) * kInvTwoPi;
@@ -448,7 +456,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     }
 
     // model-side radius and table coordinates (BaryonCorrection.py:364-370, Tabulate.py:279-283)
-    const double Rmod = dev_radius(m.bg_model, m.md_model, M_j, a) / a;
+    const double Rmod = (m.same_model ? R : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
     r.rcut = m.tab.eps_model * Rmod;
     r.inv_a = 1.0 / a;
     const double x0 = log(1.0 / a), x1 = log(M_j);
@@ -1139,28 +1147,45 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
         atomicAdd(map_out + st_t + k_t, v);                    // far target (rare)
     };
 
+    // source pixels of the tile, 8 per thread; the loads of pixel i+1 are issued before pixel i is processed
+    struct Src { int ring, k, nr; bool shf, ok; int64_t p; double val; ACC o0, o1, o2; };
+    auto fetch = [&](int idx) {
+        Src sx;
+        sx.ok = false; sx.ring = 0; sx.k = 0; sx.nr = 1; sx.shf = false; sx.p = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (ACC)0;
+        if (idx < T.BR * T.W) {
+            const int r = idx / T.W, x = idx - r * T.W;
+            const int ring = i0 + r;
+            if (ring < i1) {
+                int64_t st, nr64; bool shf;
+                ring_info_small(h, ring, st, nr64, shf);
+                const int nr = (int)nr64;
+                const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
+                if (x < ke - ks) {
+                    sx.ok = true; sx.ring = ring; sx.k = ks + x; sx.nr = nr; sx.shf = shf; sx.p = st + sx.k;
+                    sx.val = map_in[sx.p];
+                    sx.o0 = offsets[3 * sx.p + 0]; sx.o1 = offsets[3 * sx.p + 1]; sx.o2 = offsets[3 * sx.p + 2];
+                }
+            }
+        }
+        return sx;
+    };
+    Src nxt = fetch(tid);
     for (int idx = tid; idx < T.BR * T.W; idx += 256) {
-        const int r = idx / T.W, x = idx - r * T.W;
-        const int ring = i0 + r;
-        if (ring >= i1) continue;
-        int64_t st, nr64; bool shf;
-        ring_info_small(h, ring, st, nr64, shf);
-        const int nr = (int)nr64;
-        const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
-        if (x >= ke - ks) continue;
-        const int k = ks + x;
-        const int64_t p = st + k;
-        const double val = map_in[p];
-        if (!(val > 0.0)) continue;                                          // HealpixRunner.py:335
+        const Src cur = nxt;
+        nxt = fetch(idx + 256);
+        if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
+        const int ring = cur.ring, k = cur.k, nr = cur.nr;
+        const bool shf = cur.shf;
+        const double val = cur.val;
         double z, sth;
         ring_z_sth(h, ring, z, sth);
         const double dphi0 = kTwoPi / (double)nr;
         const double phi = ((double)k + (shf ? 0.5 : 0.0)) * dphi0;
         double s, c;
         sincos_bounded(phi, s, c);
-        const double nx = sth * c + (double)offsets[3 * p + 0];              // :333
-        const double ny = sth * s + (double)offsets[3 * p + 1];
-        const double nz = z + (double)offsets[3 * p + 2];
+        const double nx = sth * c + (double)cur.o0;                          // :333
+        const double ny = sth * s + (double)cur.o1;
+        const double nz = z + (double)cur.o2;
         // (theta, phi) of the displaced pixel (:334) as small corrections to the pixel's own angles:
         //   in the frame rotated by -phi:  x' = n.e_r, y' = n.e_phi;  dphi = atan2(y', x');
         //   sin(dtheta) = sin(theta_n) z - cos(theta_n) sin(theta)
