@@ -179,7 +179,7 @@ static int launch_scatter(bfgx_plan *p, int64_t n, ACC *out, int64_t *counts)
     const unsigned grid = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     hipLaunchKernelGGL((halo_scatter_kernel<MODE, ACC>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, p->stream,
-                       p->model, p->hpx, n, (const HaloRec *)p->recs, out, counts);
+                       make_pair_table(p->model.tab), p->hpx, n, (const HaloRec *)p->recs, out, counts);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -193,7 +193,7 @@ static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out)
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kWavesPerBlock), lds, p->stream,
-                       p->model, p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
+                       make_pair_table(p->model.tab), p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
                        (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;

@@ -257,6 +257,22 @@ struct DevTable {
     double r0, inv_dr, r1;                // first / last node of the ln r axis
 };
 
+// what the per-pair read-out needs of the table (kept small: it travels in scalar registers)
+struct PairTable {
+    const double *values, *raxis;         // table values (r innermost) and the ln r axis
+    double r0, inv_dr, r1;
+    int32_t nr, r_uniform, rdelta, _pad;
+};
+
+__host__ __device__ inline PairTable make_pair_table(const DevTable &t)
+{
+    PairTable p;
+    p.values = t.values; p.raxis = t.axis[2];
+    p.r0 = t.r0; p.inv_dr = t.inv_dr; p.r1 = t.r1;
+    p.nr = t.n[2]; p.r_uniform = t.r_uniform; p.rdelta = t.rdelta; p._pad = 0;
+    return p;
+}
+
 struct DevModel {
     DevTable tab;
     Background bg_runner, bg_model;
@@ -571,9 +587,9 @@ template <typename ACC> __device__ inline void atomic_accumulate(ACC *p, double 
 
 // linear read-out along ln r of the 4 (z,M)-corner rows; NaN outside the axis (scipy RGI semantics)
 template <int NC>
-__device__ inline double radial_readout(const DevTable &t, const int32_t *rowoff, const double *w, double lx)
+__device__ inline double radial_readout(const PairTable &t, const int32_t *rowoff, const double *w, double lx)
 {
-    const int n = t.n[2];
+    const int n = t.nr;
     if (!(lx >= t.r0) || !(lx <= t.r1)) return __builtin_nan("");
     int i;
     double tr;
@@ -582,7 +598,7 @@ __device__ inline double radial_readout(const DevTable &t, const int32_t *rowoff
         i = min((int)u, n - 2);
         tr = u - (double)i;
     } else {
-        const double *g = t.axis[2];
+        const double *g = t.raxis;
         int lo = 0, hi = n - 1;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lx >= g[mid]) lo = mid; else hi = mid; }
         i = lo;
@@ -627,7 +643,7 @@ __device__ inline void load_pair_halo(PairHaloT<NC> &p, const HaloRec &r, int hi
 // One (halo, pixel) pair.  Returns false when the pair contributes nothing.
 //   MODE_OFFSETS: v[0..2] = nw_vec - vec (HealpixRunner.py:314-328);  MODE_PAINT: v[0] = Paint (:441-442)
 template <int MODE, int NC>
-__device__ inline bool pair_value(const DevTable &tab, const PairHaloT<NC> &r, double z, double sth, double phi_pix, double v[3])
+__device__ inline bool pair_value(const PairTable &tab, const PairHaloT<NC> &r, double z, double sth, double phi_pix, double v[3])
 {
     // pixel unit vector in the frame rotated by -phi0 about the polar axis: halo at (s0, 0, z0)
     double sd, cd;
@@ -662,7 +678,7 @@ __device__ inline bool pair_value(const DevTable &tab, const PairHaloT<NC> &r, d
 // Branch-free (fully predicated) variant for the common case: uniform ln r axis and |dphi| <= 0.5, so that two
 // pairs per lane can be interleaved by the scheduler.  x = azimuth difference already folded to (-pi, pi].
 template <int MODE, int NC>
-__device__ inline bool pair_value_fast(const DevTable &tab, const PairHaloT<NC> &r, double z, double sth, double x, double v[3])
+__device__ inline bool pair_value_fast(const PairTable &tab, const PairHaloT<NC> &r, double z, double sth, double x, double v[3])
 {
     double sd, cd;
     sincos_small(x, sd, cd);
@@ -676,7 +692,7 @@ __device__ inline bool pair_value_fast(const DevTable &tab, const PairHaloT<NC> 
     const double lx = __builtin_fma(0.5, fast_log(r2s), r.lnoff);
     ok = ok && (lx >= tab.r0) && (lx <= tab.r1);                                    // RGI fill_value = nan
     const double u = (lx - tab.r0) * tab.inv_dr;
-    const int i = max(0, min((int)u, tab.n[2] - 2));
+    const int i = max(0, min((int)u, tab.nr - 2));
     const double tr = u - (double)i, t0 = 1.0 - tr;
     double d = 0.0;
 #if BFGX_ABLATE == 1      // timing-only build: no table loads
@@ -734,7 +750,7 @@ __device__ inline int wave_scan_incl(int v, int lane)
 
 template <int MODE, typename ACC>
 __global__ void __launch_bounds__(kWave * kWavesPerBlock)
-halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict__ recs,
+halo_scatter_kernel(PairTable pt, Hpx h, int64_t nhalo, const HaloRec *__restrict__ recs,
                     ACC *__restrict__ out, int64_t *__restrict__ counts)
 {
     __shared__ RowLds lds[kWavesPerBlock];
@@ -756,7 +772,7 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
             ring_info_small(h, r.fb_ring[lane], st, nr, sh);
             ring_z_sth(h, r.fb_ring[lane], z, sth);
             const double phi_pix = ((double)r.fb_k[lane] + (sh ? 0.5 : 0.0)) * (kTwoPi / (double)nr);
-            if (pair_value<MODE, kNC>(m.tab, ph, z, sth, phi_pix, v)) {
+            if (pair_value<MODE, kNC>(pt, ph, z, sth, phi_pix, v)) {
                 ACC *o = out + NCOMP * (st + r.fb_k[lane]);
                 for (int c = 0; c < NCOMP; ++c) atomic_accumulate(o + c, v[c]);
             }
@@ -785,7 +801,7 @@ halo_scatter_kernel(DevModel m, Hpx h, int64_t nhalo, const HaloRec *__restrict_
                     if (k >= nrr) k -= nrr;
                     const double phi_pix = ((double)k + L.shift[row]) * (kTwoPi / (double)nrr);
                     double v[3];
-                    if (pair_value<MODE, kNC>(m.tab, ph, L.z[row], L.sth[row], phi_pix, v)) {
+                    if (pair_value<MODE, kNC>(pt, ph, L.z[row], L.sth[row], phi_pix, v)) {
                         ACC *o = out + NCOMP * (L.start[row] + k);
                         for (int c = 0; c < NCOMP; ++c) atomic_accumulate(o + c, v[c]);
                     }
@@ -830,7 +846,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int BR, int W, int ncomp)
 
 template <int MODE, typename ACC, int NC>
 __global__ void __launch_bounds__(kWave * kWavesPerBlock)
-tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ recs, const RowSetX *__restrict__ rowsx,
+tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ recs, const RowSetX *__restrict__ rowsx,
                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total)
 {
@@ -961,7 +977,7 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
 
                 // ---- lanes = (halo, pixel) pairs, two per lane per trip
                 const unsigned long long le = lt | (1ull << lane);
-                const bool fastok = m.tab.r_uniform != 0;
+                const bool fastok = pt.r_uniform != 0;
                 int base = 0;                                      // rows started before the current 64 pairs
                 for (int T0 = 0; T0 < (BFGX_ABLATE == 4 ? 0 : total); T0 += 2 * kWave) {
                     const unsigned long long mA = L.mask[T0 >> 6], mB = L.mask[(T0 >> 6) + 1];
@@ -992,8 +1008,8 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
                     if (true) { okA = okB = true; vA[0] = vA[1] = vA[2] = xA; vB[0] = vB[1] = vB[2] = xB; } else
 #endif
                     if (fastok && __all(small)) {
-                        okA = pair_value_fast<MODE, NC>(m.tab, hA, L.z[rowA], L.sth[rowA], xA, vA);
-                        okB = pair_value_fast<MODE, NC>(m.tab, hB, L.z[rowB], L.sth[rowB], xB, vB);
+                        okA = pair_value_fast<MODE, NC>(pt, hA, L.z[rowA], L.sth[rowA], xA, vA);
+                        okB = pair_value_fast<MODE, NC>(pt, hB, L.z[rowB], L.sth[rowB], xB, vB);
                     } else {
                         // generic path (non-uniform ln r axis or a wide azimuth span): one pair per pass of a
                         // deliberately rolled loop so that its code and registers exist only once
@@ -1003,7 +1019,7 @@ tile_scatter_kernel(DevModel m, Hpx h, Tiling T, const HaloRec *__restrict__ rec
                             const PairH &hh = pass ? hB : hA;
                             const int rw = pass ? rowB : rowA;
                             double vv[3] = {0.0, 0.0, 0.0};
-                            const bool ok = pair_value<MODE, NC>(m.tab, hh, L.z[rw], L.sth[rw], (pass ? xB : xA) + hh.phi0, vv);
+                            const bool ok = pair_value<MODE, NC>(pt, hh, L.z[rw], L.sth[rw], (pass ? xB : xA) + hh.phi0, vv);
                             if (pass) { okB = ok; vB[0] = vv[0]; vB[1] = vv[1]; vB[2] = vv[2]; }
                             else { okA = ok; vA[0] = vv[0]; vA[1] = vv[1]; vA[2] = vv[2]; }
                         }
