@@ -65,3 +65,28 @@ def paint_table(z, M, r, cosmo=COSMO):
     Rc = _Rc(z, M, cosmo)[:, :, None]
     x = r[None, None, :] / Rc
     return np.exp(-x - 2.0 * np.log1p(x))
+
+
+# examples/default_config.npy of the reference (decoded in SURVEY.md section 5), cdelta = 7, proj_cutoff = 50
+S19_PARAMS = dict(epsilon=4.0, theta_ej=4.0, theta_co=0.1, M_c=1e14, mu_beta=0.1, gamma=2.5, delta=7.0, eta=0.3, eta_delta=0.1,
+                  tau=-1.5, tau_delta=0.0, A=0.055, M1=3e11, epsilon_h=0.015, a=0.3, n=2.0, p=0.3, q=0.707, cdelta=7.0,
+                  alpha_nt=0.2, nu_nt=0.5, gamma_nt=0.5, cutoff=1000.0, proj_cutoff=50.0, mu_theta_ej=0.1, mu_theta_co=0.0,
+                  M_theta_ej=5e13, M_theta_co=5e13)
+
+
+def s19_displacement_table(z, M, r, cosmo=COSMO, params=None):
+    """Benchmark table (ii): d(z, M, r) from the Schneider19 one-halo DMO/DMB profiles through the GPU table builders
+    (Baryonification2D.setup_interpolator's inner loop: get_masses x2 + displacement_rows per redshift)."""
+    import warnings
+    from . import tables
+    from .Profiles import Baryonification2D, DarkMatterBaryon, DarkMatterOnly
+    par = dict(S19_PARAMS if params is None else params)
+    c = Cosmology.from_dict(cosmo)
+    model = Baryonification2D(DarkMatterOnly(**par), DarkMatterBaryon(**par), c, epsilon_max=20)
+    out = np.zeros((z.size, M.size, r.size))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for j, zj in enumerate(z):
+            a = 1.0 / (1.0 + zj)
+            out[j], _ = tables.displacement_rows(r, model.get_masses(model.DMO, r, M, a), model.get_masses(model.DMB, r, M, a))
+    return out

@@ -41,6 +41,9 @@ def parse():
     ap.add_argument('--algo', type=int, default=1, help='1 = LDS tiles (default), 0 = per-halo global atomics')
     ap.add_argument('--mode', choices=['baryonify', 'paint'], default='baryonify',
                     help="'paint' = PaintProfilesShell (BASELINE config 3 with --nside 2048); not the headline metric")
+    ap.add_argument('--table', choices=['closed-form', 's19'], default='closed-form',
+                    help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
+                         "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample')
     return ap.parse_args()
@@ -92,7 +95,10 @@ def main():
     else:                                                # shards differ: analytic support of the catalog
         z, M, r = np.geomspace(0.2, 0.3, 10), np.geomspace(1e12, 1e15, 10), np.geomspace(1e-3, 3e2, 500)
     paint = args.mode == 'paint'
-    table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
+    if args.table == 's19' and not paint:
+        table = syn.s19_displacement_table(z, M, r)
+    else:
+        table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
     axes = [np.log(1 + z), np.log(M), np.log(r)]
     hmap = np.zeros(npix) if paint else syn.make_map(nside)
     model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, args.eps, args.eps,
@@ -173,8 +179,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config %d: %d-halo synthetic catalog per GPU (SURVEY 8d seeds), %s, "
-                                   "NSIDE=%d shell, epsilon_max=%g, 10x10x500 closed-form %s table" % (
+                                   "NSIDE=%d shell, epsilon_max=%g, 10x10x500 %s %s table" % (
                                        3 if paint else 2, args.halos, "PaintProfilesShell" if paint else "BaryonifyShell", nside, args.eps,
+                                       "Schneider19 (K4-K6 built)" if (args.table == 's19' and not paint) else "closed-form",
                                        "profile" if paint else "displacement"),
                        "halos_per_gpu": args.halos, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
