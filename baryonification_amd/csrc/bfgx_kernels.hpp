@@ -444,7 +444,13 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     const int64_t nl4 = 4 * h.nside;
     bool pole = false;
     double sr_ = 0.0;
-    if (radius >= kPi) {
+    // a halo with a non-finite / non-positive disc radius or position can touch no pixel: give it an empty row range
+    // (this also keeps every ring index below in range whatever the input columns hold)
+    const bool bad = !(radius > 0.0) || !isfinite(radius) || !(theta >= 0.0) || !(theta <= kPi) || !isfinite(phi);
+    if (bad) {
+        r.cosr = 1.0; r.irmin = 1; r.irmax = 0; r.rfirst = 1; r.rlast = 0;
+        r.z0 = 1.0; r.s0 = 0.0; r.xa = 1.0; r.phi0 = 0.0; r.cph0 = 1.0; r.sph0 = 0.0;
+    } else if (radius >= kPi) {
         r.cosr = -1.0; r.irmin = (int32_t)nl4; r.irmax = 0; r.rfirst = 1; r.rlast = (int32_t)(nl4 - 1);
         pole = true;
     } else {
@@ -529,7 +535,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     // <4-pixel fallback (HealpixRunner.py:309-310): only discs of a few pixels can qualify -> exact census
     r.fb = 0; r._pad = 0;
     for (int q = 0; q < 4; ++q) { r.fb_ring[q] = 0; r.fb_k[q] = 0; }
-    if (fallback4 && (r.rlast - r.rfirst) < 8) {
+    if (fallback4 && !bad && (r.rlast - r.rfirst) < 8) {
         int total = 0;
         for (int ring = r.rfirst; ring <= r.rlast && total < 4; ++ring) {
             RowSpan s;

@@ -128,3 +128,20 @@ def test_tile_binning_is_complete(gpu, nside):
     cd2 = _lib.make_catalog_dev(400, t2['M'].data_ptr(), t2['z'].data_ptr(), t2['ra'].data_ptr(), t2['dec'].data_ptr())
     assert plan.count_pairs(cd2, fallback4=True) == int(counts.sum())
     plan.close()
+
+
+def test_invalid_halos_are_ignored(gpu):
+    """NaN / non-positive masses, |dec| > 90 or NaN positions touch no pixel (and must never fault the GPU)"""
+    g = load_golden('lowz_baryonify')
+    ref = run(g, True, 1)
+    n = g['cat']['M'].size
+    for k in g['cat']:
+        g['cat'][k] = np.concatenate([g['cat'][k], g['cat'][k][:6]])
+    g['cat']['M'][n:n + 2] = [np.nan, -1e14]
+    g['cat']['dec'][n + 2] = 91.0
+    g['cat']['ra'][n + 3] = np.nan
+    g['cat']['z'][n + 4] = np.nan
+    g['cat']['M'][n + 5] = 0.0
+    for algo in ALGOS:
+        out = run(g, True, algo)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
