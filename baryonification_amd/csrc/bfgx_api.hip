@@ -85,7 +85,9 @@ struct bfgx_plan {
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
     Tiling tiling;
-    int32_t *tile_count = nullptr, *tile_start = nullptr, *tile_cursor = nullptr, *entries = nullptr, *overflow = nullptr;
+    int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_start = nullptr, *tile_cursor = nullptr, *entries = nullptr,
+            *overflow = nullptr;
+    TileRef *tref = nullptr;
     unsigned long long *pair_total = nullptr;
     int64_t capacity = 0;
     // optional per-kernel HIP-event timing (bfgx_plan_timing_*)
@@ -141,9 +143,10 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
     const unsigned grid = (unsigned)((c->n + 255) / 256);
     KernelTimer kt(p, BFGX_K_PREP);
     int32_t *tc = bin ? p->tile_count : (int32_t *)nullptr;
+    int32_t *tcb = bin ? p->tile_count_b : (int32_t *)nullptr;
 #define BFGX_PREP(NCV)                                                                                              \
     hipLaunchKernelGGL(halo_prep_kernel<NCV>, dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
-                       c->ra, c->dec, c->extra[0], c->extra[1], p->recs, p->rowsx, fallback4, p->tiling, tc)
+                       c->ra, c->dec, c->extra[0], c->extra[1], p->recs, p->rowsx, fallback4, p->tiling, tc, tcb, p->tref)
     if (p->NC == 4) BFGX_PREP(4);
     else if (p->NC == 8) BFGX_PREP(8);
     else BFGX_PREP(16);
@@ -156,17 +159,17 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
 static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4)
 {
     const size_t nt = (size_t)p->tiling.ntiles;
-    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * (nt + 1), p->stream));
-    HIP_TRY(hipMemsetAsync(p->tile_cursor, 0, sizeof(int32_t) * nt, p->stream));
+    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 3 * (nt + 1), p->stream));     // count, count_b, cursor
     if (int rc = launch_prep(p, c, fallback4, true)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, p->tile_count, p->tile_start);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, p->tile_count,
+                       p->tile_count_b, p->tile_start);
     HIP_TRY(hipGetLastError());
     if (c->n > 0) {
         const unsigned grid = (unsigned)((c->n + 255) / 256);
-        hipLaunchKernelGGL(tile_fill_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
-                           (const HaloRec *)p->recs, (const int32_t *)p->tile_start, p->tile_cursor, p->entries,
-                           p->capacity, p->overflow);
+        hipLaunchKernelGGL(tile_place_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
+                           (const HaloRec *)p->recs, (const TileRef *)p->tref, (const int32_t *)p->tile_start,
+                           (const int32_t *)p->tile_count, p->tile_cursor, p->entries, p->capacity, p->overflow);
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;
@@ -224,9 +227,9 @@ static int ensure_entry_capacity(bfgx_plan *p, const bfgx_catalog *c)
     HIP_TRY(hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream));
     HIP_TRY(hipMemsetAsync(p->tile_cursor, 0, sizeof(int32_t) * (size_t)p->tiling.ntiles, p->stream));
     const unsigned grid = (unsigned)((c->n + 255) / 256);
-    hipLaunchKernelGGL(tile_fill_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
-                       (const HaloRec *)p->recs, (const int32_t *)p->tile_start, p->tile_cursor, p->entries,
-                       p->capacity, p->overflow);
+    hipLaunchKernelGGL(tile_place_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
+                       (const HaloRec *)p->recs, (const TileRef *)p->tref, (const int32_t *)p->tile_start,
+                       (const int32_t *)p->tile_count, p->tile_cursor, p->entries, p->capacity, p->overflow);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -442,17 +445,20 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         T.tile_band = (const int32_t *)dv;
         if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
         p->capacity = 8 * max_halos + 4096;
+        if (const char *e = std::getenv("BFGX_ENTRY_CAP")) p->capacity = std::max<int64_t>(16, std::atoll(e));   // tests: force regrowth
         auto dalloc = [&](size_t bytes, void **ptr) {
             if (hipMalloc(ptr, bytes) != hipSuccess) return 1;
             p->owned.push_back(*ptr);
             return 0;
         };
-        void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr;
-        if (dalloc(sizeof(int32_t) * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
-            dalloc(sizeof(int32_t) * (T.ntiles + 1), &d2) || dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) ||
-            dalloc(sizeof(int32_t), &d4) || dalloc(sizeof(unsigned long long), &d5))
+        void *d0 = nullptr, *d1 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr, *d6 = nullptr;
+        if (dalloc(sizeof(int32_t) * 3 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
+            dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
+            dalloc(sizeof(unsigned long long), &d5) || dalloc(sizeof(TileRef) * (size_t)(max_halos > 0 ? max_halos : 1), &d6))
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(binning workspace) failed"));
-        p->tile_count = (int32_t *)d0; p->tile_start = (int32_t *)d1; p->tile_cursor = (int32_t *)d2;
+        p->tile_count = (int32_t *)d0; p->tile_count_b = p->tile_count + (T.ntiles + 1);
+        p->tile_cursor = p->tile_count + 2 * (T.ntiles + 1);
+        p->tile_start = (int32_t *)d1; p->tref = (TileRef *)d6;
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
         if (hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream) != hipSuccess)
             return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));

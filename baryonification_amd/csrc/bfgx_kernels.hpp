@@ -357,6 +357,14 @@ __device__ inline int ring_len(const Hpx &h, int ring)
     return (int)(4 * (ring < n ? ring : (ring > 3 * n ? 4 * n - ring : n)));
 }
 
+// where K0 already reserved this halo's slots in its tiles' entry lists (n <= kRefMax), or n > kRefMax: the
+// placement pass enumerates the tiles again and takes slots from the tiles' second ("many-tile halo") region
+constexpr int kRefMax = 4;
+struct TileRef {
+    int32_t tile[kRefMax], slot[kRefMax];
+    int32_t n, _pad[3];
+};
+
 // calls f(tile) once for every tile that may hold pixels of the halo's disc (conservative superset)
 template <typename F>
 __device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const HaloRec &r, F &&f)
@@ -403,7 +411,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ ra, const double *__restrict__ dec,
                  const double *__restrict__ ex0, const double *__restrict__ ex1,
                  HaloRec *__restrict__ rec, RowSetX *__restrict__ rowsx, int fallback4, Tiling T,
-                 int32_t *__restrict__ tile_count)
+                 int32_t *__restrict__ cnt_a, int32_t *__restrict__ cnt_b, TileRef *__restrict__ tref)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
@@ -548,19 +556,34 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         }
     }
     rec[j] = r;
-    if (tile_count) for_each_tile(h, T, r, [&](int t) { atomicAdd(tile_count + t, 1); });
+    if (cnt_a) {            // tile binning, pass 1: reserve one slot per touched tile
+        TileRef ref;
+        int nt = 0;
+        for_each_tile(h, T, r, [&](int t) { if (nt < kRefMax) ref.tile[nt] = t; ++nt; });
+        ref.n = nt; ref._pad[0] = ref._pad[1] = ref._pad[2] = 0;
+        if (nt <= kRefMax) {
+            for (int i = 0; i < kRefMax; ++i) {
+                if (i < nt) ref.slot[i] = atomicAdd(cnt_a + ref.tile[i], 1);
+                else { ref.tile[i] = 0; ref.slot[i] = 0; }
+            }
+        } else {
+            for (int i = 0; i < kRefMax; ++i) ref.slot[i] = 0;
+            for_each_tile(h, T, r, [&](int t) { atomicAdd(cnt_b + t, 1); });
+        }
+        tref[j] = ref;
+    }
 }
 
 // exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(int ntiles, const int32_t *__restrict__ count, int32_t *__restrict__ start)
+tile_scan_kernel(int ntiles, const int32_t *__restrict__ count, const int32_t *__restrict__ count_b, int32_t *__restrict__ start)
 {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (ntiles + 1023) / 1024;
     const int lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
     int32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += count[i];
+    for (int i = lo; i < hi; ++i) s += count[i] + count_b[i];
     part[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -570,22 +593,32 @@ tile_scan_kernel(int ntiles, const int32_t *__restrict__ count, int32_t *__restr
         __syncthreads();
     }
     int32_t run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+    for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i] + count_b[i]; }
     if (tid == 1023) start[ntiles] = part[1023];
 }
 
-// thread per halo: writes the halo index into the entry list of every tile it may touch
+// tile binning, pass 2 (thread per halo): the slots were reserved by K0, so this is a plain scatter of halo indices;
+// only halos touching more than kRefMax tiles enumerate their tiles again and draw slots from the second region
 __global__ void __launch_bounds__(256)
-tile_fill_kernel(Hpx h, Tiling T, int64_t nhalo, const HaloRec *__restrict__ rec, const int32_t *__restrict__ start,
-                 int32_t *__restrict__ cursor, int32_t *__restrict__ entries, int64_t capacity, int32_t *__restrict__ overflow)
+tile_place_kernel(Hpx h, Tiling T, int64_t nhalo, const HaloRec *__restrict__ rec, const TileRef *__restrict__ tref,
+                  const int32_t *__restrict__ start, const int32_t *__restrict__ cnt_a, int32_t *__restrict__ cur_b,
+                  int32_t *__restrict__ entries, int64_t capacity, int32_t *__restrict__ overflow)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
-    const HaloRec r = rec[j];
-    for_each_tile(h, T, r, [&](int t) {
-        const int64_t pos = (int64_t)start[t] + atomicAdd(cursor + t, 1);
-        if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1;
-    });
+    const TileRef ref = tref[j];
+    if (ref.n <= kRefMax) {
+        for (int i = 0; i < kRefMax; ++i) if (i < ref.n) {
+            const int64_t pos = (int64_t)start[ref.tile[i]] + ref.slot[i];
+            if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1;
+        }
+    } else {
+        const HaloRec r = rec[j];
+        for_each_tile(h, T, r, [&](int t) {
+            const int64_t pos = (int64_t)start[t] + cnt_a[t] + atomicAdd(cur_b + t, 1);
+            if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1;
+        });
+    }
 }
 
 // ---------------------------------------------------------------------------------- per-pair math

@@ -145,3 +145,25 @@ def test_invalid_halos_are_ignored(gpu):
     for algo in ALGOS:
         out = run(g, True, algo)
         assert np.isfinite(out).all() and np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_entry_list_regrowth(gpu, monkeypatch):
+    """a deliberately tiny halo->tile entry list must be regrown (one-shot API) or reported (resident API)"""
+    g = load_golden('lowz_baryonify')
+    ref = run(g, True, 1)
+    monkeypatch.setenv('BFGX_ENTRY_CAP', '64')
+    out = run(g, True, 1)                                   # host API: overflow -> exact regrowth -> same answer
+    assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+    import torch
+    from baryonification_amd import _lib, engine
+    axes = [np.log(1 + g['tab_z']), np.log(g['tab_M']), np.log(g['tab_r'])]
+    model, keep = engine.model_from_tables(axes, g['tab_values'], g['cosmo_runner'], g['eps_runner'], g['eps_model'])
+    dev = torch.device('cuda', 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in g['cat'].items()}
+    plan = engine.ShellPlan(model, keep, g['nside'], t['M'].numel(), 0, torch.cuda.current_stream().cuda_stream)
+    cd = _lib.make_catalog_dev(t['M'].numel(), t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
+    off = torch.zeros(12 * g['nside'] ** 2 * 3, dtype=torch.float64, device=dev)
+    plan.offsets(cd, off.data_ptr(), True)
+    with pytest.raises(ValueError, match='overflowed'):
+        plan.status()
+    plan.close()
