@@ -870,8 +870,9 @@ struct TileWaveLdsT {
     PairHaloT<NC> pair[kChunk];
     RingSlot ring[kChunk];
     // rows of the current block, compacted to the non-empty ones
-    int32_t prefix[kWave], firstA[kWave], cntA[kWave], firstB[kWave], nr[kWave], ldsbase[kWave], eslot[kWave];
-    double z[kWave], sth[kWave], shift[kWave];
+    int32_t prefix[kWave], firstA[kWave], cntA[kWave], firstB[kWave], ldsbase[kWave], eslot[kWave];
+    double z[kWave], sth[kWave];
+    double dphi[kWave], xoff[kWave];      // azimuth of pixel k relative to the halo: k * dphi + xoff  (xoff = shift * dphi - phi0)
     unsigned long long mask[kMaskWords];  // bit t set <=> pair t is the first pair of a row
 };
 
@@ -1008,8 +1009,10 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                     const int pre = incl - cnt;
                     L.prefix[slot] = pre;
                     L.firstA[slot] = firstA; L.cntA[slot] = cntA; L.firstB[slot] = firstB;
-                    L.nr[slot] = nr; L.ldsbase[slot] = ldsbase; L.eslot[slot] = es;
-                    L.z[slot] = z; L.sth[slot] = sth; L.shift[slot] = shift;
+                    L.ldsbase[slot] = ldsbase; L.eslot[slot] = es;
+                    L.z[slot] = z; L.sth[slot] = sth;
+                    const double dph = kTwoPi / (double)nr;
+                    L.dphi[slot] = dph; L.xoff[slot] = shift * dph - L.pair[es].phi0;
                     atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1030,14 +1033,12 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                     {
                         const int jj = tA - L.prefix[rowA], ca = L.cntA[rowA];
                         kA = (jj < ca) ? (L.firstA[rowA] + jj) : (L.firstB[rowA] + (jj - ca));
-                        const int esA = L.eslot[rowA];
-                        xA = fold_dphi(((double)kA + L.shift[rowA]) * (kTwoPi / (double)L.nr[rowA]) - L.pair[esA].phi0);
+                        xA = fold_dphi(__builtin_fma((double)kA, L.dphi[rowA], L.xoff[rowA]));
                     }
                     {
                         const int jj = tB - L.prefix[rowB], ca = L.cntA[rowB];
                         kB = (jj < ca) ? (L.firstA[rowB] + jj) : (L.firstB[rowB] + (jj - ca));
-                        const int esB = L.eslot[rowB];
-                        xB = fold_dphi(((double)kB + L.shift[rowB]) * (kTwoPi / (double)L.nr[rowB]) - L.pair[esB].phi0);
+                        xB = fold_dphi(__builtin_fma((double)kB, L.dphi[rowB], L.xoff[rowB]));
                     }
                     const PairH &hA = L.pair[L.eslot[rowA]], &hB = L.pair[L.eslot[rowB]];
                     double vA[3], vB[3];

@@ -101,8 +101,9 @@ def main():
         table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
     axes = [np.log(1 + z), np.log(M), np.log(r)]
     hmap = np.zeros(npix) if paint else syn.make_map(nside)
-    model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, args.eps, args.eps,
-                                           log_values=paint)
+    with np.errstate(divide='ignore'):       # the closed-form profile underflows to 0 at the largest radii: ln -> -inf
+        values = np.log(table) if paint else table
+    model, keep = engine.model_from_tables(axes, values, syn.COSMO, args.eps, args.eps, log_values=paint)
 
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}
     d_map = torch.from_numpy(hmap).to(dev)
