@@ -10,7 +10,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for k in ('halo_prep_kernel', 'halo_scatter_kernel', 'regrid_kernel', 'sum2_kernel'):
+    for k in ('halo_prep_kernel', 'halo_scatter_kernel', 'tile_regrid_kernel', 'regrid_kernel', 'sum2_kernel'):
         if k in name:
             if k == 'halo_scatter_kernel':
                 mode = {'ILi0E': 'OFFSETS', 'ILi1E': 'PAINT', 'ILi2E': 'COUNT'}
