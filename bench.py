@@ -173,6 +173,14 @@ def main():
                  "regrid": "tile_regrid_kernel" if args.algo == 1 else "regrid_kernel",
                  "paint": "tile_scatter_kernel<PAINT>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
+        traffic = None           # HBM bytes per launch from a separate rocprofv3 --pmc run of this same configuration
+        try:
+            tj = json.load(open(os.path.join(HERE, 'profiles', 'traffic_latest.json')))
+            c = tj['config']
+            if (c['halos_per_gpu'], c['nside'], c['algo'], c['mode']) == (args.halos, nside, args.algo, args.mode) and not args.acc_f64:
+                traffic = tj['kernels'].get(dom)
+        except Exception:
+            traffic = None
         out = {
             "metric": "halos/sec for %s NSIDE=%d (1e6-halo synthetic catalog per GPU)" % ("PaintProfilesShell" if paint else "BaryonifyShell", nside),
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
@@ -192,7 +200,7 @@ def main():
             "mass_conserved": None if paint else bool(np.isclose(sums[1], sums[0])),
             "roofline": {"kernel": names[dom],
                          "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom],
                          "note": "scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "
                                  "(gfx950 memory-side float atomics), not the 8 TB/s stream peak"},
