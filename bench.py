@@ -202,8 +202,11 @@ def main():
                          "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom],
-                         "note": "scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "
-                                 "(gfx950 memory-side float atomics), not the 8 TB/s stream peak"},
+                         "note": ("tile-owned LDS accumulation, no global atomics: ~20 B of algorithmic HBM traffic per "
+                                  "~180 fp64 VALU ops per (halo, pixel) pair, so the kernel sits far below the HBM roof "
+                                  "and is bounded by fp64 issue/latency at 2 waves/SIMD (DESIGN.md section 4)") if args.algo == 1 else
+                                 ("scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "
+                                  "(gfx950 memory-side float atomics), not the 8 TB/s stream peak")},
         }
         if world == 1 and not args.no_cpu_baseline and not paint:
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
