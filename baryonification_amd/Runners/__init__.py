@@ -1,1 +1,2 @@
 from .HealpixRunner import *
+from .Map2DRunner import *

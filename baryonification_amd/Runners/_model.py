@@ -18,9 +18,10 @@ def _axes(model, p_keys):
     return [np.asarray(a, dtype=np.float64) for a in axes]
 
 
-def build_model(runner, kind):
-    """kind = 'displacement' (BaryonifyShell) or 'projected' (PaintProfilesShell).
-    Returns (bfgx_model, p_keys, keepalive)."""
+def build_model(runner, kind, runner_cosmo=None):
+    """kind = 'displacement' (BaryonifyShell / BaryonifyGrid), 'projected' (PaintProfilesShell, PaintProfilesGrid on
+    2D maps) or 'real' (PaintProfilesGrid on 3D maps).  `runner_cosmo` overrides the runner-side cosmology dict (the
+    grid runners drop w0, Map2DRunner.py:456-459).  Returns (bfgx_model, p_keys, keepalive)."""
     model = runner.model
     p_keys = list(vars(model).get('p_keys', []))                      # HealpixRunner.py:282
     if kind == 'displacement':
@@ -33,17 +34,18 @@ def build_model(runner, kind):
         logv = False
         eps_model = float(model.epsilon_max)
     else:
-        if not hasattr(model, 'raw_input_2D'):
-            raise TypeError("PaintProfilesShell on the GPU needs a tabulated profile (TabulatedProfile / "
+        attr = 'raw_input_2D' if kind == 'projected' else 'raw_input_3D'
+        if not hasattr(model, attr):
+            raise TypeError("painting on the GPU needs a tabulated profile (TabulatedProfile / "
                             "ParamTabulatedProfile); wrap the profile and call setup_interpolator()/set_table()")
         with np.errstate(divide='ignore', invalid='ignore'):
-            values = np.log(np.asarray(model.raw_input_2D, dtype=np.float64))   # Tabulate.py:238, :561
+            values = np.log(np.asarray(getattr(model, attr), dtype=np.float64))   # Tabulate.py:237-238, :560-561
         rdelta, logv, eps_model = False, True, 0.0
     table, keep = _lib.make_table(_axes(model, p_keys), values, rdelta, logv, eps_model)
 
     m = _lib.bfgx_model()
     m.table = table
-    m.cosmo_runner = _lib.make_cosmo(cosmo_to_dict(runner.cosmo))
+    m.cosmo_runner = _lib.make_cosmo(cosmo_to_dict(runner.cosmo if runner_cosmo is None else runner_cosmo))
     D, rho = massdef_to_tuple(runner.mass_def)
     m.massdef_runner = _lib.make_massdef(D, rho)
     mc = getattr(model, 'cosmo', None)

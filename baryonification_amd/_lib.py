@@ -17,7 +17,7 @@ KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BFGX_LIB', os.path.join(_HERE, 'csrc', 'libbfgx.so'))   # BFGX_LIB: ablation builds only
 
-OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS, ERR_ASSERT = 0, -1, -2, -3, -4, -5, -6
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -50,6 +50,15 @@ class bfgx_model(C.Structure):
 class bfgx_opts(C.Structure):
     _fields_ = [('device', C.c_int32), ('acc_offsets_f64', C.c_int32), ('acc_paint_f64', C.c_int32),
                 ('check_mass', C.c_int32), ('algo', C.c_int32), ('_pad', C.c_int32)]
+
+
+class bfgx_grid(C.Structure):
+    _fields_ = [('ndim', C.c_int32), ('npix', C.c_int32), ('bins', C.c_void_p), ('redshift', C.c_double)]
+
+
+class bfgx_grid_catalog(C.Structure):
+    _fields_ = [('n', C.c_int64), ('M', C.c_void_p), ('x', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p),
+                ('lnM', C.c_void_p), ('rmat', C.c_void_p), ('extra', C.c_void_p * BFGX_MAX_EXTRA)]
 
 
 class bfgx_stats(C.Structure):
@@ -88,6 +97,25 @@ SYMBOLS = {
     'bfgx_displacement_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_pressure_profile': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
     'bfgx_count_pairs_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int, C.c_void_p, _P(C.c_int64)]),
+    # regular-grid path
+    'bfgx_baryonify_grid': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_grid), C.c_void_p, C.c_void_p,
+                                      _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_paint_grid': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_grid), C.c_void_p, _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_regrid_pixels': (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_deposit_particles': (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p]),
+    'bfgx_power_spectrum': (C.c_int, [C.c_int, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_grid_plan_create': (C.c_int, [C.c_int, C.c_void_p, _P(bfgx_grid), C.c_int64, _P(bfgx_model), _P(C.c_void_p)]),
+    'bfgx_grid_plan_destroy': (None, [C.c_void_p]),
+    'bfgx_grid_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_void_p, _P(C.c_int64)]),
+    'bfgx_grid_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_void_p, _P(C.c_int64)]),
+    'bfgx_grid_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_grid_plan_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'bfgx_grid_plan_timing_read': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_deposit_particles_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_power_spectrum_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -142,8 +170,8 @@ def check(rc):
     if rc == OK:
         return
     msg = load().bfgx_last_error().decode('utf-8', 'replace')
-    if rc == ERR_MASS:
-        raise AssertionError(msg)                 # HealpixRunner.py:346
+    if rc == ERR_MASS or rc == ERR_ASSERT:
+        raise AssertionError(msg)                 # HealpixRunner.py:346, Map2DRunner.py:516 / :605
     if rc == ERR_INVALID:
         raise ValueError(msg)
     if rc == ERR_UNSUPPORTED:
@@ -208,6 +236,41 @@ def make_catalog_dev(n, M_ptr, z_ptr, ra_ptr, dec_ptr, extra_ptrs=()):
     c = bfgx_catalog()
     c.n = int(n)
     c.M, c.z, c.ra, c.dec = int(M_ptr), int(z_ptr), int(ra_ptr), int(dec_ptr)
+    for k, e in enumerate(extra_ptrs):
+        c.extra[k] = int(e)
+    return c
+
+
+def make_grid(bins, ndim, redshift):
+    """Returns (bfgx_grid, keepalive)"""
+    b = f8(bins)
+    g = bfgx_grid(int(ndim), int(b.size), b.ctypes.data, float(redshift))
+    return g, b
+
+
+def make_grid_catalog_host(M, x, y, z=None, lnM=None, rmat=None, extra=()):
+    cols = {'M': f8(M), 'x': f8(x), 'y': f8(y)}
+    if z is not None:
+        cols['z'] = f8(z)
+    if lnM is not None:
+        cols['lnM'] = f8(lnM)
+    if rmat is not None:
+        cols['rmat'] = f8(rmat).reshape(-1, 4)
+    c = bfgx_grid_catalog()
+    c.n = cols['M'].size
+    for k, v in cols.items():
+        setattr(c, k, v.ctypes.data)
+    ex = [f8(e) for e in extra]
+    for k, e in enumerate(ex):
+        c.extra[k] = e.ctypes.data
+    return c, (cols, ex)
+
+
+def make_grid_catalog_dev(n, M_ptr, x_ptr, y_ptr, z_ptr=0, lnM_ptr=0, rmat_ptr=0, extra_ptrs=()):
+    c = bfgx_grid_catalog()
+    c.n = int(n)
+    c.M, c.x, c.y = int(M_ptr), int(x_ptr), int(y_ptr)
+    c.z, c.lnM, c.rmat = (int(z_ptr) or None), (int(lnM_ptr) or None), (int(rmat_ptr) or None)
     for k, e in enumerate(extra_ptrs):
         c.extra[k] = int(e)
     return c

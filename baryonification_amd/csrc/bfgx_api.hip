@@ -20,6 +20,8 @@
 #include "bfgx_cosmo.hpp"
 #include "bfgx_kernels.hpp"
 #include "bfgx_tables.hpp"
+#include "bfgx_grid.hpp"
+#include "bfgx_fft.hpp"
 
 using namespace bfgx;
 
@@ -99,30 +101,115 @@ struct bfgx_plan {
 namespace {
 
 // brackets one kernel launch with a pair of events on the plan's stream when timing is enabled
-struct KernelTimer {
-    bfgx_plan *p; int kind; std::pair<hipEvent_t, hipEvent_t> e{nullptr, nullptr};
-    KernelTimer(bfgx_plan *p_, int kind_) : p(p_), kind(kind_)
+template <class Plan>
+struct KernelTimerT {
+    Plan *p; int kind; std::pair<hipEvent_t, hipEvent_t> e{nullptr, nullptr};
+    KernelTimerT(Plan *p_, int kind_) : p(p_), kind(kind_)
     {
         if (!p->timing) return;
         if (!p->ev_free.empty()) { e = p->ev_free.back(); p->ev_free.pop_back(); }
         else { (void)hipEventCreate(&e.first); (void)hipEventCreate(&e.second); }
         (void)hipEventRecord(e.first, p->stream);
     }
-    ~KernelTimer()
+    ~KernelTimerT()
     {
         if (!p->timing) return;
         (void)hipEventRecord(e.second, p->stream);
         p->ev[kind].push_back(e);
     }
 };
+using KernelTimer = KernelTimerT<bfgx_plan>;
 
-static int plan_upload(bfgx_plan *p, const void *host, size_t bytes, const void **dev_out)
+static int owned_upload(std::vector<void *> &owned, hipStream_t stream, const void *host, size_t bytes, const void **dev_out)
 {
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
-    p->owned.push_back(d);
-    HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, p->stream));
+    owned.push_back(d);
+    HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream));
     *dev_out = d;
+    return BFGX_OK;
+}
+
+static int plan_upload(bfgx_plan *p, const void *host, size_t bytes, const void **dev_out)
+{
+    return owned_upload(p->owned, p->stream, host, bytes, dev_out);
+}
+
+static int validate_model(const bfgx_model *model)
+{
+    if (int rc = validate_cosmo(model->cosmo_runner)) return rc;
+    if (int rc = validate_cosmo(model->cosmo_model)) return rc;
+    if (int rc = validate_table(model->table)) return rc;
+    if (!(model->eps_runner > 0)) return fail(BFGX_ERR_INVALID, "epsilon_max must be > 0");
+    if (!(model->massdef_runner.Delta > 0) || !(model->massdef_model.Delta > 0))
+        return fail(BFGX_ERR_INVALID, "mass definition needs numeric Delta > 0");
+    return BFGX_OK;
+}
+
+// device copy of the model: table axes + values (r innermost), backgrounds, mass definitions; `with_da` adds the
+// D_A(z) spline the lightcone runners need.  Synchronises the stream before returning (staging buffers are local).
+static int upload_model(std::vector<void *> &owned, hipStream_t stream, const bfgx_model *model, bool with_da, DevModel &m, int &NC)
+{
+    const bfgx_table &t = model->table;
+    std::memset(&m, 0, sizeof(m));
+    m.tab.ndim = t.ndim;
+    size_t nvals = 1;
+    for (int d = 0; d < t.ndim; ++d) {
+        m.tab.n[d] = t.n[d];
+        nvals *= (size_t)t.n[d];
+        const void *dv = nullptr;
+        if (int rc = owned_upload(owned, stream, t.axis[d], sizeof(double) * t.n[d], &dv)) return rc;
+        m.tab.axis[d] = (const double *)dv;
+    }
+    {
+        // device layout [z][M][p0][p1][r]: the radial row of every (z, M, params) corner is contiguous
+        std::vector<double> tr;
+        const double *src = t.values;
+        if (t.ndim > 3) {
+            const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2], np0 = t.n[3], np1 = t.ndim > 4 ? t.n[4] : 1;
+            tr.resize(nvals);
+            for (size_t iz = 0; iz < nz; ++iz) for (size_t im = 0; im < nm; ++im) for (size_t ir = 0; ir < nr; ++ir)
+                for (size_t a0 = 0; a0 < np0; ++a0) for (size_t a1 = 0; a1 < np1; ++a1)
+                    tr[((((iz * nm + im) * np0 + a0) * np1 + a1) * nr) + ir] = t.values[((((iz * nm + im) * nr + ir) * np0 + a0) * np1) + a1];
+            src = tr.data();
+        }
+        const void *dv = nullptr;
+        if (int rc = owned_upload(owned, stream, src, sizeof(double) * nvals, &dv)) return rc;
+        m.tab.values = (const double *)dv;
+        HIP_TRY(hipStreamSynchronize(stream));
+        NC = 4 << (t.ndim - 3);
+    }
+    m.tab.rdelta = t.rdelta_sampling;
+    m.tab.logv = t.log_values;
+    m.tab.eps_model = t.eps_model;
+    {   // uniform ln r axis -> O(1) index guess
+        const double *g = t.axis[2];
+        const int n = t.n[2];
+        const double step = (g[n - 1] - g[0]) / (n - 1);
+        bool uni = true;
+        for (int i = 0; i < n; ++i)
+            if (std::fabs(g[i] - (g[0] + i * step)) > 1e-9 * std::fabs(step)) { uni = false; break; }
+        m.tab.r_uniform = uni ? 1 : 0;
+        m.tab.r0 = g[0];
+        m.tab.r1 = g[n - 1];
+        m.tab.inv_dr = 1.0 / step;
+    }
+    m.bg_runner = make_background(model->cosmo_runner);
+    m.bg_model = make_background(model->cosmo_model);
+    m.md_runner = model->massdef_runner;
+    m.md_model = model->massdef_model;
+    m.eps_runner = model->eps_runner;
+    m.same_model = (std::memcmp(&m.bg_runner, &m.bg_model, sizeof(Background)) == 0 && m.md_runner.Delta == m.md_model.Delta &&
+                    m.md_runner.rho_type == m.md_model.rho_type) ? 1 : 0;
+    if (with_da) {
+        std::vector<double> knots, coef;
+        da_spline(m.bg_runner, knots, coef);
+        const void *dv = nullptr;
+        if (int rc = owned_upload(owned, stream, coef.data(), sizeof(double) * coef.size(), &dv)) return rc;
+        m.da_coef = (const double *)dv;
+        m.da_step = kDaZmax / (kDaKnots - 1);
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     return BFGX_OK;
 }
 
@@ -333,12 +420,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
     *out = nullptr;
     if (nside < 1 || nside > (int64_t(1) << 24)) return fail(BFGX_ERR_INVALID, "nside out of range");
     if (max_halos < 0) return fail(BFGX_ERR_INVALID, "max_halos < 0");
-    if (int rc = validate_cosmo(model->cosmo_runner)) return rc;
-    if (int rc = validate_cosmo(model->cosmo_model)) return rc;
-    if (int rc = validate_table(model->table)) return rc;
-    if (!(model->eps_runner > 0)) return fail(BFGX_ERR_INVALID, "epsilon_max must be > 0");
-    if (!(model->massdef_runner.Delta > 0) || !(model->massdef_model.Delta > 0))
-        return fail(BFGX_ERR_INVALID, "mass definition needs numeric Delta > 0");
+    if (int rc = validate_model(model)) return rc;
     if (bfgx_device_count() <= 0)
         return fail(BFGX_ERR_NO_DEVICE, "no HIP device visible: libbfgx has no CPU fallback");
     HIP_TRY(hipSetDevice(device));
@@ -354,67 +436,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
     auto bail = [&](int rc) { bfgx_plan_destroy(p); return rc; };
 
     const bfgx_table &t = model->table;
-    DevModel &m = p->model;
-    std::memset(&m, 0, sizeof(m));
-    m.tab.ndim = t.ndim;
-    size_t nvals = 1;
-    for (int d = 0; d < t.ndim; ++d) {
-        m.tab.n[d] = t.n[d];
-        nvals *= (size_t)t.n[d];
-        const void *dv = nullptr;
-        if (int rc = plan_upload(p, t.axis[d], sizeof(double) * t.n[d], &dv)) return bail(rc);
-        m.tab.axis[d] = (const double *)dv;
-    }
-    {
-        // device layout [z][M][p0][p1][r]: the radial row of every (z, M, params) corner is contiguous
-        std::vector<double> tr;
-        const double *src = t.values;
-        if (t.ndim > 3) {
-            const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2], np0 = t.n[3], np1 = t.ndim > 4 ? t.n[4] : 1;
-            tr.resize(nvals);
-            for (size_t iz = 0; iz < nz; ++iz) for (size_t im = 0; im < nm; ++im) for (size_t ir = 0; ir < nr; ++ir)
-                for (size_t a0 = 0; a0 < np0; ++a0) for (size_t a1 = 0; a1 < np1; ++a1)
-                    tr[((((iz * nm + im) * np0 + a0) * np1 + a1) * nr) + ir] = t.values[((((iz * nm + im) * nr + ir) * np0 + a0) * np1) + a1];
-            src = tr.data();
-        }
-        const void *dv = nullptr;
-        if (int rc = plan_upload(p, src, sizeof(double) * nvals, &dv)) return bail(rc);
-        m.tab.values = (const double *)dv;
-        if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
-        p->NC = 4 << (t.ndim - 3);
-    }
-    m.tab.rdelta = t.rdelta_sampling;
-    m.tab.logv = t.log_values;
-    m.tab.eps_model = t.eps_model;
-    {   // uniform ln r axis -> O(1) index guess
-        const double *g = t.axis[2];
-        const int n = t.n[2];
-        const double step = (g[n - 1] - g[0]) / (n - 1);
-        bool uni = true;
-        for (int i = 0; i < n; ++i)
-            if (std::fabs(g[i] - (g[0] + i * step)) > 1e-9 * std::fabs(step)) { uni = false; break; }
-        m.tab.r_uniform = uni ? 1 : 0;
-        m.tab.r0 = g[0];
-        m.tab.r1 = g[n - 1];
-        m.tab.inv_dr = 1.0 / step;
-    }
-    m.bg_runner = make_background(model->cosmo_runner);
-    m.bg_model = make_background(model->cosmo_model);
-    m.md_runner = model->massdef_runner;
-    m.md_model = model->massdef_model;
-    m.eps_runner = model->eps_runner;
-    m.same_model = (std::memcmp(&m.bg_runner, &m.bg_model, sizeof(Background)) == 0 && m.md_runner.Delta == m.md_model.Delta &&
-                    m.md_runner.rho_type == m.md_model.rho_type) ? 1 : 0;
-    {
-        std::vector<double> knots, coef;
-        da_spline(m.bg_runner, knots, coef);
-        const void *dv = nullptr;
-        if (int rc = plan_upload(p, coef.data(), sizeof(double) * coef.size(), &dv)) return bail(rc);
-        m.da_coef = (const double *)dv;
-        m.da_step = kDaZmax / (kDaKnots - 1);
-        // the staging vectors die at scope exit: make sure the async copies are done
-        if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
-    }
+    if (int rc = upload_model(p->owned, p->stream, model, true, p->model, p->NC)) return bail(rc);
     {
         void *d = nullptr;
         if (hipMalloc(&d, sizeof(HaloRec) * (size_t)(max_halos > 0 ? max_halos : 1)) != hipSuccess)
@@ -900,3 +922,6 @@ int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const d
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------ regular-grid path (8f-1)
+#include "bfgx_grid_api.inc"

@@ -1,0 +1,113 @@
+// bfgx_fft.hpp -- 3-D power-spectrum summary of a gridded map (examples/10_Reproduce_Schneider_deltaPk.ipynb
+// cells 12 + 15: np.fft.fftn -> |F|^2 -> np.bincount in linear k-bins) for gfx950.
+//
+// The map is real, so only the kz <= N/2 half of the spectrum is computed (r2c along the contiguous axis, then two
+// in-place c2c passes along the strided axes); the mirrored half enters the bin sums through a weight of 2.
+// Every 1-D transform runs in LDS: radix-2 decimation in time, bit-reversed on the way in, log2(N) butterfly stages
+// with a barrier each, twiddles from a host-built fp64 table.  The strided passes move tiles of kFftTile lines that
+// are adjacent in memory, so that global accesses stay contiguous (kFftTile * 16 B) and LDS accesses conflict-free
+// (line index fastest).  N must be a power of two, 8 <= N <= 1024.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bfgx_math.hpp"
+
+namespace bfgx {
+
+constexpr int kFftBlock = 256;
+constexpr int kFftTile = 8;           // lines per workgroup in the strided passes
+
+__device__ inline int bit_reverse(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
+
+// in-place radix-2 butterflies over `nl` interleaved lines held in LDS as buf[i * nl + l]
+__device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2 *__restrict__ tw)
+{
+    const int nb = (N >> 1) * nl;
+    for (int m = 1; m < N; m <<= 1) {
+        __syncthreads();
+        const int tstep = (N >> 1) / m;
+        for (int t = threadIdx.x; t < nb; t += kFftBlock) {
+            const int l = t % nl, b = t / nl;
+            const int pos = b & (m - 1);
+            const int i = ((b - pos) << 1) + pos, j = i + m;
+            const double2 w = tw[pos * tstep];
+            const double2 u = buf[i * nl + l], v = buf[j * nl + l];
+            const double tr = w.x * v.x - w.y * v.y, ti = w.x * v.y + w.y * v.x;
+            buf[i * nl + l] = make_double2(u.x + tr, u.y + ti);
+            buf[j * nl + l] = make_double2(u.x - tr, u.y - ti);
+        }
+    }
+    __syncthreads();
+}
+
+// pass 1: real lines along the contiguous axis -> first N/2 + 1 coefficients.  One workgroup per line.
+__global__ void __launch_bounds__(kFftBlock)
+fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, int N, int log2n, const double2 *__restrict__ tw)
+{
+    extern __shared__ double2 fbuf[];
+    const int64_t line = blockIdx.x;
+    const double *src = map + line * N;
+    for (int i = threadIdx.x; i < N; i += kFftBlock) fbuf[bit_reverse(i, log2n)] = make_double2(src[i], 0.0);
+    lds_fft_stages(fbuf, N, 1, tw);
+    const int nz = (N >> 1) + 1;
+    double2 *dst = out + line * nz;
+    for (int i = threadIdx.x; i < nz; i += kFftBlock) dst[i] = fbuf[i];
+}
+
+// passes 2 and 3: in-place complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
+// data[o * outer_stride + i * stride + kz0 + l]; blockIdx.x = kz tile, blockIdx.y = o.
+__global__ void __launch_bounds__(kFftBlock)
+fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
+                       const double2 *__restrict__ tw)
+{
+    extern __shared__ double2 fbuf[];
+    const int kz0 = blockIdx.x * kFftTile;
+    const int nl = min(kFftTile, nz - kz0);
+    double2 *base = data + (int64_t)blockIdx.y * outer_stride + kz0;
+    for (int t = threadIdx.x; t < N * nl; t += kFftBlock) {
+        const int l = t % nl, i = t / nl;
+        fbuf[bit_reverse(i, log2n) * nl + l] = base[(int64_t)i * stride + l];
+    }
+    lds_fft_stages(fbuf, N, nl, tw);
+    for (int t = threadIdx.x; t < N * nl; t += kFftBlock) {
+        const int l = t % nl, i = t / nl;
+        base[(int64_t)i * stride + l] = fbuf[i * nl + l];
+    }
+}
+
+// |F|^2, |k| and mode counts per linear k-bin.  F[a][b][c], c <= N/2; k = sqrt(klin[a]^2 + klin[c]^2 + klin[b]^2)
+// (the notebook's summation order); bin = floor((k - kb0) / dk); the c-mirrored half counts through a weight of 2.
+__global__ void __launch_bounds__(256)
+pk_bin_kernel(const double2 *__restrict__ F, int N, const double *__restrict__ klin, double kb0, double dk, int nk,
+              double *__restrict__ pk_sum, double *__restrict__ k_sum, unsigned long long *__restrict__ counts)
+{
+    extern __shared__ double hist[];                       // [nk] power, [nk] k, then [nk] counts (u64)
+    double *hp = hist, *hk = hist + nk;
+    unsigned long long *hc = reinterpret_cast<unsigned long long *>(hist + 2 * nk);
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) { hp[i] = 0.0; hk[i] = 0.0; hc[i] = 0ull; }
+    __syncthreads();
+    const int nz = (N >> 1) + 1;
+    const int64_t total = (int64_t)N * N * nz;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % nz);
+        const int64_t q = t / nz;
+        const int b = (int)(q % N), a = (int)(q / N);
+        const double ka = klin[a], kb = klin[b], kc = klin[c];
+        const double k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
+        const double u = floor((k - kb0) / dk);
+        if (!(u >= 0.0) || !(u < (double)nk)) continue;
+        const int bin = (int)u;
+        const double2 f = F[t];
+        const double p = f.x * f.x + f.y * f.y;
+        const int mult = (c > 0 && c < (N >> 1)) ? 2 : 1;
+        atomicAdd(hp + bin, mult * p);
+        atomicAdd(hk + bin, mult * k);
+        atomicAdd(hc + bin, (unsigned long long)mult);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+        if (hc[i]) { atomicAdd(pk_sum + i, hp[i]); atomicAdd(k_sum + i, hk[i]); atomicAdd(counts + i, hc[i]); }
+    }
+}
+
+}  // namespace bfgx

@@ -335,6 +335,49 @@ __device__ inline int axis_find(const double *g, int n, double x)
     return lo;
 }
 
+// (z, M[, p0, p1]) corner rows of the table for one halo: weights in scipy's itertools.product order and the offsets
+// of the corners' radial rows in the device layout [z][M][p0][p1][r] (r innermost).  Returns true when a coordinate is
+// outside its axis (RegularGridInterpolator fill_value = nan).
+template <int NC>
+__device__ inline bool table_corners(const DevTable &tab, double x0, double x1, double xe0, double xe1, double *wv, int32_t *ro)
+{
+    const int iz = axis_find(tab.axis[0], tab.n[0], x0);
+    const int im = axis_find(tab.axis[1], tab.n[1], x1);
+    constexpr int K = (NC == 4) ? 0 : (NC == 8 ? 1 : 2);
+    int ip[2] = {0, 0};
+    double tp[2] = {0.0, 0.0};
+    bool oob = (iz < 0 || im < 0);
+    if (K >= 1) {
+        ip[0] = axis_find(tab.axis[3], tab.n[3], xe0);
+        oob = oob || ip[0] < 0;
+        if (ip[0] >= 0) tp[0] = (xe0 - tab.axis[3][ip[0]]) / (tab.axis[3][ip[0] + 1] - tab.axis[3][ip[0]]);
+    }
+    if (K >= 2) {
+        ip[1] = axis_find(tab.axis[4], tab.n[4], xe1);
+        oob = oob || ip[1] < 0;
+        if (ip[1] >= 0) tp[1] = (xe1 - tab.axis[4][ip[1]]) / (tab.axis[4][ip[1] + 1] - tab.axis[4][ip[1]]);
+    }
+    if (!oob) {
+        const double *gz = tab.axis[0], *gm = tab.axis[1];
+        const double tz = (x0 - gz[iz]) / (gz[iz + 1] - gz[iz]);
+        const double tm = (x1 - gm[im]) / (gm[im + 1] - gm[im]);
+        const int nr = tab.n[2];
+        const int np0 = (K >= 1) ? tab.n[3] : 1, np1 = (K >= 2) ? tab.n[4] : 1;
+        for (int c = 0; c < NC; ++c) {
+            const int bz = (c >> (K + 1)) & 1, bm = (c >> K) & 1;
+            const int b0 = (K >= 1) ? ((c >> (K - 1)) & 1) : 0, b1 = (K >= 2) ? (c & 1) : 0;
+            double w = (1.0 * (bz ? tz : 1.0 - tz)) * (bm ? tm : 1.0 - tm);
+            if (K >= 1) w *= (b0 ? tp[0] : 1.0 - tp[0]);
+            if (K >= 2) w *= (b1 ? tp[1] : 1.0 - tp[1]);
+            wv[c] = w;
+            ro[c] = ((((iz + bz) * tab.n[1] + im + bm) * np0 + ip[0] + b0) * np1 + ip[1] + b1) * nr;
+        }
+    } else {
+        for (int c = 0; c < NC; ++c) { wv[c] = 0.0; ro[c] = 0; }
+    }
+    return oob;
+}
+
 // ---------------------------------------------------------------------------------- tiling
 // The sphere is cut into tiles = (band of BR consecutive rings) x (1/nphi of the azimuth).  In ring i
 // with nr pixels, tile j of the ring's band owns k in [ceil(j nr/nphi), ceil((j+1) nr/nphi)), i.e. the
@@ -491,46 +534,10 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     r.inv_a = 1.0 / a;
     const double x0 = log(1.0 / a), x1 = log(M_j);
     r.lnoff = m.tab.rdelta ? (x0 - log(Rmod)) : x0;
-    const int iz = axis_find(m.tab.axis[0], m.tab.n[0], x0);
-    const int im = axis_find(m.tab.axis[1], m.tab.n[1], x1);
-    constexpr int K = (NC == 4) ? 0 : (NC == 8 ? 1 : 2);
-    int ip[2] = {0, 0};
-    double tp[2] = {0.0, 0.0};
-    bool oob = (iz < 0 || im < 0);
-    if (K >= 1) {
-        const double xe = ex0[j];
-        ip[0] = axis_find(m.tab.axis[3], m.tab.n[3], xe);
-        oob = oob || ip[0] < 0;
-        if (ip[0] >= 0) tp[0] = (xe - m.tab.axis[3][ip[0]]) / (m.tab.axis[3][ip[0] + 1] - m.tab.axis[3][ip[0]]);
-    }
-    if (K >= 2) {
-        const double xe = ex1[j];
-        ip[1] = axis_find(m.tab.axis[4], m.tab.n[4], xe);
-        oob = oob || ip[1] < 0;
-        if (ip[1] >= 0) tp[1] = (xe - m.tab.axis[4][ip[1]]) / (m.tab.axis[4][ip[1] + 1] - m.tab.axis[4][ip[1]]);
-    }
-    r.oob = oob ? 1 : 0;
     double wv[NC];
     int32_t ro[NC];
-    if (!oob) {
-        const double *gz = m.tab.axis[0], *gm = m.tab.axis[1];
-        const double tz = (x0 - gz[iz]) / (gz[iz + 1] - gz[iz]);
-        const double tm = (x1 - gm[im]) / (gm[im + 1] - gm[im]);
-        const int nr = m.tab.n[2];
-        const int np0 = (K >= 1) ? m.tab.n[3] : 1, np1 = (K >= 2) ? m.tab.n[4] : 1;
-        // device layout of the table: [z][M][p0][p1][r] (r innermost); corner order = scipy's product order
-        for (int c = 0; c < NC; ++c) {
-            const int bz = (c >> (K + 1)) & 1, bm = (c >> K) & 1;
-            const int b0 = (K >= 1) ? ((c >> (K - 1)) & 1) : 0, b1 = (K >= 2) ? (c & 1) : 0;
-            double w = (1.0 * (bz ? tz : 1.0 - tz)) * (bm ? tm : 1.0 - tm);
-            if (K >= 1) w *= (b0 ? tp[0] : 1.0 - tp[0]);
-            if (K >= 2) w *= (b1 ? tp[1] : 1.0 - tp[1]);
-            wv[c] = w;
-            ro[c] = ((((iz + bz) * m.tab.n[1] + im + bm) * np0 + ip[0] + b0) * np1 + ip[1] + b1) * nr;
-        }
-    } else {
-        for (int c = 0; c < NC; ++c) { wv[c] = 0.0; ro[c] = 0; }
-    }
+    const bool oob = table_corners<NC>(m.tab, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
+    r.oob = oob ? 1 : 0;
     if (NC == 4) {
         for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
     } else {

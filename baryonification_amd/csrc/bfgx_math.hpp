@@ -204,4 +204,16 @@ __device__ inline double fast_sqrt(double x)
     return x > 0.0 ? r : 0.0;
 }
 
+// a * b and a + b that may not be contracted into an FMA (numpy rounds every operation separately)
+__device__ inline double mul_nc(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ inline double add_nc(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 }  // namespace bfgx

@@ -86,3 +86,87 @@ def model_from_tables(axes, values, cosmo, eps_runner, eps_model=None, rdelta_sa
     m.massdef_model = _lib.make_massdef(*(massdef_model if massdef_model is not None else massdef))
     m.eps_runner = float(eps_runner)
     return m, keep
+
+
+class GridPlan(object):
+    """Resident front-end of the regular-grid path (`bfgx_grid_plan`): periodic 2D / 3D maps at one redshift."""
+
+    def __init__(self, model, keepalive, bins, ndim, redshift, max_halos, device=0, stream=0):
+        self._keep = keepalive
+        self.ndim = int(ndim)
+        self.npix = int(len(bins))
+        self.ntot = self.npix ** self.ndim
+        self.max_halos = int(max_halos)
+        self.device = int(device)
+        self.stream = int(stream)
+        grid, gkeep = _lib.make_grid(bins, ndim, redshift)
+        h = C.c_void_p()
+        _lib.check(_lib.load().bfgx_grid_plan_create(self.device, C.c_void_p(self.stream or None), C.byref(grid),
+                                                    self.max_halos, C.byref(model), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            try:
+                _lib.load().bfgx_grid_plan_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def offsets(self, cat_dev, offsets_ptr):
+        """halo loop of BaryonifyGrid (Map2DRunner.py:476-575): offsets[npix^d][d] f64, zeroed then filled.
+        Returns the number of contributing (halo, pixel) pairs."""
+        n = C.c_int64(0)
+        _lib.check(_lib.load().bfgx_grid_offsets_device(self._h, C.byref(cat_dev), C.c_void_p(int(offsets_ptr)), C.byref(n)))
+        return int(n.value)
+
+    def paint(self, cat_dev, map_out_ptr):
+        """halo loop of PaintProfilesGrid (Map2DRunner.py:708-812)"""
+        n = C.c_int64(0)
+        _lib.check(_lib.load().bfgx_grid_paint_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_out_ptr)), C.byref(n)))
+        return int(n.value)
+
+    def regrid(self, map_in_ptr, offsets_ptr, map_out_ptr, sums_ptr=0):
+        """post-loop regrid (Map2DRunner.py:577-605): map_out zeroed then filled; sums[2] optional (zeroed by caller)"""
+        _lib.check(_lib.load().bfgx_grid_regrid_device(self._h, C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_ptr)),
+                                                      C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None)))
+
+    def timing_enable(self, on=True):
+        _lib.check(_lib.load().bfgx_grid_plan_timing_enable(self._h, int(on)))
+
+    def timing_read(self):
+        ms = np.zeros(len(_lib.KERNEL_KINDS))
+        n = np.zeros(len(_lib.KERNEL_KINDS), dtype=np.int64)
+        _lib.check(_lib.load().bfgx_grid_plan_timing_read(self._h, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_lib.KERNEL_KINDS)}
+
+
+def deposit_particles_device(x_ptr, y_ptr, z_ptr, mass_ptr, n, n_grid, edges_ptr, map_out_ptr, ndim=3, device=0, stream=0):
+    """ParticleSnapshot.make_map on device-resident columns (io.py:622-670)"""
+    _lib.check(_lib.load().bfgx_deposit_particles_device(int(device), C.c_void_p(int(stream) or None), int(ndim), int(n),
+                                                        C.c_void_p(int(x_ptr)), C.c_void_p(int(y_ptr)),
+                                                        C.c_void_p(int(z_ptr) or None), C.c_void_p(int(mass_ptr) or None),
+                                                        int(n_grid), C.c_void_p(int(edges_ptr)), C.c_void_p(int(map_out_ptr))))
+
+
+def power_spectrum_device(map_ptr, n_grid, L, nk, work_ptr, pk_sum_ptr, k_sum_ptr, counts_ptr, device=0, stream=0):
+    """FFT + |F|^2 + linear k-bins on a device-resident map; work = complex128 [n][n][n/2+1]"""
+    _lib.check(_lib.load().bfgx_power_spectrum_device(int(device), C.c_void_p(int(stream) or None), int(n_grid),
+                                                     C.c_void_p(int(map_ptr)), float(L), int(nk), C.c_void_p(int(work_ptr)),
+                                                     C.c_void_p(int(pk_sum_ptr)), C.c_void_p(int(k_sum_ptr)),
+                                                     C.c_void_p(int(counts_ptr))))
+
+
+def power_spectrum(Map, Lbox, Nk=180, device=0):
+    """P(k) summary of a cubic map as in examples/10_Reproduce_Schneider_deltaPk.ipynb (cells 12, 15): |FFT|^2 averaged in
+    Nk linear bins between the fundamental and the Nyquist frequency.  Returns (k_cen, Pk, k_count)."""
+    Map = _lib.f8(Map)
+    if Map.ndim != 3 or len(set(Map.shape)) != 1:
+        raise ValueError("power_spectrum needs a cubic 3-D map")
+    pk, kc = np.empty(Nk), np.empty(Nk)
+    cnt = np.empty(Nk, dtype=np.int64)
+    _lib.check(_lib.load().bfgx_power_spectrum(int(device), Map.shape[0], Map.ctypes.data, float(Lbox), int(Nk),
+                                              pk.ctypes.data, kc.ctypes.data, cnt.ctypes.data))
+    return kc, pk, cnt

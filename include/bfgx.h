@@ -41,7 +41,8 @@ typedef enum bfgx_status {
     BFGX_ERR_HIP = -2,            /* HIP runtime error (RuntimeError) */
     BFGX_ERR_NO_DEVICE = -3,      /* no GPU visible (RuntimeError; there is NO CPU fallback) */
     BFGX_ERR_UNSUPPORTED = -4,    /* NotImplementedError */
-    BFGX_ERR_MASS = -5            /* mass-conservation check failed (AssertionError, HealpixRunner.py:344-346) */
+    BFGX_ERR_MASS = -5,           /* mass-conservation check failed (AssertionError, HealpixRunner.py:344-346) */
+    BFGX_ERR_ASSERT = -6          /* another assert of the reference fired (AssertionError), e.g. Map2DRunner.py:516 */
 } bfgx_status;
 
 /* cosmology dict of io.py:79-85 plus the pyccl-2.x defaults the reference inherits */
@@ -105,6 +106,7 @@ typedef struct bfgx_stats {
 /* kernel kinds reported by bfgx_plan_timing_read */
 enum { BFGX_K_PREP = 0, BFGX_K_OFFSETS = 1, BFGX_K_REGRID = 2, BFGX_K_PAINT = 3, BFGX_K_SUM = 4, BFGX_K_COUNT = 5,
        BFGX_K_BIN = 6, BFGX_NUM_KERNELS = 7 };
+/* the grid plan reports its kernels under the same kinds: PREP, OFFSETS (halo loop), PAINT, REGRID, SUM */
 
 typedef struct bfgx_plan bfgx_plan;       /* opaque: device, stream, resident model + workspace */
 
@@ -182,6 +184,71 @@ int bfgx_displacement_rows(int device, int64_t nrows, int32_t nr, const double *
                            const double *M_dmb, double *d_out, int32_t *status);
 int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const double *rho_tot, const double *rho_gas,
                           int32_t nr_out, const double *r_out, double cutoff, double *P_out);
+
+/* ---- regular-grid path: periodic square / cubic maps ---------------------------------
+ * Replaces BaryonForge/Runners/Map2DRunner.py: BaryonifyGrid.process :431-607, PaintProfilesGrid.process :676-817,
+ * regrid_pixels_2D :14-83, regrid_pixels_3D :86-163; utils/io.py ParticleSnapshot.make_map :622-670; and the FFT
+ * P(k) summary of examples/10_Reproduce_Schneider_deltaPk.ipynb cells 12, 15.
+ * Maps are C-order [npix]^ndim doubles.  The grid runners build ccl.Cosmology WITHOUT w0 (Map2DRunner.py:456-459):
+ * callers pass cosmo_runner with w0 = -1.  HaloNDCatalog stores float32 columns (io.py:205): the caller passes those
+ * values widened to double, plus (optionally) lnM = the float32 logarithm the reference's read-out takes of the mass
+ * (BaryonCorrection.py:369, Tabulate.py:283), evaluated with the caller's numpy so that its last bit agrees. */
+typedef struct bfgx_grid {
+    int32_t ndim;                         /* 2 or 3 */
+    int32_t npix;                         /* pixels per side, >= 5 */
+    const double *bins;                   /* [npix] pixel-centre coordinates, comoving Mpc, strictly ascending */
+    double redshift;
+} bfgx_grid;
+
+typedef struct bfgx_grid_catalog {
+    int64_t n;
+    const double *M, *x, *y, *z;          /* z (a Cartesian coordinate) may be NULL for 2D maps */
+    const double *lnM;                    /* optional, see above; NULL -> (double)logf((float)M) on the device */
+    const double *rmat;                   /* optional [n][4]: row-major 2x2 matrices of DefaultRunnerGrid.build_Rmat
+                                             (use_ellipticity = True, 2D maps only) */
+    const double *extra[BFGX_MAX_EXTRA];
+} bfgx_grid_catalog;
+
+typedef struct bfgx_grid_plan bfgx_grid_plan;
+
+/* one-shot host API.  bfgx_paint_grid reads the LOG of raw_input_2D (2D maps) / raw_input_3D (3D maps) as table. */
+int bfgx_baryonify_grid(const bfgx_grid_catalog *cat_host, const bfgx_model *model, const bfgx_grid *grid,
+                        const double *map_in_host, double *map_out_host, const bfgx_opts *opts, bfgx_stats *stats);
+int bfgx_paint_grid(const bfgx_grid_catalog *cat_host, const bfgx_model *model, const bfgx_grid *grid,
+                    double *map_out_host, const bfgx_opts *opts, bfgx_stats *stats);
+/* regrid_pixels_2D / regrid_pixels_3D: grid[npix]^ndim += overlap-weighted values; positions [n][ndim] */
+int bfgx_regrid_pixels(int device, int32_t ndim, int32_t npix, int64_t n, const double *positions_host,
+                       const double *values_host, double *grid_inout_host);
+/* ParticleSnapshot.make_map: histogramdd of n particles on edges = linspace(0, L, n_grid + 1) (edges [n_grid + 1]
+ * given by the caller), weights = mass (NULL -> 1).  x, y, z host arrays; z NULL for 2D. */
+int bfgx_deposit_particles(int device, int32_t ndim, int64_t n, const double *x, const double *y, const double *z,
+                           const double *mass, int32_t n_grid, const double *edges, double *map_out_host);
+/* |FFT(map)|^2 averaged in nk linear k-bins between 2 pi / L and the Nyquist frequency (3D, n_grid a power of two):
+ * pk[nk], kcen[nk] (mean |k| per bin), counts[nk] (modes per bin).  Empty bins give NaN as in the notebook. */
+int bfgx_power_spectrum(int device, int32_t n_grid, const double *map_host, double L, int32_t nk,
+                        double *pk, double *kcen, int64_t *counts);
+
+/* resident API: inputs already in HBM; enqueue-only except for one small read-back of the work-item count */
+int  bfgx_grid_plan_create(int device, void *hip_stream, const bfgx_grid *grid_host_bins, int64_t max_halos,
+                           const bfgx_model *model, bfgx_grid_plan **out);
+void bfgx_grid_plan_destroy(bfgx_grid_plan *p);
+/* halo loop of BaryonifyGrid: offsets_dev [npix^ndim][ndim] f64 is zeroed and filled; n_pairs_host optional */
+int  bfgx_grid_offsets_device(bfgx_grid_plan *p, const bfgx_grid_catalog *cat_dev, double *offsets_dev, int64_t *n_pairs_host);
+/* halo loop of PaintProfilesGrid: map_out_dev [npix^ndim] f64 is zeroed and filled */
+int  bfgx_grid_paint_device(bfgx_grid_plan *p, const bfgx_grid_catalog *cat_dev, double *map_out_dev, int64_t *n_pairs_host);
+/* post-loop regrid; map_out_dev is zeroed by the call; sums_dev (optional, double[2], zeroed by the caller)
+ * receives {sum(map_in), sum(map_out)} */
+int  bfgx_grid_regrid_device(bfgx_grid_plan *p, const double *map_in_dev, const double *offsets_dev,
+                             double *map_out_dev, double *sums_dev);
+int  bfgx_grid_plan_timing_enable(bfgx_grid_plan *p, int on);
+int  bfgx_grid_plan_timing_read(bfgx_grid_plan *p, double *ms_sum, int64_t *launches);
+/* device-resident variants of the two deposit kernels and the P(k) summary (all pointers device) */
+int  bfgx_deposit_particles_device(int device, void *hip_stream, int32_t ndim, int64_t n, const double *x, const double *y,
+                                   const double *z, const double *mass, int32_t n_grid, const double *edges_dev,
+                                   double *map_out_dev);
+int  bfgx_power_spectrum_device(int device, void *hip_stream, int32_t n_grid, const double *map_dev, double L, int32_t nk,
+                                double *work_dev /* complex [n_grid][n_grid][n_grid/2+1] */, double *pk_sum_dev,
+                                double *k_sum_dev, unsigned long long *counts_dev);
 
 #ifdef __cplusplus
 }

@@ -566,3 +566,213 @@ i64 bfgo_paint(i64 nside, i64 nhalo,
     free(l.p);
     return total;
 }
+
+/* ====================================================================== regular-grid path
+ * Map2DRunner.py: regrid_pixels_2D :14-83, regrid_pixels_3D :86-163, BaryonifyGrid.process :431-607,
+ * PaintProfilesGrid.process :676-817; io.py ParticleSnapshot.make_map :622-670 (np.histogramdd).
+ * Conventions of the reference kept as they are: meshgrid(indexing='xy') pairs the FIRST array axis of a cutout
+ * with the "y" coordinate (x[i] + dy) and the SECOND with "x" (x[j] + dx), while the first axis is indexed around
+ * x_cen; linspace(-N/2, N/2, N) * res spaces the cutout samples by N/(N-1) pixels.
+ */
+
+/* Python's float % (CPython float_rem; numba follows it) */
+static double py_fmod(double x, double n)
+{
+    double m = fmod(x, n);
+    if (m != 0.0) { if ((n < 0) != (m < 0)) m += n; }
+    else m = copysign(0.0, n);
+    return m;
+}
+
+static double dmin(double a, double b) { return a < b ? a : b; }
+static double dmax(double a, double b) { return a > b ? a : b; }
+
+/* overlap of the unit cell [c, c+1] with [s, e], including the two periodic images (Map2DRunner.py:70-78) */
+static double cell_overlap(i64 c, double s, double e, double N)
+{
+    double d = dmin((double)(c + 1), e) - dmax((double)c, s);
+    if (d < 0) d = dmin((double)(c + 1), e + N) - dmax((double)c, s + N);
+    if (d < 0) d = dmin((double)(c + 1), e - N) - dmax((double)c, s - N);
+    return d;
+}
+
+static i64 wrap_cell(i64 c, i64 N)
+{
+    if (c < 0) c += N;                    /* :61-62 */
+    if (c + 1 > N) c = c % N;
+    return c;
+}
+
+/* regrid_pixels_2D / regrid_pixels_3D: `grid` [N]^ndim is accumulated into; pos [n][ndim]; val [n] */
+void bfgo_regrid_pixels(int ndim, i64 N, i64 n, const double *pos, const double *val, double *grid)
+{
+    const double Nf = (double)N;
+    for (i64 p = 0; p < n; ++p) {
+        double xs = py_fmod(pos[ndim * p + 0], Nf), ys = py_fmod(pos[ndim * p + 1], Nf);
+        double zs = ndim == 3 ? py_fmod(pos[ndim * p + 2], Nf) : 0.0;
+        double xe = xs + 1, ye = ys + 1, ze = zs + 1;
+        const int bound = 2;
+        i64 x_min = (i64)xs - bound, x_max = (i64)xe + bound;
+        i64 y_min = (i64)ys - bound, y_max = (i64)ye + bound;
+        i64 z_min = ndim == 3 ? (i64)zs - bound : 0, z_max = ndim == 3 ? (i64)ze + bound : 1;
+        for (i64 i0 = y_min; i0 < y_max; ++i0)
+            for (i64 j0 = x_min; j0 < x_max; ++j0)
+                for (i64 k0 = z_min; k0 < z_max; ++k0) {
+                    i64 i = wrap_cell(i0, N), j = wrap_cell(j0, N);
+                    double dx = cell_overlap(j, xs, xe, Nf), dy = cell_overlap(i, ys, ye, Nf);
+                    if (ndim == 3) {
+                        i64 k = wrap_cell(k0, N);
+                        double dz = cell_overlap(k, zs, ze, Nf);
+                        if (dx > 0 && dy > 0 && dz > 0) grid[(i * N + j) * N + k] += dx * dy * dz * val[p];
+                    } else if (dx > 0 && dy > 0) {
+                        grid[i * N + j] += dx * dy * val[p];
+                    }
+                }
+    }
+}
+
+static i64 argmin_abs(const double *bins, i64 n, double x)   /* np.argmin(np.abs(bins - x)): first minimum */
+{
+    i64 best = 0; double bv = fabs(bins[0] - x);
+    for (i64 i = 1; i < n; ++i) { double v = fabs(bins[i] - x); if (v < bv) { bv = v; best = i; } }
+    return best;
+}
+
+static void np_linspace_sym(i64 Nsize, double res, double *x)  /* np.linspace(-Nsize/2, Nsize/2, Nsize) * res */
+{
+    double start = -(double)Nsize / 2, stop = (double)Nsize / 2;
+    double step = (stop - start) / (double)(Nsize - 1);
+    for (i64 i = 0; i < Nsize; ++i) { double y = (double)i * step; y += start; x[i] = y; }
+    x[Nsize - 1] = stop;
+    for (i64 i = 0; i < Nsize; ++i) x[i] = x[i] * res;
+}
+
+static void pick_indices(i64 center, i64 width, i64 Npix, i64 *out)   /* Map2DRunner.py:403-429 */
+{
+    for (i64 t = 0; t < 2 * width; ++t) {
+        i64 v = center - width + t;
+        if (v < 0) v += Npix;
+        if (v >= Npix) v -= Npix;
+        out[t] = v;
+    }
+}
+
+/*
+ * Halo loop of BaryonifyGrid.process (mode 0, Map2DRunner.py:476-575) or PaintProfilesGrid.process (mode 1, :708-812).
+ *   bins [npix] pixel centres; a = 1/(1+redshift); R[j] = mass_def.get_radius(cosmo, M_j, a) physical Mpc;
+ *   lnM[j] = the ln M table coordinate.  HaloNDCatalog stores float32 columns (io.py:205) and the read-out takes
+ *   np.log of that float32 scalar (BaryonCorrection.py:369, Tabulate.py:283), i.e. a float32 logarithm whose last
+ *   bit depends on numpy's SIMD logf: the caller evaluates it with numpy and passes the result in;
+ *   Rmod[j] = model-side comoving radius (BaryonCorrection.py:370), used by mode 0 only;
+ *   rmat [nhalo][4] row-major 2x2 shear matrices (use_ellipticity, 2D only) or NULL;
+ *   table: mode 0 displacement table, mode 1 the LOG of raw_input_2D (2D maps) / raw_input_3D (3D maps).
+ *   out: mode 0 pix_offsets [npix^ndim][ndim], mode 1 new_map [npix^ndim]; accumulated into.
+ * Returns the number of (halo, pixel) pairs of the cutouts; *assert_fail is set when the reference's
+ * "Halo offsets ... are larger than res" assert (:516, :747) would fire.
+ */
+i64 bfgo_grid_loop(int mode, int ndim, i64 npix, const double *bins, i64 nhalo,
+                   const double *hx, const double *hy, const double *hz, const double *lnM,
+                   double a, const double *R, const double *Rmod, const double *rmat,
+                   int nextra, const double *const *extra,
+                   int tdim, const int *tn, const double *const *taxes, const double *tvalues,
+                   int rdelta_sampling, double eps_runner, double eps_model, double *out, int *assert_fail)
+{
+    rgi_t t = rgi_make(tdim, tn, taxes, tvalues);
+    const double res = bins[1] - bins[0];
+    double bmax = bins[0];
+    for (i64 i = 1; i < npix; ++i) if (bins[i] > bmax) bmax = bins[i];
+    i64 total = 0;
+    (void)nextra;
+    double *x = (double *)malloc(sizeof(double) * (size_t)(npix + 2));
+    i64 *xi = (i64 *)malloc(sizeof(i64) * (size_t)(npix + 2)), *yi = (i64 *)malloc(sizeof(i64) * (size_t)(npix + 2)),
+        *zi = (i64 *)malloc(sizeof(i64) * (size_t)(npix + 2));
+    if (assert_fail) *assert_fail = 0;
+    for (i64 j = 0; j < nhalo; ++j) {
+        i64 Nsize;
+        double R_j = R[j];
+        if (mode == 0) {
+            double R_q = eps_runner * R_j / a;                        /* :487 */
+            if (R_q < 0) R_q = 0;                                     /* np.clip(R_q, 0, max(bins)/2) :488 */
+            if (R_q > bmax / 2) R_q = bmax / 2;
+            double Ns = 2 * R_q / res;                                /* :496 */
+            Nsize = (i64)floor(Ns / 2) * 2;                           /* :497 */
+            if (Nsize < 2) continue;                                  /* :498 */
+        } else {
+            R_j = R_j / a;                                            /* :718 comoving */
+            double Ns = 2 * eps_runner * R_j / res;                   /* :726 */
+            Nsize = (i64)floor(Ns / 2) * 2;
+            if (Nsize < 2) Nsize = 2;                                 /* np.clip(Nsize, 2, bins.size//2) :728 */
+            if (Nsize > npix / 2) Nsize = npix / 2;
+        }
+        np_linspace_sym(Nsize, res, x);                               /* :500 */
+        i64 w = Nsize / 2;
+        i64 xc = argmin_abs(bins, npix, hx[j]), yc = argmin_abs(bins, npix, hy[j]);
+        i64 zc = ndim == 3 ? argmin_abs(bins, npix, hz[j]) : 0;
+        pick_indices(xc, w, npix, xi);
+        pick_indices(yc, w, npix, yi);
+        if (ndim == 3) pick_indices(zc, w, npix, zi);
+        double dx = bins[xc] - hx[j], dy = bins[yc] - hy[j], dz = ndim == 3 ? bins[zc] - hz[j] : 0.0;
+        if (ndim == 2 && !(dx <= res && dy <= res)) { if (assert_fail) *assert_fail = 1; }
+
+        double tx[BFGO_MAXDIM];
+        tx[0] = log(1.0 / a);
+        tx[1] = lnM[j];
+        for (int k = 3; k < tdim; ++k) tx[k] = extra[k - 3][j];
+        const i64 nk = ndim == 3 ? Nsize : 1;
+        for (i64 i = 0; i < Nsize; ++i)
+            for (i64 jj = 0; jj < Nsize; ++jj)
+                for (i64 k = 0; k < nk; ++k) {
+                    /* meshgrid(x, x[, x], indexing='xy'): x_grid[i,j,k] = x[j], y_grid = x[i], z_grid = x[k] */
+                    double X = x[jj] + dx, Y = x[i] + dy, Z = ndim == 3 ? x[k] + dz : 0.0;
+                    double r = ndim == 3 ? sqrt(X * X + Y * Y + Z * Z) : sqrt(X * X + Y * Y);
+                    double xh = X / r, yh = Y / r, zh = Z / r;
+                    if (rmat) {                                       /* :525-530 (2D only) */
+                        const double *Rm = rmat + 4 * j;
+                        double Xe = X * Rm[0] + Y * Rm[2], Ye = X * Rm[1] + Y * Rm[3];
+                        r = sqrt(Xe * Xe + Ye * Ye);
+                    }
+                    i64 flat = ndim == 3 ? (xi[i] * npix + yi[jj]) * npix + zi[k] : xi[i] * npix + yi[jj];
+                    ++total;
+                    if (mode == 0) {
+                        double Rc = Rmod[j];
+                        tx[2] = rdelta_sampling ? (log(r) - log(Rc)) : log(r);
+                        double d = rgi_eval(&t, tx);
+                        if (!(r < eps_model * Rc)) d = 0.0;           /* BaryonCorrection.py:381-382 */
+                        double off = d / res;                         /* :534 */
+                        out[ndim * flat + 0] += off * xh;
+                        out[ndim * flat + 1] += off * yh;
+                        if (ndim == 3) out[ndim * flat + 2] += off * zh;
+                    } else {
+                        tx[2] = log(r);
+                        double P = exp(rgi_eval(&t, tx));
+                        int ok = isfinite(P) && (r < R_j * eps_runner);   /* :800-801 */
+                        if (ok) out[flat] += P;
+                    }
+                }
+    }
+    free(x); free(xi); free(yi); free(zi);
+    return total;
+}
+
+/* np.histogramdd(coords, bins=(edges,)*ndim, weights=w): edges [nedge] ascending; last edge inclusive */
+void bfgo_histogramdd(int ndim, i64 n, const double *const *coords, const double *weights, i64 nedge, const double *edges, double *out)
+{
+    const i64 nb = nedge - 1;
+    for (i64 p = 0; p < n; ++p) {
+        i64 idx[3] = {0, 0, 0};
+        int ok = 1;
+        for (int d = 0; d < ndim && ok; ++d) {
+            double v = coords[d][p];
+            /* searchsorted(edges, v, side='right') */
+            i64 lo = 0, hi = nedge;
+            while (lo < hi) { i64 mid = (lo + hi) >> 1; if (edges[mid] <= v) lo = mid + 1; else hi = mid; }
+            i64 c = lo;
+            if (v == edges[nedge - 1]) c -= 1;
+            if (c < 1 || c > nb || v != v) ok = 0;
+            idx[d] = c - 1;
+        }
+        if (!ok) continue;
+        i64 flat = ndim == 3 ? (idx[0] * nb + idx[1]) * nb + idx[2] : idx[0] * nb + idx[1];
+        out[flat] += weights ? weights[p] : 1.0;
+    }
+}

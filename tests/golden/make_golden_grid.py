@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""
+Generates tests/golden/grid_*.npz by running the UNMODIFIED reference (imported from /root/reference through the
+oracle/refshim stand-ins for pyccl / healpy / numba) on small synthetic inputs.  Build container only:
+
+    python tests/golden/make_golden_grid.py
+
+Reference code exercised as shipped:
+
+    BaryonForge.Runners.BaryonifyGrid.process        (Map2DRunner.py:431-607), 2D, 2D + ellipticity, 3D
+    BaryonForge.Runners.PaintProfilesGrid.process    (Map2DRunner.py:676-817), 2D and 3D
+    BaryonForge.Runners.regrid_pixels_2D / _3D       (Map2DRunner.py:14-163; numba.njit -> plain Python here)
+    BaryonForge.utils.HaloNDCatalog / GriddedMap / ParticleSnapshot.make_map   (io.py)
+
+Each fixture stores inputs and the reference's output (data only).  The oracle-vs-reference residual is printed
+for every case (the oracle's pin).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+from oracle.refshim import install  # noqa: E402
+
+install.install()
+import BaryonForge as bfg  # noqa: E402  (the reference, from /root/reference)
+
+from baryonification_amd import synthetic as syn  # noqa: E402
+from oracle import grid as G  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+import make_golden as MG  # noqa: E402  (reference-model builders)
+
+COSMO = dict(syn.COSMO, w0=-0.9)        # w0 != -1 on purpose: the grid runners must ignore it (Map2DRunner.py:456-459)
+
+
+def grid_catalog(N, L, seed, logM_lo, logM_hi, ndim, ell=False):
+    rng = np.random.default_rng(seed)
+    cat = {'M': 10 ** rng.uniform(logM_lo, logM_hi, N), 'x': rng.uniform(0, L, N), 'y': rng.uniform(0, L, N),
+           'z': rng.uniform(0, L, N) if ndim == 3 else None}
+    # hand-placed halos: box corners / edges (periodic wrap of the cutout), one beyond the last pixel centre
+    cat['x'][:4] = [0.01 * L, 0.995 * L, 0.5 * L, 0.0]
+    cat['y'][:4] = [0.99 * L, 0.002 * L, 0.5 * L, 0.0]
+    if ndim == 3:
+        cat['z'][:4] = [0.5 * L, 0.999 * L, 0.001 * L, 0.0]
+    cat['M'][:4] = 10 ** (logM_hi - np.array([0.0, 0.1, 0.2, 0.3]))
+    extra = {}
+    if ell:
+        extra['q_ell'] = rng.uniform(0.4, 1.0, N)
+        extra['q_ell'][5] = 1.0 - 1e-6                      # the small-eta series branch of build_Rmat
+        A = rng.normal(size=(N, 2))
+        extra['A_ell'] = A
+    return cat, extra
+
+
+def run_grid(name, kind, shape, L, cat, extra, redshift, eps_runner, eps_model, table_axes, table, map_seed=3,
+             rdelta=False, cosmo_model=None):
+    ndim = len(shape)
+    N = shape[0]
+    bins = (np.arange(N) + 0.5) * (L / N)
+    z, M, r_axis = table_axes
+    cosmo_model = cosmo_model or COSMO
+    HCat = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], M=cat['M'], redshift=redshift, cosmo=COSMO, z=cat['z'], **extra)
+    used = {k: np.array(HCat.cat[k], dtype=np.float64) for k in ('M', 'x', 'y', 'z')}      # float32-rounded by the catalog
+    for k in extra:
+        used[k] = np.array(HCat.cat[k], dtype=np.float64)
+    ell = 'q_ell' in extra
+    t0 = time.time()
+    bg = G.grid_background(COSMO)
+    rmat = None
+    if ell:
+        # per-halo matrices exactly as the runner builds them (float32 catalog columns, Map2DRunner.py:490-493, :528)
+        runner0 = bfg.Runners.DefaultRunnerGrid.__new__(bfg.Runners.DefaultRunnerGrid)
+        rmat = np.zeros((used['M'].size, 2, 2))
+        for j in range(used['M'].size):
+            A_j = HCat.cat['A_ell'][j]
+            A_j = A_j / np.sqrt(np.sum(A_j ** 2))
+            rmat[j] = runner0.build_Rmat(A_j, HCat.cat['q_ell'][j])
+    if kind == 'baryonify':
+        rng = np.random.default_rng(map_seed)
+        hmap = rng.poisson(3.0, shape).astype(np.float64)
+        GMap = bfg.utils.GriddedMap(map=hmap, redshift=redshift, bins=bins, cosmo=COSMO)
+        model = MG.ref_displacement_model(z, M, r_axis, table, rdelta, eps_model, cosmo_model)
+        out = bfg.Runners.BaryonifyGrid(HCat, GMap, eps_runner, model, use_ellipticity=ell, verbose=False).process()
+        otab = O.Table([np.log(1 + z), np.log(M), np.log(r_axis)], table, rdelta, eps_model)
+        oout = G.baryonify_grid(hmap, bins, used, redshift, otab, eps_runner, bg, O.Background.from_dict(cosmo_model), rmat)
+    else:
+        hmap = np.zeros(shape)
+        GMap = bfg.utils.GriddedMap(map=hmap, redshift=redshift, bins=bins, cosmo=COSMO)
+        model = MG.ref_tabulated_profile(z, M, r_axis, table, cosmo_model)
+        out = bfg.Runners.PaintProfilesGrid(HCat, GMap, eps_runner, model, use_ellipticity=ell, verbose=False).process()
+        with np.errstate(divide='ignore'):
+            otab = O.Table([np.log(1 + z), np.log(M), np.log(r_axis)], np.log(table))
+        oout = G.paint_grid(shape, bins, used, redshift, otab, eps_runner, bg, rmat)
+    dt = time.time() - t0
+    scale = np.abs(out).max()
+    print(f"{name:20s} {kind:9s} shape={shape} N={used['M'].size:4d} ref+oracle {dt:6.1f}s  "
+          f"max|oracle-ref|/max|ref| = {np.abs(oout - out).max() / scale:.3e}   changed px = {int((out != hmap).sum())}")
+    np.savez_compressed(
+        os.path.join(HERE, name + '.npz'), kind=kind, ndim=ndim, npix=N, L=L, bins=bins, redshift=redshift,
+        eps_runner=eps_runner, eps_model=eps_model, rdelta=rdelta,
+        cat_M=used['M'], cat_x=used['x'], cat_y=used['y'], cat_z=used['z'],
+        rmat=rmat if rmat is not None else np.zeros(0),
+        tab_z=z, tab_M=M, tab_r=r_axis, tab_values=table,
+        map_in=hmap.astype(np.uint8) if kind == 'baryonify' else np.zeros(0, dtype=np.uint8),
+        cosmo_runner=np.array([COSMO[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+        cosmo_model=np.array([cosmo_model[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+        expected=out)
+
+
+def table_for(redshift, logM_lo, logM_hi, NR=160, R_min=1e-3, R_max=2e2):
+    z = np.linspace(max(redshift - 0.05, 0.0), redshift + 0.05, 3)
+    M = np.geomspace(10 ** (logM_lo - 0.05), 10 ** (logM_hi + 0.05), 7)
+    r = np.geomspace(R_min, R_max, NR)
+    return z, M, r
+
+
+def run_regrid(name, shape, n, seed):
+    """regrid_pixels_2D / _3D on arbitrary positions: far outside the box, negative, exactly on cell edges"""
+    rng = np.random.default_rng(seed)
+    ndim = len(shape)
+    N = shape[0]
+    pos = rng.uniform(-2.5 * N, 3.5 * N, (n, ndim))
+    pos[:8] = np.round(pos[:8])                                  # on cell edges
+    pos[8, :] = 0.0
+    pos[9, :] = N
+    pos[10, :] = -1e-17                                          # % N rounds to N exactly
+    pos[11, :] = N - 1e-13
+    val = rng.uniform(0.5, 2.0, n)
+    grid = np.zeros(shape)
+    (bfg.Runners.regrid_pixels_2D if ndim == 2 else bfg.Runners.regrid_pixels_3D)(grid, pos, val)
+    ogrid = G.regrid_pixels(np.zeros(shape), pos, val)
+    print(f"{name:20s} regrid    shape={shape} n={n:5d}  max|oracle-ref| = {np.abs(ogrid - grid).max():.3e}  "
+          f"sum ref/val = {grid.sum() / val.sum():.15f}")
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), kind='regrid', ndim=ndim, npix=N, pos=pos, val=val, expected=grid)
+
+
+def run_make_map(name, ndim, n, L, N_grid, seed):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(0, L, (n, 3))
+    xyz[:3] = [[0.0, 0.0, 0.0], [L, L, L], [L, 0.5 * L, 0.0]]    # both box edges (the last edge is inclusive)
+    xyz[3] = [L * (1 + 1e-9), 0.3 * L, 0.2 * L]                  # outside -> dropped
+    edges = np.linspace(0, L, N_grid + 1)
+    xyz[4:4 + 6, 0] = edges[3:9]                                 # exactly on interior edges
+    mass = rng.uniform(0.5, 1.5, n)
+    Snap = bfg.utils.ParticleSnapshot(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2] if ndim == 3 else None, M=mass, L=L,
+                                      redshift=0.0, cosmo=COSMO)
+    out = Snap.make_map(N_grid)
+    oout = G.make_map([xyz[:, d] for d in range(ndim)], mass, L, N_grid)
+    print(f"{name:20s} make_map  ndim={ndim} n={n}  max|oracle-ref| = {np.abs(oout - out).max():.3e}  kept mass frac = "
+          f"{out.sum() / mass.sum():.6f}")
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), kind='make_map', ndim=ndim, L=L, N_grid=N_grid, xyz=xyz, mass=mass,
+                        expected=out)
+
+
+def main():
+    # 2D: 96^2 pixels of 1.5 Mpc; cutouts of 2 ... 48 pixels, periodic wrap, masked (eps_model < eps_runner) pixels
+    L, N, zr = 144.0, 96, 0.25
+    cat, extra = grid_catalog(80, L, 5, 12.6, 15.2, 2)
+    ax = table_for(zr, 12.6, 15.2)
+    run_grid('grid2d_baryonify', 'baryonify', (N, N), L, cat, {}, zr, 6.0, 4.5, ax, syn.displacement_table(*ax))
+    cat, extra = grid_catalog(60, L, 6, 12.6, 15.2, 2, ell=True)
+    run_grid('grid2d_baryonify_ell', 'baryonify', (N, N), L, cat, extra, zr, 5.0, 20.0, ax, syn.displacement_table(*ax))
+    cat, extra = grid_catalog(80, L, 7, 12.0, 15.2, 2)
+    ax = table_for(zr, 12.0, 15.2)
+    P = syn.paint_table(*ax)
+    P[ax[2][None, None, :] / syn._Rc(ax[0], ax[1])[:, :, None] > 5.0] = 0.0
+    run_grid('grid2d_paint', 'paint', (N, N), L, cat, {}, zr, 4.0, 0.0, ax, P)
+    cat, extra = grid_catalog(40, L, 8, 12.6, 15.2, 2, ell=True)
+    run_grid('grid2d_paint_ell', 'paint', (N, N), L, cat, extra, zr, 4.0, 0.0, ax, syn.paint_table(*ax))
+
+    # 3D: 28^3 pixels of 2.5 Mpc (the reference's regrid runs as plain Python here)
+    L, N, zr = 70.0, 28, 0.0
+    cat, extra = grid_catalog(40, L, 9, 13.0, 15.3, 3)
+    ax = table_for(zr, 13.0, 15.3, NR=140)
+    run_grid('grid3d_baryonify', 'baryonify', (N, N, N), L, cat, {}, zr, 5.0, 20.0, ax, syn.displacement_table(*ax),
+             cosmo_model=MG.COSMO_B)
+    cat, extra = grid_catalog(40, L, 10, 12.5, 15.3, 3)
+    ax = table_for(zr, 12.5, 15.3, NR=140)
+    run_grid('grid3d_paint', 'paint', (N, N, N), L, cat, {}, zr, 3.0, 0.0, ax, syn.paint_table(*ax))
+
+    run_regrid('grid2d_regrid', (37, 37), 600, 21)
+    run_regrid('grid3d_regrid', (11, 11, 11), 400, 22)
+    run_make_map('grid2d_make_map', 2, 5000, 50.0, 32, 31)
+    run_make_map('grid3d_make_map', 3, 5000, 50.0, 16, 32)
+
+
+if __name__ == '__main__':
+    main()

@@ -63,3 +63,79 @@ def product_runner(g, acc_f64=None):
         runner = bfg.Runners.PaintProfilesShell(Catalog, Shell, g['eps_runner'], model, verbose=False)
     runner.acc_f64 = acc_f64
     return runner
+
+
+# ------------------------------------------------------------------------------------------ regular-grid path
+GRID_RUNNER_CASES = ['grid2d_baryonify', 'grid2d_baryonify_ell', 'grid2d_paint', 'grid2d_paint_ell', 'grid3d_baryonify',
+                     'grid3d_paint']
+
+
+def load_grid_golden(name):
+    f = np.load(os.path.join(GOLDEN, name + '.npz'))
+    g = {k: f[k] for k in f.files}
+    g['kind'] = str(g['kind'])
+    for k in ('ndim', 'npix'):
+        if k in g:
+            g[k] = int(g[k])
+    if g['kind'] in ('baryonify', 'paint'):
+        g['rdelta'] = bool(g['rdelta'])
+        for k in ('L', 'redshift', 'eps_runner', 'eps_model'):
+            g[k] = float(g[k])
+        g['cosmo_runner'] = dict(zip(COSMO_KEYS, g['cosmo_runner'].tolist()))
+        g['cosmo_model'] = dict(zip(COSMO_KEYS, g['cosmo_model'].tolist()))
+        g['cat'] = {'M': g['cat_M'], 'x': g['cat_x'], 'y': g['cat_y'], 'z': g['cat_z']}
+        g['rmat'] = g['rmat'] if g['rmat'].size else None
+        g['shape'] = (g['npix'],) * g['ndim']
+        g['map_in'] = g['map_in'].astype(np.float64)
+    return g
+
+
+def grid_oracle_run(g):
+    from oracle import grid as G
+    from oracle import oracle as O
+    axes = [np.log(1 + g['tab_z']), np.log(g['tab_M']), np.log(g['tab_r'])]
+    bg = G.grid_background(g['cosmo_runner'])
+    if g['kind'] == 'baryonify':
+        tab = O.Table(axes, g['tab_values'], g['rdelta'], g['eps_model'])
+        return G.baryonify_grid(g['map_in'], g['bins'], g['cat'], g['redshift'], tab, g['eps_runner'], bg,
+                                O.Background.from_dict(g['cosmo_model']), g['rmat'])
+    with np.errstate(divide='ignore'):
+        tab = O.Table(axes, np.log(g['tab_values']))
+    return G.paint_grid(g['shape'], g['bins'], g['cat'], g['redshift'], tab, g['eps_runner'], bg, g['rmat'])
+
+
+class _FixedRmat(object):
+    """mixin for the *_ell fixtures: they store the shear matrices the reference built (from float32 q_ell / A_ell
+    columns that are not kept), so the product runner is handed those instead of re-deriving them"""
+    _rmat_fixture = None
+
+    def _rmats(self, what):
+        return self._rmat_fixture
+
+
+def grid_product_runner(g):
+    """the product's drop-in objects for a grid fixture, built as a BaryonForge user would"""
+    import baryonification_amd as bfg
+    cat = g['cat']
+    ell = g['rmat'] is not None
+    extra = {}
+    if ell:         # placeholders: the constructor asserts the columns exist; the matrices come from the fixture
+        extra = {'q_ell': np.ones(cat['M'].size), 'A_ell': np.ones((cat['M'].size, 2))}
+    HCat = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], M=cat['M'], redshift=g['redshift'], cosmo=g['cosmo_runner'],
+                                   z=cat['z'] if g['ndim'] == 3 else None, **extra)
+    cosmo_model = bfg.utils.Cosmology.from_dict(g['cosmo_model'])
+    if g['kind'] == 'baryonify':
+        GMap = bfg.utils.GriddedMap(map=g['map_in'].reshape(g['shape']), redshift=g['redshift'], bins=g['bins'], cosmo=g['cosmo_runner'])
+        model = bfg.Profiles.Baryonification2D(None, None, cosmo_model, epsilon_max=g['eps_model'])
+        model.set_table(g['tab_z'], g['tab_M'], g['tab_r'], g['tab_values'], Rdelta_sampling=g['rdelta'])
+        base = bfg.Runners.BaryonifyGrid
+    else:
+        GMap = bfg.utils.GriddedMap(map=np.zeros(g['shape']), redshift=g['redshift'], bins=g['bins'], cosmo=g['cosmo_runner'])
+        model = bfg.utils.TabulatedProfile(None, cosmo_model)
+        model.set_table(g['tab_z'], g['tab_M'], g['tab_r'], g['tab_values'])
+        base = bfg.Runners.PaintProfilesGrid
+    cls = type(base.__name__, (_FixedRmat, base), {}) if ell else base
+    runner = cls(HCat, GMap, g['eps_runner'], model, use_ellipticity=ell, verbose=False)
+    if ell:
+        runner._rmat_fixture = g['rmat']
+    return runner

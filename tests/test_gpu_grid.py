@@ -1,0 +1,210 @@
+"""Parity of the regular-grid HIP path (csrc/bfgx_grid.hpp, bfgx_fft.hpp), called through the drop-in runners and
+functions (-> ctypes -> C ABI), against (a) the reference's own outputs (tests/golden/grid_*.npz) and (b) the CPU
+oracle on the same inputs at sizes the oracle finishes in seconds.
+
+Stated tolerances: everything on this path is fp64 (geometry, read-out, accumulation by fp64 atomics); differences
+are libm ulps and atomic summation order                               ->  |d| <= 1e-10 * max|map|
+regrid_pixels_* / make_map have no libm in them                        ->  1e-13 * max (summation order only)
+P(k): fp64 radix-2 FFT vs numpy's pocketfft, bin sums in another order ->  1e-10 relative per bin
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', H.GRID_RUNNER_CASES)
+def test_grid_runner_vs_reference_golden(gpu, name):
+    g = H.load_grid_golden(name)
+    out = H.grid_product_runner(g).process()
+    exp = g['expected']
+    assert out.dtype == np.float64 and out.shape == exp.shape
+    assert np.abs(out - exp).max() <= 1e-10 * np.abs(exp).max()
+    if g['kind'] == 'baryonify':
+        assert np.isclose(out.sum(), g['map_in'].sum())
+
+
+@pytest.mark.parametrize('name', H.GRID_RUNNER_CASES)
+def test_grid_runner_vs_oracle(gpu, name):
+    g = H.load_grid_golden(name)
+    out = H.grid_product_runner(g).process()
+    ora = H.grid_oracle_run(g)
+    assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
+
+
+@pytest.mark.parametrize('name', ['grid2d_regrid', 'grid3d_regrid'])
+def test_regrid_pixels_vs_reference_golden(gpu, name):
+    import baryonification_amd as bfg
+    g = H.load_grid_golden(name)
+    grid = np.zeros((g['npix'],) * g['ndim'])
+    (bfg.Runners.regrid_pixels_2D if g['ndim'] == 2 else bfg.Runners.regrid_pixels_3D)(grid, g['pos'], g['val'])
+    assert np.abs(grid - g['expected']).max() <= 1e-13 * np.abs(g['expected']).max()
+    # in place and additive, like the reference's njit function
+    (bfg.Runners.regrid_pixels_2D if g['ndim'] == 2 else bfg.Runners.regrid_pixels_3D)(grid, g['pos'], g['val'])
+    assert np.abs(grid - 2 * g['expected']).max() <= 1e-13 * np.abs(g['expected']).max()
+
+
+@pytest.mark.parametrize('name', ['grid2d_make_map', 'grid3d_make_map'])
+def test_make_map_vs_reference_golden(gpu, name):
+    import baryonification_amd as bfg
+    g = H.load_grid_golden(name)
+    xyz = g['xyz']
+    Snap = bfg.utils.ParticleSnapshot(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2] if g['ndim'] == 3 else None, M=g['mass'],
+                                      L=float(g['L']), redshift=0.0, cosmo=H.load_grid_golden('grid2d_paint')['cosmo_runner'])
+    out = Snap.make_map(int(g['N_grid']))
+    assert out.shape == g['expected'].shape
+    assert np.abs(out - g['expected']).max() <= 1e-13 * np.abs(g['expected']).max()
+    assert np.array_equal(out != 0, g['expected'] != 0)            # bin membership is exact (edges, inclusive last edge)
+
+
+@pytest.mark.parametrize('N,Nk', [(32, 12), (64, 180)])
+def test_power_spectrum_vs_numpy_restatement(gpu, N, Nk):
+    from baryonification_amd.engine import power_spectrum
+    from oracle import grid as G
+    rng = np.random.default_rng(N)
+    Map = rng.poisson(4.0, (N, N, N)).astype(np.float64)
+    Map[3, 5, 7] += 500.0
+    L = 305.0
+    k_cen, Pk, k_c = power_spectrum(Map, L, Nk)
+    ok_cen, oPk, ok_c = G.power_spectrum(Map, L, Nk)
+    assert np.array_equal(k_c, ok_c)
+    good = ok_c > 0
+    assert np.array_equal(np.isnan(Pk), ~good)
+    assert np.abs(Pk[good] / oPk[good] - 1).max() <= 1e-10
+    assert np.abs(k_cen[good] / ok_cen[good] - 1).max() <= 1e-12
+
+
+def _big_case(ndim, N, nh, seed):
+    """synthetic grid case above the fixture sizes: many halos, overlapping cutouts, periodic wraps"""
+    from baryonification_amd import synthetic as syn
+    rng = np.random.default_rng(seed)
+    L = 2.0 * N
+    bins = (np.arange(N) + 0.5) * (L / N)
+    M = (10 ** rng.uniform(12.5, 15.0, nh)).astype(np.float32).astype(np.float64)
+    pos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    zr = 0.3
+    z = np.linspace(zr - 0.05, zr + 0.05, 3)
+    Mt = np.geomspace(10 ** 12.4, 10 ** 15.1, 8)
+    r = np.geomspace(1e-3, 2e2, 200)
+    cat = {'M': M, 'x': pos[:, 0], 'y': pos[:, 1], 'z': pos[:, 2]}
+    hmap = rng.poisson(2.0, (N,) * ndim).astype(np.float64)
+    return dict(ndim=ndim, N=N, L=L, bins=bins, cat=cat, redshift=zr, z=z, Mt=Mt, r=r, map=hmap,
+                d=syn.displacement_table(z, Mt, r), P=syn.paint_table(z, Mt, r), cosmo=dict(syn.COSMO))
+
+
+@pytest.mark.parametrize('ndim,N,nh', [(2, 512, 4000), (3, 80, 1500)])
+def test_grid_baryonify_vs_oracle_larger(gpu, ndim, N, nh):
+    import baryonification_amd as bfg
+    from oracle import grid as G
+    from oracle import oracle as O
+    c = _big_case(ndim, N, nh, 100 + ndim)
+    cat = c['cat']
+    HCat = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], z=cat['z'] if ndim == 3 else None, M=cat['M'], redshift=c['redshift'],
+                                   cosmo=c['cosmo'])
+    GMap = bfg.utils.GriddedMap(map=c['map'], redshift=c['redshift'], bins=c['bins'], cosmo=c['cosmo'])
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(c['cosmo']), epsilon_max=8.0)
+    model.set_table(c['z'], c['Mt'], c['r'], c['d'])
+    runner = bfg.Runners.BaryonifyGrid(HCat, GMap, 6.0, model, verbose=False)
+    out = runner.process()
+    tab = O.Table([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], c['d'], False, 8.0)
+    off, pairs = G.baryonify_grid_offsets(c['map'].shape, c['bins'], cat, c['redshift'], tab, 6.0, G.grid_background(c['cosmo']),
+                                          return_pairs=True)
+    ora = G.regrid_offsets(c['map'], off)
+    assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
+    assert np.isclose(out.sum(), c['map'].sum(), rtol=1e-12)
+    assert 0 < runner.last_stats['n_pairs'] <= pairs           # contributing pairs <= cutout pixels
+
+
+def test_grid_paint_3d_vs_oracle_larger(gpu):
+    import baryonification_amd as bfg
+    from oracle import grid as G
+    from oracle import oracle as O
+    c = _big_case(3, 96, 3000, 7)
+    cat = c['cat']
+    HCat = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], z=cat['z'], M=cat['M'], redshift=c['redshift'], cosmo=c['cosmo'])
+    GMap = bfg.utils.GriddedMap(map=np.zeros((96,) * 3), redshift=c['redshift'], bins=c['bins'], cosmo=c['cosmo'])
+    model = bfg.utils.TabulatedProfile(None, bfg.utils.Cosmology.from_dict(c['cosmo']))
+    model.set_table(c['z'], c['Mt'], c['r'], c['P'], table_3D=2.0 * c['P'])        # 3D maps read raw_input_3D
+    out = bfg.Runners.PaintProfilesGrid(HCat, GMap, 4.0, model, verbose=False).process()
+    tab = O.Table([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], np.log(2.0 * c['P']))
+    ora = G.paint_grid((96,) * 3, c['bins'], cat, c['redshift'], tab, 4.0, G.grid_background(c['cosmo']))
+    assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
+
+
+def test_grid_nan_poisoning_and_invalid_halos(gpu):
+    """a halo outside the table's mass range poisons (-> zeroes) the offsets of every pixel of its ball, exactly as the
+    reference's post-loop np.where(np.isfinite(...)) does; NaN / non-positive halos are ignored"""
+    import baryonification_amd as bfg
+    from oracle import grid as G
+    from oracle import oracle as O
+    c = _big_case(2, 128, 300, 9)
+    cat = {k: v.copy() for k, v in c['cat'].items()}
+    cat['M'][0] = 3e15                                         # above the table's last mass node
+    HCat = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], M=cat['M'], redshift=c['redshift'], cosmo=c['cosmo'])
+    used = {k: np.array(HCat.cat[k], dtype=np.float64) for k in ('M', 'x', 'y', 'z')}
+    GMap = bfg.utils.GriddedMap(map=c['map'], redshift=c['redshift'], bins=c['bins'], cosmo=c['cosmo'])
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(c['cosmo']), epsilon_max=8.0)
+    model.set_table(c['z'], c['Mt'], c['r'], c['d'])
+    out = bfg.Runners.BaryonifyGrid(HCat, GMap, 6.0, model, verbose=False).process()
+    tab = O.Table([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], c['d'], False, 8.0)
+    ora = G.baryonify_grid(c['map'], c['bins'], used, c['redshift'], tab, 6.0, G.grid_background(c['cosmo']))
+    assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
+    # invalid rows change nothing
+    bad = {k: np.concatenate([v, [np.nan if k == 'M' else 10.0, -1.0 if k == 'M' else 20.0]]) for k, v in used.items()}
+    HCat2 = bfg.utils.HaloNDCatalog(x=bad['x'], y=bad['y'], M=bad['M'], redshift=c['redshift'], cosmo=c['cosmo'])
+    out2 = bfg.Runners.BaryonifyGrid(HCat2, GMap, 6.0, model, verbose=False).process()
+    assert np.abs(out2 - out).max() <= 1e-12 * np.abs(out).max()
+
+
+def test_grid_work_item_table_regrowth(gpu):
+    """the work-item table starts too small (BFGX_GRID_ITEM_CAP) and is regrown inside the call: same result"""
+    c = H.load_grid_golden('grid3d_baryonify')
+    base = H.grid_product_runner(c).process()
+    os.environ['BFGX_GRID_ITEM_CAP'] = '3'
+    try:
+        again = H.grid_product_runner(c).process()
+    finally:
+        del os.environ['BFGX_GRID_ITEM_CAP']
+    assert np.abs(again - base).max() <= 1e-12 * np.abs(base).max()
+
+
+def test_grid_plan_resident_path(gpu):
+    """device-resident GridPlan (what bench.py --mode grid uses) == one-shot host API"""
+    import torch
+    import baryonification_amd as bfg
+    from baryonification_amd import _lib, engine
+    c = _big_case(3, 64, 800, 5)
+    cat = c['cat']
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(c['cosmo']), epsilon_max=8.0)
+    model.set_table(c['z'], c['Mt'], c['r'], c['d'])
+    HCat = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], z=cat['z'], M=cat['M'], redshift=c['redshift'], cosmo=c['cosmo'])
+    GMap = bfg.utils.GriddedMap(map=c['map'], redshift=c['redshift'], bins=c['bins'], cosmo=c['cosmo'])
+    host = bfg.Runners.BaryonifyGrid(HCat, GMap, 6.0, model, verbose=False).process()
+
+    cos = dict(c['cosmo'], w0=-1.0)
+    m, keep = engine.model_from_tables([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], c['d'], cos, 6.0, 8.0)
+    dev = torch.device('cuda:0')
+    t = {k: torch.tensor(cat[k], dtype=torch.float64, device=dev) for k in ('M', 'x', 'y', 'z')}
+    lnM = torch.tensor(np.log(cat['M'].astype(np.float32)).astype(np.float64), device=dev)
+    plan = engine.GridPlan(m, keep, c['bins'], 3, c['redshift'], cat['M'].size, 0, torch.cuda.current_stream().cuda_stream)
+    dcat = _lib.make_grid_catalog_dev(cat['M'].size, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(),
+                                      lnM.data_ptr())
+    off = torch.empty((64 ** 3, 3), dtype=torch.float64, device=dev)
+    m_in = torch.tensor(c['map'], device=dev)
+    m_out = torch.empty_like(m_in)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.timing_enable(True)
+    npairs = plan.offsets(dcat, off.data_ptr())
+    plan.regrid(m_in.data_ptr(), off.data_ptr(), m_out.data_ptr(), sums.data_ptr())
+    torch.cuda.synchronize()
+    tm = plan.timing_read()
+    assert npairs > 0 and tm['offsets'][1] == 1 and tm['regrid'][1] == 1
+    out = m_out.cpu().numpy()
+    assert np.abs(out - host).max() <= 1e-12 * np.abs(host).max()
+    s = sums.cpu().numpy()
+    assert np.isclose(s[0], c['map'].sum()) and np.isclose(s[1], s[0], rtol=1e-12)
+    plan.close()

@@ -104,3 +104,59 @@ def test_host_readouts_match_oracle_rgi():
     assert np.array_equal(np.isnan(d), np.isnan(exp)) and np.isnan(d).any()
     assert np.nanmax(np.abs(d - exp)) < 1e-15
     assert np.ndim(r.model.displacement(1.0, M, a)) == 0
+
+
+# ------------------------------------------------------------------------------------------ regular-grid path
+
+def test_grid_containers_match_reference_layout():
+    rng = np.random.default_rng(1)
+    x, y, z, M = rng.uniform(0, 50, 5), rng.uniform(0, 50, 5), rng.uniform(0, 50, 5), 10 ** rng.uniform(12, 15, 5)
+    A = rng.normal(size=(5, 2))
+    cat = bfg.utils.HaloNDCatalog(x=x, y=y, M=M, redshift=0.2, cosmo=syn.COSMO, z=z, q_ell=np.full(5, 0.7), A_ell=A)
+    assert cat.cat.dtype.names == ('M', 'x', 'y', 'z', 'q_ell', 'A_ell')
+    assert cat.cat.dtype['M'] == np.dtype('>f4') and cat.cat['A_ell'].shape == (5, 2)      # io.py:205-206
+    assert np.array_equal(cat.cat['M'], M.astype(np.float32)) and cat.redshift == 0.2
+    assert cat.cosmology is syn.COSMO and cat[1:3].cat.size == 2 and cat[1:3].redshift == 0.2
+    cat2 = bfg.utils.HaloNDCatalog(x=x, y=y, M=M, redshift=0.0, cosmo=syn.COSMO)
+    assert np.all(cat2.cat['z'] == 0)
+    with pytest.raises(ValueError):
+        bfg.utils.HaloNDCatalog(x=x, y=y, M=M, redshift=0.0, cosmo={'Omega_m': 0.3})
+
+    bins = (np.arange(16) + 0.5) * 2.0
+    g2 = bfg.utils.GriddedMap(map=np.zeros((16, 16)), redshift=0.1, bins=bins, cosmo=syn.COSMO)
+    assert g2.is2D and g2.Npix == 16 and g2.res == 2.0 and g2.inds.shape == (16, 16) and len(g2.grid) == 2
+    g3 = bfg.utils.GriddedMap(map=np.zeros((16, 16, 16)), redshift=0.1, bins=bins, cosmo=syn.COSMO)
+    assert not g3.is2D and g3.inds[1, 2, 3] == (1 * 16 + 2) * 16 + 3 and g3.data is g3.map
+    with pytest.raises(AssertionError):
+        bfg.utils.GriddedMap(map=np.zeros((16, 8)), redshift=0.1, bins=bins, cosmo=syn.COSMO)
+
+    snap = bfg.utils.ParticleSnapshot(x=x, y=y, z=None, M=np.ones(5), L=50.0, redshift=0.0, cosmo=syn.COSMO)
+    assert snap.is2D and snap.cat.dtype['x'] == np.float64 and np.all(snap.cat['z'] == 0)
+
+
+def test_grid_runner_contract():
+    rng = np.random.default_rng(2)
+    bins = (np.arange(16) + 0.5) * 2.0
+    cat = bfg.utils.HaloNDCatalog(x=rng.uniform(0, 32, 4), y=rng.uniform(0, 32, 4), M=np.full(4, 1e14), redshift=0.2, cosmo=syn.COSMO)
+    gmap = bfg.utils.GriddedMap(map=np.ones((16, 16)), redshift=0.2, bins=bins, cosmo=syn.COSMO)
+    r = bfg.Runners.BaryonifyGrid(cat, gmap, 5.0, None)
+    for name in ('HaloNDCatalog', 'GriddedMap', 'cosmo', 'model', 'epsilon_max', 'mass_def', 'verbose', 'use_ellipticity'):
+        assert hasattr(r, name)
+    assert r.cosmo is cat.cosmology and r._runner_cosmo()['w0'] == -1.0          # Map2DRunner.py:456-459 drops w0
+    assert pickle.loads(pickle.dumps(r)).epsilon_max == 5.0
+    assert np.array_equal(r.pick_indices(1, 3, 16), [14, 15, 0, 1, 2, 3])
+    with pytest.raises(AssertionError, match='q_ell'):
+        bfg.Runners.BaryonifyGrid(cat, gmap, 5.0, None, use_ellipticity=True)
+    with pytest.raises(AssertionError, match='must provide a model'):
+        bfg.Runners.PaintProfilesGrid(cat, gmap, 5.0, None).process()
+    # build_Rmat: the shear matrix has unit determinant and reduces to the identity for q -> 1
+    Rm = r.build_Rmat(np.array([0.6, 0.8]), 0.5)
+    assert np.isclose(np.linalg.det(Rm), 1.0) and np.allclose(Rm, Rm.T)
+    assert np.allclose(r.build_Rmat(np.array([1.0, 0.0]), 1.0 - 1e-9), np.eye(2), atol=1e-8)
+    with pytest.raises(NotImplementedError):
+        r.build_Rmat(np.array([1.0, 0.0, 0.0]), 0.5)
+    # argument checks of the regrid functions happen before any device work
+    with pytest.raises(ValueError):
+        bfg.Runners.regrid_pixels_2D(np.zeros((8, 8), dtype=np.float32), np.zeros((3, 2)), np.zeros(3))
+    with pytest.raises(ValueError):
+        bfg.Runners.regrid_pixels_3D(np.zeros((8, 8, 8)), np.zeros((3, 2)), np.zeros(3))
