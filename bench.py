@@ -39,8 +39,12 @@ def parse():
     ap.add_argument('--eps', type=float, default=10.0)
     ap.add_argument('--acc-f64', action='store_true', help='fp64 pix_offsets accumulators instead of fp32')
     ap.add_argument('--algo', type=int, default=1, help='1 = LDS tiles (default), 0 = per-halo global atomics')
-    ap.add_argument('--mode', choices=['baryonify', 'paint'], default='baryonify',
-                    help="'paint' = PaintProfilesShell (BASELINE config 3 with --nside 2048); not the headline metric")
+    ap.add_argument('--mode', choices=['baryonify', 'paint', 'grid3d'], default='baryonify',
+                    help="'paint' = PaintProfilesShell (BASELINE config 3 with --nside 2048); 'grid3d' = BASELINE config 5 "
+                         "(particle deposit + BaryonifyGrid on an --ngrid^3 periodic grid + FFT P(k)); neither is the headline metric")
+    ap.add_argument('--ngrid', type=int, default=512, help='grid3d: cells per side (power of two)')
+    ap.add_argument('--particles', type=int, default=0, help='grid3d: particles in the snapshot (default ngrid^3 / 2)')
+    ap.add_argument('--grid-halos', type=int, default=100_000, help='grid3d: halos per GPU')
     ap.add_argument('--table', choices=['closed-form', 's19'], default='closed-form',
                     help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
                          "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
@@ -72,8 +76,149 @@ def cpu_baseline(args, cat, hmap, axes, table):
             "loop_halos_per_s": n / (t1 - t0), "regrid_pix_per_s": hmap.size / (t2 - t1)}
 
 
+def cpu_baseline_grid(args, cat, bins, zr, axes, table, eps, hmap_sample_pixels=1 << 22):
+    """Oracle (C restatement, 1 thread): the full halo loop + the regrid of a bounded pixel sample, scaled."""
+    from oracle import grid as G
+    from oracle import oracle as O
+    from baryonification_amd import synthetic as syn
+    N = args.ngrid
+    tab = O.Table(axes, table, False, eps)
+    t0 = time.time()
+    off, pairs = G.baryonify_grid_offsets((N, N, N), bins, cat, zr, tab, eps, G.grid_background(syn.COSMO), return_pairs=True)
+    t1 = time.time()
+    ns = min(hmap_sample_pixels, N ** 3)
+    rng = np.random.default_rng(1)
+    pos = off[:ns] + rng.uniform(0, N, (ns, 3))           # same arithmetic per pixel as the real regrid
+    G.regrid_pixels(np.zeros((N, N, N)), pos, np.ones(ns))
+    t2 = time.time()
+    t_full = (t1 - t0) + (t2 - t1) * N ** 3 / ns
+    return {"value": N ** 3 / t_full, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "full halo loop (%d halos, %d cutout pixels, %.2f s) + regrid of %d of %d pixels (%.2f s) scaled to the "
+                      "grid; particle deposit and FFT not included" % (cat['M'].size, pairs, t1 - t0, ns, N ** 3, t2 - t1)}
+
+
+def main_grid(args):
+    """BASELINE config 5 on one GPU (or halo-sharded over N): ParticleSnapshot.make_map -> BaryonifyGrid -> P(k)."""
+    import torch
+    import torch.distributed as dist
+    from baryonification_amd import _lib, engine, synthetic as syn
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libbfgx has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    N, nh, eps, zr, Nk = args.ngrid, args.grid_halos, 5.0, 0.0, 180
+    L = 205.0 / syn.COSMO['h']                                   # TNG300 box of the reference's notebook 10
+    npart = args.particles or N ** 3 // 2
+    bins = (np.arange(N) + 0.5) * (L / N)
+    edges = np.linspace(0, L, N + 1)
+    rng = np.random.default_rng(syn.SEED_CATALOG + rank)
+    M = syn.make_catalog(nh, seed=syn.SEED_CATALOG + rank)['M'].astype(np.float32).astype(np.float64)   # HaloNDCatalog is float32
+    pos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    cat = {'M': M, 'x': pos[:, 0].copy(), 'y': pos[:, 1].copy(), 'z': pos[:, 2].copy()}
+    z, Mt, r = np.array([0.0, 0.01]), np.geomspace(0.99e12, 1.01e15, 10), np.geomspace(1e-3, 3e2, 500)
+    table = syn.displacement_table(z, Mt, r)
+    axes = [np.log(1 + z), np.log(Mt), np.log(r)]
+    model, keep = engine.model_from_tables(axes, table, dict(syn.COSMO, w0=-1.0), eps, eps)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = engine.GridPlan(model, keep, bins, 3, zr, nh, device=local_rank, stream=stream)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in cat.items()}
+    lnM = torch.from_numpy(np.log(M.astype(np.float32)).astype(np.float64)).to(dev)
+    cat_dev = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
+    torch.manual_seed(syn.SEED_MAP)
+    part = torch.rand((3, npart), dtype=torch.float64, device=dev) * L       # synthetic snapshot, unit particle mass
+    d_edges = torch.from_numpy(edges).to(dev)
+    d_map = torch.empty(N ** 3, dtype=torch.float64, device=dev)
+    d_off = torch.empty(N ** 3 * 3, dtype=torch.float64, device=dev)
+    d_out = torch.empty(N ** 3, dtype=torch.float64, device=dev)
+    d_work = torch.empty(N * N * (N // 2 + 1) * 2, dtype=torch.float64, device=dev)
+    d_sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    d_pk, d_ks = torch.zeros(Nk, dtype=torch.float64, device=dev), torch.zeros(Nk, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(Nk, dtype=torch.int64, device=dev)
+    ev = {k: [] for k in ('deposit', 'pk')}
+    pairs = [0]
+
+    def timed(kind, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        ev[kind].append((a, b))
+
+    def step():
+        d_sums.zero_()
+        if rank == 0:
+            timed('deposit', lambda: engine.deposit_particles_device(part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), 0, npart, N,
+                                                                     d_edges.data_ptr(), d_map.data_ptr(), 3, local_rank, stream))
+        pairs[0] = plan.offsets(cat_dev, d_off.data_ptr())
+        if world > 1:
+            dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr())
+            timed('pk', lambda: engine.power_spectrum_device(d_out.data_ptr(), N, L, Nk, d_work.data_ptr(), d_pk.data_ptr(),
+                                                             d_ks.data_ptr(), d_cnt.data_ptr(), local_rank, stream))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    for k in ev:
+        ev[k].clear()
+    plan.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt = plan.timing_read()
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    if rank == 0:
+        kernels = {k: ms / n for k, (ms, n) in kt.items() if n}
+        for k, lst in ev.items():
+            kernels[k] = float(np.mean([a.elapsed_time(b) for a, b in lst]))
+        sums = d_sums.cpu().numpy()
+        pk = (d_pk / d_cnt).cpu().numpy()
+        alg = {'regrid': N ** 3 * (3 * 8 + 8 + 8 * 8 + 8), 'offsets': pairs[0] * 3 * 8 + nh * 32, 'deposit': npart * (3 * 8 + 8) + N ** 3 * 8,
+               'pk': N ** 3 * 8 + 5 * N * N * (N // 2 + 1) * 16}
+        dom = max(alg, key=lambda k: kernels.get(k) or 0.0)
+        ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
+        out = {"metric": "grid cells/sec for particle deposit + BaryonifyGrid + FFT P(k) on a %d^3 periodic grid" % N,
+               "value": N ** 3 / elapsed * args.steps, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE config 5 (single-node form): %d^3 grid of a %.1f Mpc box at z=0, %d uniform particles, %d halos "
+                                      "per GPU (SURVEY 8d mass function, float32 catalog), epsilon_max=%g, closed-form displacement table, "
+                                      "P(k) in %d linear bins" % (N, L, npart, nh, eps, Nk),
+                          "ngrid": N, "particles": npart, "halos_per_gpu": nh, "contributing_pairs_per_gpu": pairs[0],
+                          "parallelism": "halo shards x%d + RCCL reduce(pix_offsets) -> rank 0 regrid + P(k)" % world if world > 1 else "single GPU"},
+               "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
+               "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),
+               "roofline": {"kernel": {"regrid": "grid_regrid_kernel<3>", "offsets": "grid_scatter_kernel<3,OFFSETS>", "deposit": "particle_deposit_kernel<3>",
+                                       "pk": "fft_r2c_lines + 2 x fft_c2c_strided + pk_bin"}[dom],
+                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_launch": alg[dom]}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_grid(args, cat, bins, zr, axes, table, eps)
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == 'grid3d':
+        return main_grid(args)
     import torch
     import torch.distributed as dist
     from baryonification_amd import _lib, engine, synthetic as syn
