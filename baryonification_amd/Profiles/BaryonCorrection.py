@@ -16,7 +16,7 @@ from .. import tables
 
 from ..utils.cosmology import MassDef
 
-__all__ = ['BaryonificationClass', 'Baryonification2D']
+__all__ = ['BaryonificationClass', 'Baryonification2D', 'Baryonification3D']
 
 
 class BaryonificationClass(object):
@@ -135,4 +135,20 @@ class Baryonification2D(BaryonificationClass):
         else:                                            # e.g. pixel-convolved profiles: host projection, GPU integral
             Sigma = np.atleast_2d(model.projected(self.cosmo, r_int, M_use, a)) * a
             M_f = tables.enclosed_mass_from_sigma(r_int, Sigma, r)
+        return M_f[0] if scalar else M_f
+
+
+class Baryonification3D(BaryonificationClass):
+    """3-D displacement model: d(r) = M_DMB^-1(M_DMO(r)) - r from the enclosed masses of the 3-D density profiles."""
+
+    def get_masses(self, model, r, M, a):
+        """M_enc(r) = cumsum(4 pi r^3 rho dln r) on a 50 000-point grid, read out with a log-log PCHIP over the points
+        with rho > 0 (BaryonCorrection.py:470-548).  The density is sampled on the host; prefix sum and PCHIP run on
+        the GPU."""
+        r = np.asarray(r, dtype=np.float64)
+        scalar = isinstance(M, (float, int))
+        M_use = np.atleast_1d(np.asarray(M, dtype=np.float64))
+        r_int = tables.r_int_3d(r)
+        rho = np.atleast_2d(model.real(self.cosmo, r_int, M_use, a))
+        M_f = tables.enclosed_mass_3d(r_int, rho, r)
         return M_f[0] if scalar else M_f

@@ -1,0 +1,78 @@
+"""
+Particle-snapshot runner: drop-in for BaryonForge/Runners/SnapshotRunner.py (`DefaultRunnerSnapshot` :9-92,
+`BaryonifySnapshot` :95-262).  Same constructor and attributes; `process()` returns a copy of the snapshot's
+structured array with displaced, periodically re-wrapped x, y(, z).  No KD-tree is built: the HIP path bins the halos
+into a periodic cell grid and gathers per particle (csrc/bfgx_snapshot.hpp); `KDTree_kwargs` is accepted and ignored,
+`tree` is None.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..utils.cosmology import MassDef
+from ._model import build_model
+
+__all__ = ['DefaultRunnerSnapshot', 'BaryonifySnapshot']
+
+
+class DefaultRunnerSnapshot(object):
+
+    def __init__(self, HaloNDCatalog, ParticleSnapshot, epsilon_max, model, mass_def=MassDef(200, 'critical'), verbose=True,
+                 KDTree_kwargs={}):
+        self.HaloNDCatalog = HaloNDCatalog
+        self.ParticleSnapshot = ParticleSnapshot
+        self.epsilon_max = epsilon_max
+        self.cosmo = HaloNDCatalog.cosmology
+        self.model = model
+        self.mass_def = mass_def
+        self.verbose = verbose
+        self.tree = None               # the reference keeps a scipy KDTree here; the GPU path needs none
+        self.device = 0
+        self.last_stats = None
+
+    def enforce_periodicity(self, dx):
+        L = self.ParticleSnapshot.L
+        dx = np.where(dx > L / 2, dx - L, dx)
+        dx = np.where(dx < -L / 2, dx + L, dx)
+        return dx
+
+    def compute_distance(self, *args):
+        d = 0
+        for dx in args:
+            d = d + self.enforce_periodicity(dx) ** 2
+        return np.sqrt(d)
+
+
+class BaryonifySnapshot(DefaultRunnerSnapshot):
+    """Moves every particle within epsilon_max * R200c of a halo radially by the model's displacement."""
+
+    def process(self):
+        snap = self.ParticleSnapshot
+        hcat = self.HaloNDCatalog.cat
+        is2D = snap.is2D
+        cosmo = dict(self.cosmo)
+        cosmo['w0'] = -1.0                                            # SnapshotRunner.py:204-207 does not pass w0
+        model, p_keys, keep = build_model(self, 'displacement', cosmo)
+        if p_keys:
+            raise NotImplementedError("BaryonifySnapshot passes no halo properties to the model (SnapshotRunner.py:240)")
+        lnM = np.log(np.asarray(hcat['M'], dtype=np.float32)).astype(np.float64)     # float32 log, as BaryonifyGrid
+        cat, cols = _lib.make_grid_catalog_host(hcat['M'], hcat['x'], hcat['y'], None if is2D else hcat['z'], lnM)
+        x, y = _lib.f8(snap.cat['x']), _lib.f8(snap.cat['y'])
+        z = None if is2D else _lib.f8(snap.cat['z'])
+        s = _lib.bfgx_snapshot(2 if is2D else 3, 0, x.size, x.ctypes.data, y.ctypes.data, None if is2D else z.ctypes.data,
+                               float(snap.L), float(self.HaloNDCatalog.redshift))
+        ox, oy = np.empty_like(x), np.empty_like(y)
+        oz = None if is2D else np.empty_like(z)
+        opts = _lib.bfgx_opts(int(self.device), 1, 1, 0, 1, 0)
+        stats = _lib.bfgx_stats()
+        rc = _lib.load().bfgx_baryonify_snapshot(C.byref(cat), C.byref(model), C.byref(s), ox.ctypes.data, oy.ctypes.data,
+                                                 None if is2D else oz.ctypes.data, C.byref(opts), C.byref(stats))
+        _lib.check(rc)
+        self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+        new_cat = snap.cat.copy()
+        new_cat['x'], new_cat['y'] = ox, oy
+        if not is2D:
+            new_cat['z'] = oz
+        del keep, cols
+        return new_cat

@@ -1,2 +1,3 @@
 from .HealpixRunner import *
 from .Map2DRunner import *
+from .SnapshotRunner import *

@@ -61,6 +61,11 @@ class bfgx_grid_catalog(C.Structure):
                 ('lnM', C.c_void_p), ('rmat', C.c_void_p), ('extra', C.c_void_p * BFGX_MAX_EXTRA)]
 
 
+class bfgx_snapshot(C.Structure):
+    _fields_ = [('ndim', C.c_int32), ('_pad', C.c_int32), ('n', C.c_int64), ('x', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p),
+                ('L', C.c_double), ('redshift', C.c_double)]
+
+
 class bfgx_stats(C.Structure):
     _fields_ = [('n_pairs', C.c_int64), ('sum_in', C.c_double), ('sum_out', C.c_double),
                 ('ms_h2d', C.c_double), ('ms_kernels', C.c_double), ('ms_d2h', C.c_double)]
@@ -94,6 +99,7 @@ SYMBOLS = {
     'bfgx_enclosed_mass_2d': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p,
                                         C.c_int32, C.c_void_p, C.c_void_p]),
     'bfgx_enclosed_mass_from_sigma': (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_enclosed_mass_3d': (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'bfgx_displacement_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_pressure_profile': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
     'bfgx_count_pairs_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int, C.c_void_p, _P(C.c_int64)]),
@@ -105,6 +111,10 @@ SYMBOLS = {
     'bfgx_deposit_particles': (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]),
     'bfgx_power_spectrum': (C.c_int, [C.c_int, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_baryonify_snapshot': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_snapshot), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_baryonify_snapshot_device': (C.c_int, [C.c_int, C.c_void_p, _P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_snapshot), C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     'bfgx_grid_plan_create': (C.c_int, [C.c_int, C.c_void_p, _P(bfgx_grid), C.c_int64, _P(bfgx_model), _P(C.c_void_p)]),
     'bfgx_grid_plan_destroy': (None, [C.c_void_p]),
     'bfgx_grid_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_void_p, _P(C.c_int64)]),

@@ -22,6 +22,7 @@
 #include "bfgx_tables.hpp"
 #include "bfgx_grid.hpp"
 #include "bfgx_fft.hpp"
+#include "bfgx_snapshot.hpp"
 
 using namespace bfgx;
 
@@ -840,8 +841,8 @@ int bfgx_project_profile(int device, int64_t nrows, int32_t nl, const double *l,
     return BFGX_OK;
 }
 
-int bfgx_enclosed_mass_from_sigma(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *Sigma,
-                                  int32_t nr, const double *r, double *M_f)
+static int enclosed_mass_rows(int dim, int device, int64_t nrows, int64_t n_int, const double *r_int, const double *Sigma,
+                              int32_t nr, const double *r, double *M_f)
 {
     if (!r_int || !Sigma || !r || !M_f) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (nrows < 1 || n_int < 3 || nr < 1) return fail(BFGX_ERR_INVALID, "bad sizes");
@@ -852,10 +853,22 @@ int bfgx_enclosed_mass_from_sigma(int device, int64_t nrows, int64_t n_int, cons
         dM.up(nullptr, sizeof(double) * nrows * nr))
         return fail(BFGX_ERR_HIP, "device allocation/copy failed");
     hipLaunchKernelGGL(enclosed_mass_kernel, dim3((unsigned)nrows), dim3(kTabThreads), 0, 0, n_int, dri.as<double>(),
-                       dS.as<double>(), nr, dr.as<double>(), dcx.as<double>(), dcy.as<double>(), dM.as<double>());
+                       dS.as<double>(), nr, dr.as<double>(), dcx.as<double>(), dcy.as<double>(), dM.as<double>(), dim);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(M_f, dM.p, sizeof(double) * nrows * nr, hipMemcpyDeviceToHost));
     return BFGX_OK;
+}
+
+int bfgx_enclosed_mass_from_sigma(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *Sigma,
+                                  int32_t nr, const double *r, double *M_f)
+{
+    return enclosed_mass_rows(2, device, nrows, n_int, r_int, Sigma, nr, r, M_f);
+}
+
+int bfgx_enclosed_mass_3d(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *rho,
+                          int32_t nr, const double *r, double *M_f)
+{
+    return enclosed_mass_rows(3, device, nrows, n_int, r_int, rho, nr, r, M_f);
 }
 
 int bfgx_enclosed_mass_2d(int device, int64_t nrows, int32_t nl, const double *l, const double *rho, double a,
@@ -875,7 +888,7 @@ int bfgx_enclosed_mass_2d(int device, int64_t nrows, int32_t nl, const double *l
                        nl, dl.as<double>(), drho.as<double>(), n_int, dri.as<double>(), a, dS.as<double>());
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(enclosed_mass_kernel, dim3((unsigned)nrows), dim3(kTabThreads), 0, 0, n_int, dri.as<double>(),
-                       dS.as<double>(), nr, dr.as<double>(), dcx.as<double>(), dcy.as<double>(), dM.as<double>());
+                       dS.as<double>(), nr, dr.as<double>(), dcx.as<double>(), dcy.as<double>(), dM.as<double>(), 2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(M_f, dM.p, sizeof(double) * nrows * nr, hipMemcpyDeviceToHost));
     return BFGX_OK;
@@ -925,3 +938,6 @@ int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const d
 
 // ------------------------------------------------------------------------------ regular-grid path (8f-1)
 #include "bfgx_grid_api.inc"
+
+// ------------------------------------------------------------------------------ particle snapshots (8f-2)
+#include "bfgx_snapshot_api.inc"

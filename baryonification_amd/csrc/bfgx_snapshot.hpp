@@ -1,0 +1,237 @@
+// bfgx_snapshot.hpp -- particle-snapshot baryonification for gfx950 (BaryonifySnapshot.process, SnapshotRunner.py:173-262).
+//
+// The reference loops over halos, asks a periodic KD-tree for the particles within R_q and adds a radial offset to
+// each.  Here the roles are swapped so that the scatter becomes a gather: halos are binned into a uniform periodic
+// cell grid (a halo is listed in every cell its query ball's bounding cube touches: count -> scan -> fill), then one
+// thread per particle walks the halo list of ITS cell, keeps the halos whose ball contains it, sums their offsets in
+// registers and writes the displaced, re-wrapped position once.  No atomics on the particle side, no neighbour search
+// structure over the 10^8 particles, every particle read and written exactly once.
+//
+//   snap_halo_prep_kernel    per-halo scalars (:217-222) + cell range + per-cell counts
+//   scan_* kernels           exclusive scan of the per-cell counts
+//   snap_halo_fill_kernel    halo index into each touched cell's list
+//   snap_displace_kernel     per particle: min-image separation (:67-92), displacement read-out, offset (:225-252),
+//                            periodic re-wrap (:254-262)
+#pragma once
+#include "bfgx_kernels.hpp"
+#include "bfgx_tables.hpp"
+
+namespace bfgx {
+
+struct SnapGeom {
+    int32_t ndim, nc;                 // dimensions; cells per side
+    double L, inv_cell;               // box size; nc / L
+    double a;                         // 1 / (1 + redshift)
+    int64_t ncell;                    // nc^ndim
+};
+
+struct SnapHaloRec {
+    double pos[3];
+    double Rq2;                       // squared query radius (scipy's ball query compares squared distances)
+    double rcut;                      // eps_model * R_model (comoving)
+    double lnoff;                     // added to ln d: -ln R_model for Rdelta-sampled tables
+    double w[kNC];
+    int32_t rowoff[kNC];
+    int32_t clo[3], cn[3];            // first cell and number of cells per axis (periodic)
+    int32_t oob, valid;
+};
+
+__device__ inline int snap_cell(double v, const SnapGeom &g)
+{
+    const int c = (int)floor(v * g.inv_cell);
+    return max(0, min(c, g.nc - 1));
+}
+
+__device__ inline int64_t snap_cell_index(const SnapGeom &g, int cx, int cy, int cz)
+{
+    return (g.ndim == 3) ? ((int64_t)cx * g.nc + cy) * g.nc + cz : (int64_t)cx * g.nc + cy;
+}
+
+template <typename F>
+__device__ inline void snap_for_each_cell(const SnapGeom &g, const SnapHaloRec &r, F f)
+{
+    const int nz = (g.ndim == 3) ? r.cn[2] : 1;
+    for (int ix = 0; ix < r.cn[0]; ++ix) {
+        int cx = r.clo[0] + ix; cx -= (cx >= g.nc) ? g.nc : 0;
+        for (int iy = 0; iy < r.cn[1]; ++iy) {
+            int cy = r.clo[1] + iy; cy -= (cy >= g.nc) ? g.nc : 0;
+            for (int iz = 0; iz < nz; ++iz) {
+                int cz = (g.ndim == 3) ? r.clo[2] + iz : 0; cz -= (cz >= g.nc) ? g.nc : 0;
+                f(snap_cell_index(g, cx, cy, cz));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+snap_halo_prep_kernel(DevModel m, SnapGeom g, int64_t nh, const double *__restrict__ M, const double *__restrict__ hx,
+                      const double *__restrict__ hy, const double *__restrict__ hz, const double *__restrict__ lnM,
+                      SnapHaloRec *__restrict__ recs, int32_t *__restrict__ cell_count, int32_t *__restrict__ flags)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nh) return;
+    SnapHaloRec r;
+    const double M_j = M[j];
+    r.pos[0] = hx[j]; r.pos[1] = hy[j]; r.pos[2] = (g.ndim == 3) ? hz[j] : 0.0;
+    r.valid = (M_j > 0.0) && isfinite(M_j) && isfinite(r.pos[0]) && isfinite(r.pos[1]) && isfinite(r.pos[2]);
+    r.Rq2 = 0.0; r.rcut = 0.0; r.lnoff = 0.0; r.oob = 1;
+    for (int q = 0; q < kNC; ++q) { r.w[q] = 0.0; r.rowoff[q] = 0; }
+    for (int q = 0; q < 3; ++q) { r.clo[q] = 0; r.cn[q] = 0; }
+    if (r.valid) {
+        const double a = g.a;
+        const double R_phys = dev_radius(m.bg_runner, m.md_runner, M_j, a);             // :220 physical Mpc
+        double R_q = m.eps_runner * R_phys / a;                                         // :221
+        R_q = fmin(fmax(R_q, 0.0), g.L / 2);                                            // :222
+        r.Rq2 = R_q * R_q;
+        const double Rmod = (m.same_model ? R_phys : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
+        r.rcut = m.tab.eps_model * Rmod;
+        r.lnoff = m.tab.rdelta ? -log(Rmod) : 0.0;
+        const double x1 = lnM ? lnM[j] : (double)logf((float)M_j);                      // float32 log, see bfgx_grid.hpp
+        double wv[kNC];
+        int32_t ro[kNC];
+        r.oob = table_corners<kNC>(m.tab, log(1.0 / a), x1, 0.0, 0.0, wv, ro) ? 1 : 0;
+        for (int q = 0; q < kNC; ++q) { r.w[q] = wv[q]; r.rowoff[q] = ro[q]; }
+        if (!(R_q > 0.0) || !isfinite(R_q)) r.valid = 0;
+        for (int ax = 0; ax < g.ndim && r.valid; ++ax) {
+            // scipy's periodic ball query wraps the query point into the box (BoxDist1D::wrap_position); the separations
+            // below keep the halo position as given, as the reference does (:226-228)
+            double p = r.pos[ax];
+            p -= floor(p / g.L) * g.L;
+            // cells of the unwrapped interval [p - R_q, p + R_q]; one extra cell on a side that crosses the box face
+            // (floor((x +- L) * inv) and floor(x * inv) +- nc may differ by one after rounding)
+            const double lo_v = p - R_q, hi_v = p + R_q;
+            int cl = (int)floor(lo_v * g.inv_cell), ch = (int)floor(hi_v * g.inv_cell);
+            if (lo_v <= 0.0) cl -= 1;
+            if (hi_v >= g.L) ch += 1;
+            int n = ch - cl + 1;
+            if (n >= g.nc) { cl = 0; n = g.nc; }
+            cl %= g.nc; if (cl < 0) cl += g.nc;
+            r.clo[ax] = cl; r.cn[ax] = n;
+        }
+        // an out-of-table halo displaces nothing (its read-out is NaN -> offset 0, :242): keep it out of the lists
+        if (r.oob) r.valid = 0;
+    }
+    recs[j] = r;
+    if (r.valid) snap_for_each_cell(g, r, [&](int64_t c) { atomicAdd(cell_count + c, 1); });
+}
+
+__global__ void __launch_bounds__(256)
+snap_halo_fill_kernel(SnapGeom g, int64_t nh, const SnapHaloRec *__restrict__ recs, const int32_t *__restrict__ cell_start,
+                      int32_t *__restrict__ cell_cursor, int32_t *__restrict__ entries)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nh) return;
+    const SnapHaloRec &r = recs[j];
+    if (!r.valid) return;
+    snap_for_each_cell(g, r, [&](int64_t c) { entries[cell_start[c] + atomicAdd(cell_cursor + c, 1)] = (int32_t)j; });
+}
+
+// ---- exclusive scan of int32 counts (n up to 2^31): 4096 elements per block, block sums scanned by one block
+constexpr int kScanPerBlock = 4 * kTabThreads;
+
+__global__ void __launch_bounds__(kTabThreads)
+scan_blocks_kernel(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out, int32_t *__restrict__ block_sums)
+{
+    __shared__ int sh[kTabThreads];
+    const int64_t base = (int64_t)blockIdx.x * kScanPerBlock + 4 * (int64_t)threadIdx.x;
+    int v[4], s = 0;
+    for (int q = 0; q < 4; ++q) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    int tot;
+    int pre = block_excl_scan_int(s, sh, tot);
+    for (int q = 0; q < 4; ++q) { if (base + q < n) out[base + q] = pre; pre += v[q]; }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// one block: exclusive scan of up to kScanPerBlock block sums, in place; total -> *total_out
+__global__ void __launch_bounds__(kTabThreads)
+scan_sums_kernel(int nb, int32_t *__restrict__ block_sums, int64_t *__restrict__ total_out)
+{
+    __shared__ int sh[kTabThreads];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nb; c0 += kScanPerBlock) {
+        const int base = c0 + 4 * threadIdx.x;
+        int v[4], s = 0;
+        for (int q = 0; q < 4; ++q) { v[q] = (base + q < nb) ? block_sums[base + q] : 0; s += v[q]; }
+        int tot;
+        int pre = block_excl_scan_int(s, sh, tot) + (int)carry;
+        for (int q = 0; q < 4; ++q) { if (base + q < nb) block_sums[base + q] = pre; pre += v[q]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(256)
+scan_add_kernel(int64_t n, int32_t *__restrict__ out, const int32_t *__restrict__ block_sums)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += block_sums[i / kScanPerBlock];
+}
+
+// min-image of a coordinate difference (SnapshotRunner.py:87-91)
+__device__ inline double min_image(double dx, double L)
+{
+    if (dx > L / 2) dx -= L;
+    if (dx < -L / 2) dx += L;
+    return dx;
+}
+
+// flags: bit 1 = a particle lies outside [0, L] (scipy's periodic KDTree refuses such data)
+template <int DIM>
+__global__ void __launch_bounds__(256)
+snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restrict__ px, const double *__restrict__ py,
+                     const double *__restrict__ pz, const SnapHaloRec *__restrict__ recs, const int32_t *__restrict__ cell_start,
+                     const int32_t *__restrict__ entries, double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz,
+                     int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long npairs = 0;
+    if (p < np) {
+        const double x = px[p], y = py[p], z = (DIM == 3) ? pz[p] : 0.0;
+        double tx = 0.0, ty = 0.0, tz = 0.0;
+        const bool inside = (x >= 0.0 && x <= g.L) && (y >= 0.0 && y <= g.L) && (DIM == 2 || (z >= 0.0 && z <= g.L));
+        if (!inside) atomicOr(flags, 2);
+        else {
+            const int64_t c = snap_cell_index(g, snap_cell(x, g), snap_cell(y, g), (DIM == 3) ? snap_cell(z, g) : 0);
+            const int e0 = cell_start[c], e1 = cell_start[c + 1];
+            for (int e = e0; e < e1; ++e) {
+                const SnapHaloRec &r = recs[entries[e]];
+                const double dx = min_image(x - r.pos[0], g.L), dy = min_image(y - r.pos[1], g.L);
+                const double dz = (DIM == 3) ? min_image(z - r.pos[2], g.L) : 0.0;
+                double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
+                if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
+                if (!(d2 <= r.Rq2)) continue;                                            // :225 / :237 query_ball_point
+                const double d = sqrt(d2);                                               // :228 compute_distance
+                double disp = radial_readout<kNC>(pt, r.rowoff, r.w, log(d) + r.lnoff);  // BaryonCorrection.py:356-379
+                if (!(d < r.rcut)) disp = 0.0;                                           // :381-382
+                double off = disp * g.a;                                                 // :240 displacement * a
+                if (!isfinite(off)) off = 0.0;                                           // :241
+                if (off == 0.0 && d > 0.0) continue;
+                ++npairs;
+                tx += off * (dx / d); ty += off * (dy / d);                              // :242-244 (0 * NaN stays NaN at d = 0)
+                if (DIM == 3) tz += off * (dz / d);
+            }
+        }
+        double nx = x + tx, ny = y + ty, nz = z + tz;                                    // :254-257
+        if (nx > g.L) nx -= g.L;                                                         // :259-262
+        if (nx < 0.0) nx += g.L;
+        if (ny > g.L) ny -= g.L;
+        if (ny < 0.0) ny += g.L;
+        ox[p] = nx; oy[p] = ny;
+        if (DIM == 3) {
+            if (nz > g.L) nz -= g.L;
+            if (nz < 0.0) nz += g.L;
+            oz[p] = nz;
+        }
+    }
+    if (pair_total) {
+#pragma unroll
+        for (int s = kWave >> 1; s > 0; s >>= 1) npairs += __shfl_down(npairs, s, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && npairs) atomicAdd(pair_total, npairs);
+    }
+}
+
+}  // namespace bfgx

@@ -134,11 +134,19 @@ project_kernel(int nl, const double *__restrict__ l, const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------ K4a
-// one block (kTabThreads) per row.  Sigma[row][n] already carries the factor a.  Scratch cx/cy: [nrows][n].
+// one block (kTabThreads) per row.  dim 2: Sigma[row][n] (already carrying the factor a), terms 2 pi r^2 Sigma dlnr
+// (Baryonification2D.get_masses); dim 3: the 3-D density, terms 4 pi r^3 rho dlnr (Baryonification3D.get_masses,
+// BaryonCorrection.py:519-546).  Negative samples count as 0, points with a zero sample or a non-finite running sum are
+// dropped before the log-log PCHIP.  Scratch cx/cy: [nrows][n].
+__device__ inline double shell_term(int dim, double r, double v, double dlnr)
+{
+    return dim == 3 ? 4.0 * kPi * (r * r * r) * v * dlnr : 2.0 * kPi * r * r * v * dlnr;
+}
+
 __global__ void __launch_bounds__(kTabThreads)
 enclosed_mass_kernel(int64_t n, const double *__restrict__ r_int, const double *__restrict__ Sigma,
                      int nr, const double *__restrict__ r, double *__restrict__ cx, double *__restrict__ cy,
-                     double *__restrict__ M_f /*[nrows][nr]*/)
+                     double *__restrict__ M_f /*[nrows][nr]*/, int dim)
 {
     __shared__ double shd[kTabThreads];
     __shared__ int shi[kTabThreads];
@@ -152,14 +160,14 @@ enclosed_mass_kernel(int64_t n, const double *__restrict__ r_int, const double *
     int c = 0;
     for (int64_t i = lo; i < hi; ++i) {
         const double sg = S[i] < 0.0 ? 0.0 : S[i];
-        s += 2.0 * kPi * r_int[i] * r_int[i] * sg * dlnr;
+        s += shell_term(dim, r_int[i], sg, dlnr);
     }
     double tot;
     const double base = block_excl_scan_sum(s, shd, tot);
     double run = base;
     for (int64_t i = lo; i < hi; ++i) {                       // count usable points
         const double sg = S[i] < 0.0 ? 0.0 : S[i];
-        run += 2.0 * kPi * r_int[i] * r_int[i] * sg * dlnr;
+        run += shell_term(dim, r_int[i], sg, dlnr);
         c += (sg > 0.0 && isfinite(run)) ? 1 : 0;
     }
     int ctot;
@@ -167,7 +175,7 @@ enclosed_mass_kernel(int64_t n, const double *__restrict__ r_int, const double *
     run = base;
     for (int64_t i = lo; i < hi; ++i) {                       // compact (ln r, ln M_enc)
         const double sg = S[i] < 0.0 ? 0.0 : S[i];
-        run += 2.0 * kPi * r_int[i] * r_int[i] * sg * dlnr;
+        run += shell_term(dim, r_int[i], sg, dlnr);
         if (sg > 0.0 && isfinite(run)) { ox[cbase] = log(r_int[i]); oy[cbase] = log(run); ++cbase; }
     }
     __threadfence_block();

@@ -170,3 +170,16 @@ def power_spectrum(Map, Lbox, Nk=180, device=0):
     _lib.check(_lib.load().bfgx_power_spectrum(int(device), Map.shape[0], Map.ctypes.data, float(Lbox), int(Nk),
                                               pk.ctypes.data, kc.ctypes.data, cnt.ctypes.data))
     return kc, pk, cnt
+
+
+def baryonify_snapshot_device(model, halos_dev, part_ptrs, n_part, L, redshift, out_ptrs, device=0, stream=0):
+    """BaryonifySnapshot on device-resident columns: part_ptrs / out_ptrs = (x, y[, z]) device pointers.
+    Returns the number of displaced (halo, particle) pairs."""
+    ndim = len(part_ptrs)
+    s = _lib.bfgx_snapshot(ndim, 0, int(n_part), int(part_ptrs[0]), int(part_ptrs[1]), int(part_ptrs[2]) if ndim == 3 else None,
+                           float(L), float(redshift))
+    n = C.c_int64(0)
+    _lib.check(_lib.load().bfgx_baryonify_snapshot_device(int(device), C.c_void_p(int(stream) or None), C.byref(halos_dev), C.byref(model),
+                                                         C.byref(s), C.c_void_p(int(out_ptrs[0])), C.c_void_p(int(out_ptrs[1])),
+                                                         C.c_void_p(int(out_ptrs[2])) if ndim == 3 else None, C.byref(n)))
+    return int(n.value)

@@ -31,6 +31,13 @@ def r_int_2d(r):
     return np.geomspace(r_min / 1.5, r_max * 1.5, N_INT_2D)
 
 
+def r_int_3d(r):
+    """radial grid of Baryonification3D.get_masses (BaryonCorrection.py:525-527)"""
+    r_min = np.min([np.min(r), 1e-6])
+    r_max = np.max([np.max(r), 1000])
+    return np.geomspace(r_min / 1.2, r_max * 1.2, N_INT_2D)
+
+
 def _rows(a):
     a = _lib.f8(np.atleast_2d(a))
     return a, a.shape[0]
@@ -62,6 +69,16 @@ def enclosed_mass_from_sigma(r_int, Sigma, r, device=0):
     out = np.empty((nrows, r.size))
     _lib.check(_lib.load().bfgx_enclosed_mass_from_sigma(device, nrows, r_int.size, r_int.ctypes.data, Sigma.ctypes.data,
                                                          r.size, r.ctypes.data, out.ctypes.data))
+    return out
+
+
+def enclosed_mass_3d(r_int, rho, r, device=0):
+    """3-D enclosed mass from the density sampled on r_int (Baryonification3D.get_masses, BaryonCorrection.py:528-546)"""
+    r_int, r = _lib.f8(r_int), _lib.f8(r)
+    rho, nrows = _rows(rho)
+    out = np.empty((nrows, r.size))
+    _lib.check(_lib.load().bfgx_enclosed_mass_3d(device, nrows, r_int.size, r_int.ctypes.data, rho.ctypes.data,
+                                                 r.size, r.ctypes.data, out.ctypes.data))
     return out
 
 

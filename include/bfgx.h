@@ -170,6 +170,9 @@ int  bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int fall
  *   bfgx_enclosed_mass_2d         Baryonification2D.get_masses, Profiles/BaryonCorrection.py:639-661
  *                                 (projection onto r_int times a, Sigma<0 -> 0, prefix sum, log-log PCHIP at r)
  *   bfgx_enclosed_mass_from_sigma the same from a projected profile the caller computed some other way
+ *   bfgx_enclosed_mass_3d         Baryonification3D.get_masses, Profiles/BaryonCorrection.py:519-546: rho sampled on
+ *                                 r_int = geomspace(min(r,1e-6)/1.2, max(r,1000)*1.2, 50 000), rho<0 -> 0,
+ *                                 cumsum(4 pi r^3 rho dlnr), log-log PCHIP at r over the points with rho > 0
  *   bfgx_displacement_rows        setup_interpolator's per-mass loop body, BaryonCorrection.py:226-301;
  *                                 status[row]: 0 ok, 1 mass profile nearly constant (iterate > 30),
  *                                 2 fewer than 5 usable points -- both give d = 0 and warrant the reference's warning
@@ -180,6 +183,8 @@ int bfgx_enclosed_mass_2d(int device, int64_t nrows, int32_t nl, const double *l
                           int64_t n_int, const double *r_int, int32_t nr, const double *r, double *M_f);
 int bfgx_enclosed_mass_from_sigma(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *Sigma,
                                   int32_t nr, const double *r, double *M_f);
+int bfgx_enclosed_mass_3d(int device, int64_t nrows, int64_t n_int, const double *r_int, const double *rho,
+                          int32_t nr, const double *r, double *M_f);
 int bfgx_displacement_rows(int device, int64_t nrows, int32_t nr, const double *r, const double *M_dmo,
                            const double *M_dmb, double *d_out, int32_t *status);
 int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const double *rho_tot, const double *rho_gas,
@@ -249,6 +254,27 @@ int  bfgx_deposit_particles_device(int device, void *hip_stream, int32_t ndim, i
 int  bfgx_power_spectrum_device(int device, void *hip_stream, int32_t n_grid, const double *map_dev, double L, int32_t nk,
                                 double *work_dev /* complex [n_grid][n_grid][n_grid/2+1] */, double *pk_sum_dev,
                                 double *k_sum_dev, unsigned long long *counts_dev);
+
+/* ---- particle-snapshot path ----------------------------------------------------------
+ * Replaces BaryonifySnapshot.process, BaryonForge/Runners/SnapshotRunner.py:173-262: every particle within
+ * R_q = clip(epsilon_max R200c / a, 0, L/2) of a halo (periodic box) moves radially by displacement(d, M, a) * a;
+ * positions are re-wrapped into [0, L] once.  Halos are given as bfgx_grid_catalog (float32-valued columns, lnM as
+ * for the grid runners; rmat / extra unused).  cosmo_runner.w0 = -1 (SnapshotRunner.py:204-207 does not pass w0). */
+typedef struct bfgx_snapshot {
+    int32_t ndim;                         /* 2 or 3 */
+    int32_t _pad;
+    int64_t n;                            /* particles */
+    const double *x, *y, *z;              /* coordinates in [0, L]; z may be NULL for 2D */
+    double L;                             /* box size, comoving Mpc */
+    double redshift;
+} bfgx_snapshot;
+
+int bfgx_baryonify_snapshot(const bfgx_grid_catalog *halos_host, const bfgx_model *model, const bfgx_snapshot *snap_host,
+                            double *x_out_host, double *y_out_host, double *z_out_host, const bfgx_opts *opts, bfgx_stats *stats);
+/* the same with halo columns, particle columns and outputs resident in HBM (out may not alias in); blocking */
+int bfgx_baryonify_snapshot_device(int device, void *hip_stream, const bfgx_grid_catalog *halos_dev, const bfgx_model *model,
+                                   const bfgx_snapshot *snap_dev, double *x_out_dev, double *y_out_dev, double *z_out_dev,
+                                   int64_t *n_pairs_host);
 
 #ifdef __cplusplus
 }

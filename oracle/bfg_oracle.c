@@ -776,3 +776,52 @@ void bfgo_histogramdd(int ndim, i64 n, const double *const *coords, const double
         out[flat] += weights ? weights[p] : 1.0;
     }
 }
+
+/* ====================================================================== particle-snapshot path
+ * BaryonifySnapshot.process, SnapshotRunner.py:173-262.  The KD-tree ball query (scipy cKDTree, periodic, p = 2:
+ * squared min-image separation <= R_q^2) is restated as a brute-force halo x particle loop.
+ *   R[j] = mass_def.get_radius(cosmo, M_j, a) physical Mpc; Rmod[j] model-side comoving radius; lnM as in the grid loop.
+ *   out: tot_offsets [npart][ndim], accumulated into.  Returns the number of (halo, particle) pairs inside the balls.
+ */
+static double min_image_d(double dx, double L)
+{
+    if (dx > L / 2) dx = dx - L;          /* compute_distance / enforce_periodicity :87-91 */
+    if (dx < -L / 2) dx = dx + L;
+    return dx;
+}
+
+i64 bfgo_snapshot_offsets(int ndim, i64 npart, const double *px, const double *py, const double *pz, double L,
+                          i64 nhalo, const double *hx, const double *hy, const double *hz, const double *lnM,
+                          double a, const double *R, const double *Rmod,
+                          int tdim, const int *tn, const double *const *taxes, const double *tvalues,
+                          int rdelta_sampling, double eps_runner, double eps_model, double *tot_offsets)
+{
+    rgi_t t = rgi_make(tdim, tn, taxes, tvalues);
+    i64 total = 0;
+    for (i64 j = 0; j < nhalo; ++j) {
+        double R_q = eps_runner * R[j] / a;                           /* :221 */
+        if (R_q < 0) R_q = 0;                                         /* :222 np.clip(R_q, 0, L/2) */
+        if (R_q > L / 2) R_q = L / 2;
+        double tx[BFGO_MAXDIM];
+        tx[0] = log(1.0 / a);
+        tx[1] = lnM[j];
+        double Rc = Rmod[j];
+        for (i64 p = 0; p < npart; ++p) {
+            double dx = min_image_d(px[p] - hx[j], L), dy = min_image_d(py[p] - hy[j], L);
+            double dz = ndim == 3 ? min_image_d(pz[p] - hz[j], L) : 0.0;
+            double d2 = ndim == 3 ? dx * dx + dy * dy + dz * dz : dx * dx + dy * dy;
+            if (!(d2 <= R_q * R_q)) continue;                         /* :225 / :237 query_ball_point */
+            ++total;
+            double d = sqrt(d2);                                      /* :228 / :241 */
+            tx[2] = rdelta_sampling ? (log(d) - log(Rc)) : log(d);
+            double disp = rgi_eval(&t, tx);
+            if (!(d < eps_model * Rc)) disp = 0.0;                    /* BaryonCorrection.py:381-382 */
+            double off = disp * a;                                    /* :232 / :247 */
+            if (!isfinite(off)) off = 0.0;                            /* :233 / :248 */
+            tot_offsets[ndim * p + 0] += off * (dx / d);
+            tot_offsets[ndim * p + 1] += off * (dy / d);
+            if (ndim == 3) tot_offsets[ndim * p + 2] += off * (dz / d);
+        }
+    }
+    return total;
+}

@@ -159,3 +159,34 @@ def power_spectrum(Map, Lbox, Nk=180):
         P = (np.conjugate(F) * F).real.flatten()
         Pk = np.bincount(kinds[kmsk], minlength=Nk, weights=P[kmsk]) / k_c
     return k_cen, Pk, k_c
+
+
+def baryonify_snapshot(coords, L, cat, redshift, table, eps_runner, bg_runner, bg_model=None, return_pairs=False):
+    """BaryonifySnapshot.process() (SnapshotRunner.py:199-262): coords = [x, y(, z)] particle columns in [0, L];
+    returns the displaced, re-wrapped columns.  Brute force over halo x particle (C: bfgo_snapshot_offsets)."""
+    L_ = lib()
+    if not hasattr(L_, '_snap_ready'):
+        i64, dbl, vp, ci = C.c_int64, C.c_double, C.c_void_p, C.c_int
+        L_.bfgo_snapshot_offsets.argtypes = [ci, i64, vp, vp, vp, dbl, i64, vp, vp, vp, vp, dbl, vp, vp, ci, vp, vp, vp, ci, dbl, dbl, vp]
+        L_.bfgo_snapshot_offsets.restype = i64
+        L_._snap_ready = True
+    ndim = len(coords)
+    cs = [_f8(c) for c in coords]
+    a = 1.0 / (1.0 + redshift)
+    M = _f8(cat['M'])
+    lnM = np.log(M.astype(np.float32)).astype(np.float64)       # float32 log of the float32 catalog mass (see _loop)
+    hx, hy, hz = _f8(cat['x']), _f8(cat['y']), _f8(cat['z'])
+    R = _f8(bg_runner.get_radius(M, a))
+    Rmod = _f8((bg_model or bg_runner).get_radius(M, a) / a)
+    tdim, tn, tax = table._cargs()
+    off = np.zeros((cs[0].size, ndim))
+    pairs = L_.bfgo_snapshot_offsets(ndim, cs[0].size, _ptr(cs[0]), _ptr(cs[1]), _ptr(cs[2]) if ndim == 3 else None, float(L), M.size,
+                                     _ptr(hx), _ptr(hy), _ptr(hz), _ptr(lnM), a, _ptr(R), _ptr(Rmod), tdim, _ptr(tn), tax,
+                                     _ptr(table.values), int(table.rdelta_sampling), float(eps_runner), table.eps_model, _ptr(off))
+    out = []
+    for c in range(ndim):                                       # :254-262
+        v = cs[c] + off[:, c]
+        v = np.where(v > L, v - L, v)
+        v = np.where(v < 0, v + L, v)
+        out.append(v)
+    return (out, pairs) if return_pairs else out

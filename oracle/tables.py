@@ -65,6 +65,27 @@ def enclosed_mass_from_sigma(r_int, Sigma, r):
     return M_f
 
 
+def r_int_3d(r):
+    """BaryonCorrection.py:525-527"""
+    r_min = np.min([np.min(r), 1e-6])
+    r_max = np.max([np.max(r), 1000])
+    return np.geomspace(r_min / 1.2, r_max * 1.2, N_INT_2D)
+
+
+def enclosed_mass_3d(r_int, rho, r):
+    """Baryonification3D.get_masses, BaryonCorrection.py:528-546, from the density sampled on r_int"""
+    dlnr = np.log(r_int[1] / r_int[0])
+    rho = np.where(rho < 0, 0, rho)
+    M_enc = np.cumsum(4 * np.pi * r_int ** 3 * rho * dlnr, axis=-1)
+    lnr = np.log(r)
+    M_f = np.zeros([M_enc.shape[0], r.size])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for i in range(M_enc.shape[0]):
+            Mask = (rho[i] > 0) & (np.isfinite(M_enc[i]))
+            M_f[i] = np.exp(interpolate.PchipInterpolator(np.log(r_int)[Mask], np.log(M_enc[i])[Mask], extrapolate=False)(lnr))
+    return M_f
+
+
 def enclosed_mass_2d(l, rho, a, r):
     """get_masses for a profile whose `projected` is `_projected_realspace` (l = los_grid(r_int_2d(r), ...))"""
     r_int = r_int_2d(r)

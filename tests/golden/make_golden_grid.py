@@ -35,6 +35,8 @@ from baryonification_amd import synthetic as syn  # noqa: E402
 from oracle import grid as G  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 import make_golden as MG  # noqa: E402  (reference-model builders)
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers as TH  # noqa: E402  (tests/helpers.py: the seeded particle generator shared with the tests)
 
 COSMO = dict(syn.COSMO, w0=-0.9)        # w0 != -1 on purpose: the grid runners must ignore it (Map2DRunner.py:456-459)
 
@@ -190,5 +192,57 @@ def main():
     run_make_map('grid3d_make_map', 3, 5000, 50.0, 16, 32)
 
 
+
+
+def run_snapshot(name, ndim, L, npart, nh, seed, redshift, eps_runner, eps_model, rdelta=False, cosmo_model=None):
+    """BaryonifySnapshot.process (SnapshotRunner.py:199-262) with scipy's own periodic KDTree"""
+    rng = np.random.default_rng(seed)
+    cosmo_model = cosmo_model or COSMO
+    M = 10 ** rng.uniform(12.8, 15.1, nh)
+    hpos = rng.uniform(0, L, (nh, 3))
+    hpos[:3] = [[0.02 * L, 0.98 * L, 0.5 * L], [0.999 * L, 0.001 * L, 0.0], [0.5 * L, 0.5 * L, 0.999 * L]]    # balls across the faces
+    M[:3] = 10 ** np.array([15.1, 14.8, 14.5])
+    part = TH.snapshot_particles(seed, npart, L, hpos[0])       # regenerated from the seed by the tests (not stored)
+    HCat = bfg.utils.HaloNDCatalog(x=hpos[:, 0], y=hpos[:, 1], z=hpos[:, 2] if ndim == 3 else None, M=M, redshift=redshift, cosmo=COSMO)
+    used = {k: np.array(HCat.cat[k], dtype=np.float64) for k in ('M', 'x', 'y', 'z')}
+    Snap = bfg.utils.ParticleSnapshot(x=part[:, 0], y=part[:, 1], z=part[:, 2] if ndim == 3 else None, M=np.ones(npart), L=L,
+                                      redshift=redshift, cosmo=COSMO)
+    z, Mt, r_axis = table_for(redshift, 12.8, 15.1, NR=150, R_min=1e-3, R_max=1e2)
+    if rdelta:
+        r_axis = np.geomspace(1e-3, 30, 100)
+        Rc = syn._Rc(z, Mt, cosmo_model)[:, :, None]
+        x = r_axis[None, None, :]
+        table = -0.05 * Rc * x * np.exp(-x) / (1 + x * x)
+    else:
+        table = syn.displacement_table(z, Mt, r_axis)
+    model = MG.ref_displacement_model(z, Mt, r_axis, table, rdelta, eps_model, cosmo_model)
+    t0 = time.time()
+    new_cat = bfg.Runners.BaryonifySnapshot(HCat, Snap, eps_runner, model, verbose=False).process()
+    out = np.stack([new_cat[k] for k in ('x', 'y', 'z')[:ndim]], axis=1)
+    otab = O.Table([np.log(1 + z), np.log(Mt), np.log(r_axis)], table, rdelta, eps_model)
+    oo, pairs = G.baryonify_snapshot([part[:, d] for d in range(ndim)], L, used, redshift, otab, eps_runner, G.grid_background(COSMO),
+                                     O.Background.from_dict(cosmo_model), return_pairs=True)
+    oo = np.stack(oo, axis=1)
+    moved = np.abs(out - part[:, :ndim]).max(axis=1) > 0
+    print(f"{name:20s} snapshot  ndim={ndim} npart={npart} nh={nh} ref+oracle {time.time() - t0:5.1f}s  max|oracle-ref| = "
+          f"{np.nanmax(np.abs(oo - out)):.3e}  nan equal: {np.array_equal(np.isnan(oo), np.isnan(out))}  moved = {int(moved.sum())}  pairs = {pairs}")
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), kind='snapshot', ndim=ndim, L=L, redshift=redshift, eps_runner=eps_runner,
+                        eps_model=eps_model, rdelta=rdelta, part_seed=seed, npart=npart, halo0=hpos[0], moved_idx=np.nonzero(moved)[0],
+                        moved_pos=out[moved], cat_M=used['M'], cat_x=used['x'], cat_y=used['y'],
+                        cat_z=used['z'], tab_z=z, tab_M=Mt, tab_r=r_axis, tab_values=table,
+                        cosmo_runner=np.array([COSMO[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+                        cosmo_model=np.array([cosmo_model[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+                        )
+
+
+def main_snapshot():
+    run_snapshot('snap3d_baryonify', 3, 120.0, 20000, 60, 41, 0.0, 5.0, 20.0)
+    run_snapshot('snap2d_baryonify', 2, 200.0, 20000, 80, 42, 0.1, 6.0, 4.0)
+    run_snapshot('snap3d_rdelta', 3, 120.0, 12000, 40, 43, 0.0, 5.0, 20.0, rdelta=True, cosmo_model=MG.COSMO_B)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'snapshot':
+        main_snapshot()
+    else:
+        main()

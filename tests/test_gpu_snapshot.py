@@ -1,0 +1,106 @@
+"""Parity of the particle-snapshot HIP path (csrc/bfgx_snapshot.hpp) through the drop-in BaryonifySnapshot runner
+(-> ctypes -> C ABI) against the reference's outputs (tests/golden/snap*.npz) and the brute-force CPU oracle.
+All fp64; differences are libm ulps and the order in which a particle's halos are summed  ->  |d| <= 1e-10 * max|offset|
+(and 1e-13 of the box size on the positions themselves)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _positions(new_cat, ndim):
+    return np.stack([new_cat[k] for k in ('x', 'y', 'z')[:ndim]], axis=1)
+
+
+@pytest.mark.parametrize('name', H.SNAPSHOT_CASES)
+def test_snapshot_runner_vs_reference_golden(gpu, name):
+    g = H.load_snapshot_golden(name)
+    runner = H.snapshot_product_runner(g)
+    new_cat = runner.process()
+    assert new_cat.dtype == runner.ParticleSnapshot.cat.dtype and new_cat is not runner.ParticleSnapshot.cat
+    out = _positions(new_cat, g['ndim'])
+    exp = g['expected']
+    assert np.array_equal(np.isnan(out), np.isnan(exp))
+    scale = np.nanmax(np.abs(exp - g['part']))                   # largest displacement
+    assert np.nanmax(np.abs(out - exp)) <= max(1e-10 * scale, 1e-13 * g['L'])
+    moved = np.abs(out - g['part']).max(axis=1) > 0
+    assert np.array_equal(np.nonzero(moved)[0], g['moved_idx'])  # exactly the reference's particles moved
+    assert np.array_equal(new_cat['M'], runner.ParticleSnapshot.cat['M'])
+    assert runner.last_stats['n_pairs'] >= g['moved_idx'].size
+
+
+@pytest.mark.parametrize('cells', ['7', '64', '301'])
+def test_snapshot_cell_grid_independence(gpu, cells):
+    """the halo-cell grid is only an acceleration structure: any resolution gives the same particles"""
+    g = H.load_snapshot_golden('snap3d_baryonify')
+    os.environ['BFGX_SNAP_CELLS'] = cells
+    try:
+        out = _positions(H.snapshot_product_runner(g).process(), 3)
+    finally:
+        del os.environ['BFGX_SNAP_CELLS']
+    assert np.nanmax(np.abs(out - g['expected'])) <= 1e-13 * g['L']
+
+
+@pytest.mark.parametrize('ndim', [2, 3])
+def test_snapshot_vs_oracle_larger(gpu, ndim):
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    from oracle import grid as G
+    from oracle import oracle as O
+    rng = np.random.default_rng(50 + ndim)
+    L, nh, npart, zr = 300.0, 1500, 300_000, 0.2
+    M = (10 ** rng.uniform(12.8, 15.0, nh)).astype(np.float32).astype(np.float64)
+    hpos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    part = rng.uniform(0, L, (npart, 3))
+    part[:50_000] = (hpos[rng.integers(0, nh, 50_000)] + rng.normal(scale=1.0, size=(50_000, 3))) % L    # clustered around halos
+    z, Mt, r = np.linspace(0.15, 0.25, 3), np.geomspace(10 ** 12.7, 10 ** 15.1, 8), np.geomspace(1e-3, 2e2, 200)
+    d = syn.displacement_table(z, Mt, r)
+    cos = dict(syn.COSMO)
+    HCat = bfg.utils.HaloNDCatalog(x=hpos[:, 0], y=hpos[:, 1], z=hpos[:, 2] if ndim == 3 else None, M=M, redshift=zr, cosmo=cos)
+    Snap = bfg.utils.ParticleSnapshot(x=part[:, 0], y=part[:, 1], z=part[:, 2] if ndim == 3 else None, M=np.ones(npart), L=L, redshift=zr, cosmo=cos)
+    model = bfg.Profiles.Baryonification3D(None, None, bfg.utils.Cosmology.from_dict(cos), epsilon_max=8.0)
+    model.set_table(z, Mt, r, d)
+    runner = bfg.Runners.BaryonifySnapshot(HCat, Snap, 5.0, model, verbose=False)
+    out = _positions(runner.process(), ndim)
+    cat = {'M': M, 'x': hpos[:, 0], 'y': hpos[:, 1], 'z': hpos[:, 2] if ndim == 3 else np.zeros(nh)}
+    tab = O.Table([np.log(1 + z), np.log(Mt), np.log(r)], d, False, 8.0)
+    ora, pairs = G.baryonify_snapshot([part[:, k] for k in range(ndim)], L, cat, zr, tab, 5.0, G.grid_background(cos), return_pairs=True)
+    ora = np.stack(ora, axis=1)
+    scale = np.abs(ora - part[:, :ndim]).max()
+    assert scale > 1e-3
+    assert np.abs(out - ora).max() <= max(1e-10 * scale, 1e-13 * L)
+    assert 0 < runner.last_stats['n_pairs'] <= pairs
+
+
+def test_snapshot_device_resident_and_errors(gpu):
+    import ctypes as C
+    import torch
+    import baryonification_amd as bfg
+    from baryonification_amd import _lib, engine
+    g = H.load_snapshot_golden('snap3d_baryonify')
+    host = _positions(H.snapshot_product_runner(g).process(), 3)
+    dev = torch.device('cuda:0')
+    cat = g['cat']
+    m, keep = engine.model_from_tables([np.log(1 + g['tab_z']), np.log(g['tab_M']), np.log(g['tab_r'])], g['tab_values'],
+                                       dict(g['cosmo_runner'], w0=-1.0), g['eps_runner'], g['eps_model'], cosmo_model=g['cosmo_model'])
+    t = {k: torch.tensor(cat[k], dtype=torch.float64, device=dev) for k in ('M', 'x', 'y', 'z')}
+    lnM = torch.tensor(np.log(cat['M'].astype(np.float32)).astype(np.float64), device=dev)
+    p = torch.tensor(np.ascontiguousarray(g['part'].T), device=dev)
+    o = torch.empty_like(p)
+    out = engine.baryonify_snapshot_device(m, _lib.make_grid_catalog_dev(cat['M'].size, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(),
+                                                                        t['z'].data_ptr(), lnM.data_ptr()),
+                                           (p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr()), g['npart'], g['L'], g['redshift'],
+                                           (o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert out > 0
+    assert np.nanmax(np.abs(o.cpu().numpy().T - host)) <= 1e-13 * g['L']
+    # particles outside the box are refused (scipy's periodic KDTree raises ValueError there too)
+    bad = g['part'].copy()
+    bad[5, 0] = -1.0
+    g2 = dict(g, part=bad)
+    with pytest.raises(ValueError):
+        H.snapshot_product_runner(g2).process()

@@ -113,3 +113,64 @@ def test_hip_pressure(gpu, G):
     from baryonification_amd import tables as T
     P = T.pressure_profile(G['rho_tot'], G['rho_gas'], G['r_p'], cutoff=float(G['P_cutoff']))
     assert np.abs(P / G['P_ref'] - 1).max() < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------- 3-D builder
+@pytest.fixture(scope='module')
+def G3():
+    f = np.load(os.path.join(HERE, 'golden', 'tables3d_s19.npz'))
+    return {k: f[k] for k in f.files}
+
+
+def _analytic_rho(r, M):
+    """the closed-form density of tests/golden/make_golden_tables3d.py (hole, negative patch, far cut-off)"""
+    M = np.atleast_1d(M)[:, None]
+    rs = 0.3 * (M / 1e14) ** (1.0 / 3.0)
+    x = r[None, :] / rs
+    rho = M / (4 * np.pi * rs ** 3) / (x * (1 + x) ** 2) / (1 + (r[None, :] / 30.0) ** 2) ** 2
+    rho = np.where((r[None, :] > 2.0) & (r[None, :] < 2.2), 0.0, rho)
+    rho = np.where((r[None, :] > 8.0) & (r[None, :] < 8.3), -1e-3 * rho, rho)
+    return np.where(r[None, :] > 900.0, 0.0, rho)
+
+
+def test_oracle_enclosed_mass_3d_matches_reference(G3):
+    r_int = OT.r_int_3d(G3['an_r'])
+    assert r_int.size == 50_000 and np.isclose(r_int[0], 1e-6 / 1.2) and np.isclose(r_int[-1], 1.2e3 * 1.2)
+    m = OT.enclosed_mass_3d(r_int, _analytic_rho(r_int, G3['an_M']), G3['an_r'])
+    assert np.array_equal(np.isnan(m), np.isnan(G3['an_Menc']))
+    assert np.nanmax(np.abs(m / G3['an_Menc'] - 1)) < 1e-13
+    for zi in range(2):           # the displacement step is shared with the 2-D builder
+        d, st = OT.displacement_rows(G3['r'], G3['M_dmo'][zi], G3['M_dmb'][zi])
+        assert np.abs(d - G3['d_ref'][zi]).max() <= 1e-13 * np.abs(G3['d_ref'][zi]).max() and np.all(st == 0)
+
+
+@pytest.mark.gpu
+def test_hip_enclosed_mass_3d(gpu, G3):
+    from baryonification_amd import tables as T
+    r_int = T.r_int_3d(G3['an_r'])
+    assert np.array_equal(r_int, OT.r_int_3d(G3['an_r']))
+    m = T.enclosed_mass_3d(r_int, _analytic_rho(r_int, G3['an_M']), G3['an_r'])
+    assert np.array_equal(np.isnan(m), np.isnan(G3['an_Menc']))
+    assert np.nanmax(np.abs(m / G3['an_Menc'] - 1)) < 1e-10          # parallel prefix sum vs np.cumsum, r*r*r vs r**3
+
+
+@pytest.mark.gpu
+@pytest.mark.filterwarnings('ignore')
+def test_baryonification3d_end_to_end(gpu, G3):
+    """our Schneider19 port + GPU builders reproduce the reference's Baryonification3D table (notebook-10 settings)"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    par = dict(zip([str(k) for k in G3['par_keys']], G3['par_vals'].tolist()))
+    cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+    DMO = bfg.Profiles.DarkMatter(**par)
+    DMB = bfg.Profiles.CollisionlessMatter(**par) + bfg.Profiles.Stars(**par) + bfg.Profiles.Gas(**par)
+    model = bfg.Profiles.Baryonification3D(DMO, DMB, cosmo, epsilon_max=20)
+    m = model.get_masses(DMO, G3['r'], G3['M_range'], 1.0)
+    assert np.nanmax(np.abs(m / G3['M_dmo'][0] - 1)) < 1e-9
+    assert model.get_masses(DMO, G3['r'], 1e14, 1.0).shape == (80,)
+    model.setup_interpolator(z_min=0, z_max=0.01, N_samples_z=2, z_linear_sampling=True, M_min=1e13, M_max=1e15,
+                             N_samples_Mass=3, R_min=1e-4, R_max=300, N_samples_R=80, verbose=False)
+    err = np.abs(model.raw_input_d - G3['d_ref'])
+    assert err.max() <= 2e-4 * np.abs(G3['d_ref']).max()             # CollisionlessMatter port differs at ~1e-6
+    nz = G3['d_ref'] != 0
+    assert np.median(err[nz] / np.abs(G3['d_ref'][nz])) < 1e-5
