@@ -223,10 +223,17 @@ grid_scatter_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restrict__ re
             }
         }
     }
-    if (pair_total) {
+    if (pair_total) {                     // one atomic per workgroup (same-address atomics serialise)
+        __shared__ unsigned long long wsum[kGridBlock / kWave];
 #pragma unroll
         for (int s = kWave >> 1; s > 0; s >>= 1) npairs += __shfl_down(npairs, s, kWave);
-        if ((threadIdx.x & (kWave - 1)) == 0 && npairs) atomicAdd(pair_total, npairs);
+        if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = npairs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kGridBlock / kWave; ++w) t += wsum[w];
+            if (t) atomicAdd(pair_total, t);
+        }
     }
 }
 

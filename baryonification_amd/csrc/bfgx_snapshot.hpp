@@ -187,9 +187,10 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
                      const int32_t *__restrict__ entries, double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz,
                      int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long npairs = 0;
-    if (p < np) {
+    // grid-stride: a bounded number of workgroups, so that the pair census ends in a few thousand atomics on one
+    // address instead of one per wave (10^6 same-address atomics cost ~10 ms)
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
         const double x = px[p], y = py[p], z = (DIM == 3) ? pz[p] : 0.0;
         double tx = 0.0, ty = 0.0, tz = 0.0;
         const bool inside = (x >= 0.0 && x <= g.L) && (y >= 0.0 && y <= g.L) && (DIM == 2 || (z >= 0.0 && z <= g.L));
@@ -228,9 +229,16 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
         }
     }
     if (pair_total) {
+        __shared__ unsigned long long wsum[256 / kWave];
 #pragma unroll
         for (int s = kWave >> 1; s > 0; s >>= 1) npairs += __shfl_down(npairs, s, kWave);
-        if ((threadIdx.x & (kWave - 1)) == 0 && npairs) atomicAdd(pair_total, npairs);
+        if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = npairs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < 256 / kWave; ++w) t += wsum[w];
+            if (t) atomicAdd(pair_total, t);
+        }
     }
 }
 

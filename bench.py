@@ -39,9 +39,10 @@ def parse():
     ap.add_argument('--eps', type=float, default=10.0)
     ap.add_argument('--acc-f64', action='store_true', help='fp64 pix_offsets accumulators instead of fp32')
     ap.add_argument('--algo', type=int, default=1, help='1 = LDS tiles (default), 0 = per-halo global atomics')
-    ap.add_argument('--mode', choices=['baryonify', 'paint', 'grid3d'], default='baryonify',
+    ap.add_argument('--mode', choices=['baryonify', 'paint', 'grid3d', 'snapshot'], default='baryonify',
                     help="'paint' = PaintProfilesShell (BASELINE config 3 with --nside 2048); 'grid3d' = BASELINE config 5 "
-                         "(particle deposit + BaryonifyGrid on an --ngrid^3 periodic grid + FFT P(k)); neither is the headline metric")
+                         "(particle deposit + BaryonifyGrid on an --ngrid^3 periodic grid + FFT P(k)); 'snapshot' = the flow of the "
+                         "reference's notebook 10 (BaryonifySnapshot of the particles + deposit + FFT P(k)); none of these is the headline metric")
     ap.add_argument('--ngrid', type=int, default=512, help='grid3d: cells per side (power of two)')
     ap.add_argument('--particles', type=int, default=0, help='grid3d: particles in the snapshot (default ngrid^3 / 2)')
     ap.add_argument('--grid-halos', type=int, default=100_000, help='grid3d: halos per GPU')
@@ -140,7 +141,11 @@ def main_grid(args):
     d_sums = torch.zeros(2, dtype=torch.float64, device=dev)
     d_pk, d_ks = torch.zeros(Nk, dtype=torch.float64, device=dev), torch.zeros(Nk, dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(Nk, dtype=torch.int64, device=dev)
-    ev = {k: [] for k in ('deposit', 'pk')}
+    snapshot = args.mode == 'snapshot'
+    if snapshot:
+        assert world == 1, "--mode snapshot is single-GPU (particles are not sharded)"
+        part_out = torch.empty_like(part)
+    ev = {k: [] for k in (('displace', 'deposit', 'pk') if snapshot else ('deposit', 'pk'))}
     pairs = [0]
 
     def timed(kind, fn):
@@ -148,7 +153,19 @@ def main_grid(args):
         a.record(); fn(); b.record()
         ev[kind].append((a, b))
 
+    def step_snapshot():
+        def displace():
+            pairs[0] = engine.baryonify_snapshot_device(model, cat_dev, (part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr()), npart, L, zr,
+                                                        (part_out[0].data_ptr(), part_out[1].data_ptr(), part_out[2].data_ptr()), local_rank, stream)
+        timed('displace', displace)
+        timed('deposit', lambda: engine.deposit_particles_device(part_out[0].data_ptr(), part_out[1].data_ptr(), part_out[2].data_ptr(), 0, npart, N,
+                                                                 d_edges.data_ptr(), d_out.data_ptr(), 3, local_rank, stream))
+        timed('pk', lambda: engine.power_spectrum_device(d_out.data_ptr(), N, L, Nk, d_work.data_ptr(), d_pk.data_ptr(),
+                                                         d_ks.data_ptr(), d_cnt.data_ptr(), local_rank, stream))
+
     def step():
+        if snapshot:
+            return step_snapshot()
         d_sums.zero_()
         if rank == 0:
             timed('deposit', lambda: engine.deposit_particles_device(part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), 0, npart, N,
@@ -189,11 +206,14 @@ def main_grid(args):
         sums = d_sums.cpu().numpy()
         pk = (d_pk / d_cnt).cpu().numpy()
         alg = {'regrid': N ** 3 * (3 * 8 + 8 + 8 * 8 + 8), 'offsets': pairs[0] * 3 * 8 + nh * 32, 'deposit': npart * (3 * 8 + 8) + N ** 3 * 8,
-               'pk': N ** 3 * 8 + 5 * N * N * (N // 2 + 1) * 16}
+               'pk': N ** 3 * 8 + 5 * N * N * (N // 2 + 1) * 16, 'displace': npart * 48 + nh * 32}
         dom = max(alg, key=lambda k: kernels.get(k) or 0.0)
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
-        out = {"metric": "grid cells/sec for particle deposit + BaryonifyGrid + FFT P(k) on a %d^3 periodic grid" % N,
-               "value": N ** 3 / elapsed * args.steps, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        if snapshot:
+            sums = np.array([float(npart), float(d_out.sum().item())])       # every particle lands in the box
+        out = {"metric": ("particles/sec for BaryonifySnapshot + deposit + FFT P(k) on a %d^3 grid" % N) if snapshot else
+                         ("grid cells/sec for particle deposit + BaryonifyGrid + FFT P(k) on a %d^3 periodic grid" % N),
+               "value": (npart if snapshot else N ** 3) / elapsed * args.steps, "unit": "particles/s" if snapshot else "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE config 5 (single-node form): %d^3 grid of a %.1f Mpc box at z=0, %d uniform particles, %d halos "
@@ -204,10 +224,10 @@ def main_grid(args):
                "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
                "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),
                "roofline": {"kernel": {"regrid": "grid_regrid_kernel<3>", "offsets": "grid_scatter_kernel<3,OFFSETS>", "deposit": "particle_deposit_kernel<3>",
-                                       "pk": "fft_r2c_lines + 2 x fft_c2c_strided + pk_bin"}[dom],
+                                       "pk": "fft_r2c_lines + 2 x fft_c2c_strided + pk_bin", "displace": "snap_displace_kernel<3>"}[dom],
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_launch": alg[dom]}}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not snapshot:
             out["cpu_baseline"] = cpu_baseline_grid(args, cat, bins, zr, axes, table, eps)
         print(json.dumps(out), flush=True)
     plan.close()
@@ -217,7 +237,7 @@ def main_grid(args):
 
 def main():
     args = parse()
-    if args.mode == 'grid3d':
+    if args.mode in ('grid3d', 'snapshot'):
         return main_grid(args)
     import torch
     import torch.distributed as dist
