@@ -1158,9 +1158,19 @@ __device__ inline double ring_theta(const Hpx &h, int ring)
 constexpr int kApronR = 2;     // apron rings above / below the band
 constexpr int kApronK = 4;     // apron pixels left / right of the tile's azimuth range
 
+// one ring of the tiled regrid's LDS window (rings i0 - kApronR - 1 .. i1 + kApronR): everything the per-pixel code
+// needs of a ring, so that no pixel re-derives ring geometry (integer divisions, square roots, 2 pi / n)
+struct RegRow {
+    double theta, z, sth;                 // colatitude (-inf / +inf beyond the poles), cos, sin
+    double dphi, inv_dphi;                // 2 pi / nr and nr / (2 pi)
+    double c0, s0;                        // cos / sin of the azimuth of the tile's first pixel (ks) in this ring
+    int64_t start;
+    int32_t nr, ks, ke, shf;              // nr == 0: no such ring
+};
+
 __host__ __device__ inline size_t regrid_lds_bytes(int BR, int W)
 {
-    return ((size_t)(BR + 2 * kApronR) * (W + 2 * kApronK) + (BR + 2 * kApronR + 2)) * sizeof(double);
+    return (size_t)(BR + 2 * kApronR) * (W + 2 * kApronK) * sizeof(double) + (size_t)(BR + 2 * kApronR + 2) * sizeof(RegRow);
 }
 
 // colatitude of a ring centre without libm (atan2 of the ring's sin/cos), for the tiled regrid
@@ -1179,7 +1189,7 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     extern __shared__ __align__(16) unsigned char smem[];
     const int LR = T.BR + 2 * kApronR, LW = T.W + 2 * kApronK;
     double *acc = reinterpret_cast<double *>(smem);            // [LR][LW]
-    double *rth = acc + LR * LW;                               // colatitudes of rings i0-A-1 .. i1+A
+    RegRow *rows = reinterpret_cast<RegRow *>(acc + LR * LW);  // rings rth0 .. rth0 + LR + 1
     const int tile = blockIdx.x;
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
@@ -1188,64 +1198,86 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     const int i0 = 1 + band * T.BR;
     const int i1 = min(i0 + T.BR, nl4);                        // exclusive
     const int tid = threadIdx.x;
+    const int rth0 = i0 - kApronR - 1;
     for (int i = tid; i < LR * LW; i += 256) acc[i] = 0.0;
     if (tid < LR + 2) {
-        const int ring = i0 - kApronR - 1 + tid;
-        rth[tid] = (ring >= 1 && ring <= nl4 - 1) ? ring_theta_nolibm(h, ring) : 0.0;
+        const int ring = rth0 + tid;
+        RegRow rw;
+        rw.theta = (ring < 1) ? -1.0e300 : 1.0e300;
+        rw.z = rw.sth = rw.dphi = rw.inv_dphi = rw.c0 = rw.s0 = 0.0;
+        rw.start = 0; rw.nr = 0; rw.ks = 0; rw.ke = 0; rw.shf = 0;
+        if (ring >= 1 && ring <= nl4 - 1) {
+            int64_t st, nr64; bool shf;
+            ring_info_small(h, ring, st, nr64, shf);
+            ring_z_sth(h, ring, rw.z, rw.sth);
+            rw.theta = atan2_generic(rw.sth, rw.z);
+            rw.start = st; rw.nr = (int)nr64; rw.shf = shf ? 1 : 0;
+            rw.dphi = kTwoPi / (double)rw.nr;
+            rw.inv_dphi = (double)rw.nr * kInvTwoPi;
+            rw.ks = tile_ks(tj, rw.nr, nphi);
+            rw.ke = tile_ks(tj + 1, rw.nr, nphi);
+            sincos_bounded(((double)rw.ks + (shf ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
+        }
+        rows[tid] = rw;
     }
     __syncthreads();
-    const int rth0 = i0 - kApronR - 1;
 
     auto add_target = [&](int ring_t, int k_t, double v) {
+        const int ti = ring_t - rth0;
+        if (ti >= 1 && ti <= LR) {                             // rings i0 - kApronR .. i1 + kApronR - 1 own an LDS row
+            const RegRow &rt = rows[ti];
+            int dk = k_t - rt.ks;
+            if (dk >= LW - kApronK) dk -= rt.nr;
+            if (dk < -kApronK) dk += rt.nr;
+            if (dk >= -kApronK && dk < LW - kApronK) { atomicAdd(acc + (ti - 1) * LW + dk + kApronK, v); return; }
+            atomicAdd(map_out + rt.start + k_t, v);            // far target in a window ring (rare)
+            return;
+        }
         int64_t st_t, nr64; bool sh_t;
         ring_info_small(h, ring_t, st_t, nr64, sh_t);
-        const int nr_t = (int)nr64;
-        const int rr = ring_t - (i0 - kApronR);
-        if (rr >= 0 && rr < LR) {
-            int dk = k_t - tile_ks(tj, nr_t, nphi);
-            if (dk >= LW - kApronK) dk -= nr_t;
-            if (dk < -kApronK) dk += nr_t;
-            if (dk >= -kApronK && dk < LW - kApronK) { atomicAdd(acc + rr * LW + dk + kApronK, v); return; }
-        }
         atomicAdd(map_out + st_t + k_t, v);                    // far target (rare)
     };
 
     // source pixels of the tile, 8 per thread; the loads of pixel i+1 are issued before pixel i is processed
-    struct Src { int ring, k, nr; bool shf, ok; int64_t p; double val; ACC o0, o1, o2; };
+    struct Src { int ti, x; bool ok; double val; ACC o0, o1, o2; };
+    const int wshift = ((T.W & (T.W - 1)) == 0) ? __ffs(T.W) - 1 : -1;      // W a power of two: shift instead of divide
     auto fetch = [&](int idx) {
         Src sx;
-        sx.ok = false; sx.ring = 0; sx.k = 0; sx.nr = 1; sx.shf = false; sx.p = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (ACC)0;
+        sx.ok = false; sx.ti = 0; sx.x = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (ACC)0;
         if (idx < T.BR * T.W) {
-            const int r = idx / T.W, x = idx - r * T.W;
-            const int ring = i0 + r;
-            if (ring < i1) {
-                int64_t st, nr64; bool shf;
-                ring_info_small(h, ring, st, nr64, shf);
-                const int nr = (int)nr64;
-                const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
-                if (x < ke - ks) {
-                    sx.ok = true; sx.ring = ring; sx.k = ks + x; sx.nr = nr; sx.shf = shf; sx.p = st + sx.k;
-                    sx.val = map_in[sx.p];
-                    sx.o0 = offsets[3 * sx.p + 0]; sx.o1 = offsets[3 * sx.p + 1]; sx.o2 = offsets[3 * sx.p + 2];
+            const int r = (wshift >= 0) ? (idx >> wshift) : idx / T.W, x = idx - r * T.W;
+            if (i0 + r < i1) {
+                const RegRow &rw = rows[r + kApronR + 1];
+                if (x < rw.ke - rw.ks) {
+                    const int64_t p = rw.start + rw.ks + x;
+                    sx.ok = true; sx.ti = r + kApronR + 1; sx.x = x;
+                    sx.val = map_in[p];
+                    sx.o0 = offsets[3 * p + 0]; sx.o1 = offsets[3 * p + 1]; sx.o2 = offsets[3 * p + 2];
                 }
             }
         }
         return sx;
     };
+    int last_nr = -1, last_x = -1;                     // sincos(x * dphi) is reused while the ring length stays the same
+    double sa = 0.0, ca = 1.0;
     Src nxt = fetch(tid);
     for (int idx = tid; idx < T.BR * T.W; idx += 256) {
         const Src cur = nxt;
         nxt = fetch(idx + 256);
         if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
-        const int ring = cur.ring, k = cur.k, nr = cur.nr;
-        const bool shf = cur.shf;
+        const RegRow &rw = rows[cur.ti];
         const double val = cur.val;
-        double z, sth;
-        ring_z_sth(h, ring, z, sth);
-        const double dphi0 = kTwoPi / (double)nr;
-        const double phi = ((double)k + (shf ? 0.5 : 0.0)) * dphi0;
+        const double z = rw.z, sth = rw.sth;
+        const double phi = ((double)(rw.ks + cur.x) + (rw.shf ? 0.5 : 0.0)) * rw.dphi;
         double s, c;
-        sincos_bounded(phi, s, c);
+        const double ang = (double)cur.x * rw.dphi;                          // azimuth relative to the tile's first pixel
+        if (ang <= 0.45) {
+            if (rw.nr != last_nr || cur.x != last_x) { sincos_small(ang, sa, ca); last_nr = rw.nr; last_x = cur.x; }
+            c = rw.c0 * ca - rw.s0 * sa;
+            s = rw.s0 * ca + rw.c0 * sa;
+        } else {
+            sincos_bounded(phi, s, c);
+        }
         const double nx = sth * c + (double)cur.o0;                          // :333
         const double ny = sth * s + (double)cur.o1;
         const double nz = z + (double)cur.o2;
@@ -1258,19 +1290,25 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
         const double tq = yr * fast_rcp(xr);
         const double sn = fast_sqrt(xr * xr + yr * yr) * inv;                // sin(theta_new)
         const double q = sn * z - zc * sth;
-        const double th_pix = rth[ring - rth0];
         double theta, ph;
         if (xr > 0.0 && fabs(tq) <= 0.1 && fabs(q) <= 0.05) {
             ph = phi + atan_small(tq);
-            theta = th_pix + asin_small(q);
+            theta = rw.theta + asin_small(q);
         } else {                                                             // large displacement: libm
             theta = atan2_generic(sn, zc);
             ph = atan2_generic(ny, nx);
         }
         if (ph < 0) ph += kTwoPi;
         if (ph >= kTwoPi) ph -= kTwoPi;
-        // get_interp_weights (:337): healpix_cxx get_interpol with ring colatitudes from the LDS table
-        const int ir1 = (int)ring_above(h, zc), ir2 = ir1 + 1;
+        // get_interp_weights (:337): healpix_cxx get_interpol.  ring_above(z) is the ring with theta_ring <= theta <
+        // theta_next; found by walking the window's colatitude table from the pixel's own ring (on a ring boundary both
+        // answers interpolate to the same value), with the closed form as fallback outside the window.
+        int t1 = cur.ti;
+        while (t1 > 0 && theta < rows[t1].theta) --t1;
+        while (t1 < LR + 1 && theta >= rows[t1 + 1].theta) ++t1;
+        const bool in_window = (theta >= rows[t1].theta) && (t1 < LR + 1) && (theta < rows[t1 + 1].theta);
+        const int ir1 = in_window ? rth0 + t1 : (int)ring_above(h, zc);
+        const int ir2 = ir1 + 1;
         int tr[4] = {0, 0, 0, 0}, tk[4] = {0, 0, 0, 0};
         double w[4] = {0.0, 0.0, 0.0, 0.0};
         double theta1 = 0.0, theta2 = 0.0;
@@ -1278,10 +1316,17 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
         for (int half = 0; half < 2; ++half) {
             const int ir = half ? ir2 : ir1;
             if (half ? (ir < nl4) : (ir > 0)) {
-                const int n2 = ring_len(h, ir);
-                const bool sh2 = (ir < h.nside) || (ir >= 3 * h.nside) || (((ir - (int)h.nside) & 1) == 0);
-                const double shd = sh2 ? 0.5 : 0.0;
-                const double tmp = ph * ((double)n2 * kInvTwoPi) - shd;
+                const int ti = ir - rth0;
+                int n2; double shd, invd, th;
+                if (ti >= 0 && ti < LR + 2) {
+                    const RegRow &r2 = rows[ti];
+                    n2 = r2.nr; shd = r2.shf ? 0.5 : 0.0; invd = r2.inv_dphi; th = r2.theta;
+                } else {
+                    n2 = ring_len(h, ir);
+                    const bool sh2 = (ir < h.nside) || (ir >= 3 * h.nside) || (((ir - (int)h.nside) & 1) == 0);
+                    shd = sh2 ? 0.5 : 0.0; invd = (double)n2 * kInvTwoPi; th = ring_theta_nolibm(h, ir);
+                }
+                const double tmp = ph * invd - shd;
                 int j1 = (int)floor(tmp);
                 const double w1 = tmp - (double)j1;
                 int j2 = j1 + 1;
@@ -1290,8 +1335,6 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
                 tr[2 * half] = ir; tr[2 * half + 1] = ir;
                 tk[2 * half] = j1; tk[2 * half + 1] = j2;
                 w[2 * half] = 1.0 - w1; w[2 * half + 1] = w1;
-                const int ti = ir - rth0;
-                const double th = (ti >= 0 && ti < LR + 2) ? rth[ti] : ring_theta_nolibm(h, ir);
                 if (half) theta2 = th; else theta1 = th;
             }
         }
@@ -1320,18 +1363,17 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     // flush: row-contiguous fp64 atomics
     const int lane = tid & (kWave - 1), wid = tid / kWave;
     for (int rr = wid; rr < LR; rr += 256 / kWave) {
-        const int ring_t = i0 - kApronR + rr;
-        if (ring_t < 1 || ring_t > nl4 - 1) continue;
-        int64_t st_t, nr64; bool sh_t;
-        ring_info_small(h, ring_t, st_t, nr64, sh_t);
-        const int nr_t = (int)nr64;
-        const int k0 = tile_ks(tj, nr_t, nphi) - kApronK;
+        const RegRow &rt = rows[rr + 1];
+        if (rt.nr == 0) continue;
+        const int k0 = rt.ks - kApronK;
         for (int xx = lane; xx < LW; xx += kWave) {
             const double v = acc[rr * LW + xx];
             if (v != 0.0) {
-                int k = (k0 + xx) % nr_t;
-                if (k < 0) k += nr_t;
-                atomicAdd(map_out + st_t + k, v);
+                int k = k0 + xx;
+                if (k < 0) k += rt.nr;
+                if (k >= rt.nr) k -= rt.nr;
+                if (k < 0 || k >= rt.nr) { k %= rt.nr; if (k < 0) k += rt.nr; }
+                atomicAdd(map_out + rt.start + k, v);
             }
         }
     }
