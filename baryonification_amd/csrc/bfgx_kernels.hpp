@@ -961,7 +961,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
         if (lane < kChunk) L.ring[lane].prefix = incl_e - nrows;
         __builtin_amdgcn_wave_barrier();
 
-        for (int rb = 0; rb < total_rows; rb += kWave) {
+        for (int rb = 0; rb < (BFGX_ABLATE == 8 ? 0 : total_rows); rb += kWave) {
             // ---- lanes = ring rows (clipped to this tile)
             const int R = rb + lane;
             int firstA = 0, cntA = 0, firstB = 0, cntB = 0, nr = 1, ldsbase = 0, es = 0;
