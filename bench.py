@@ -50,30 +50,40 @@ def parse():
                     help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
                          "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample')
+    ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample (single-thread baseline)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (0 = all available cores, at most 16)')
     return ap.parse_args()
 
 
 def cpu_baseline(args, cat, hmap, axes, table):
-    """Oracle (C restatement of the reference loop, 1 thread) on a bounded sample of the same workload:
-    halo loop on the first `cpu_sample` halos + the full-map regrid; extrapolated to the full catalog."""
+    """Oracle (C restatement of the reference loop) on the host cores of the GPU box.  With --cpu-threads T > 1 (default:
+    all cores the box gives us, at most 16) the FULL catalog is split into T halo slices (private pix_offsets buffers,
+    summed) and the regrid into T pixel ranges; with T = 1 the halo loop runs on a bounded sample and is scaled."""
     from oracle import oracle as O
-    n = min(args.cpu_sample, cat['M'].size)
-    sub = {k: v[:n] for k, v in cat.items()}
     from baryonification_amd import synthetic as syn
     bg = O.Background.from_dict(syn.COSMO)
     tab = O.Table(axes, table, False, args.eps)
+    T = args.cpu_threads if args.cpu_threads > 0 else max(1, min(16, len(os.sched_getaffinity(0))))
+    N = cat['M'].size
+    if T > 1:
+        _, t_loop, t_rg, pairs = O.baryonify_shell_threads(args.nside, hmap, cat, tab, args.eps, bg, T)
+        return {"value": N / (t_loop + t_rg), "unit": "halos/s", "cores": T, "kind": "port",
+                "sample": "full workload: %d halos (%d pairs) in %d halo slices (%.2f s incl. summing the private pix_offsets) + "
+                          "full NSIDE=%d regrid in %d pixel ranges (%.2f s); scalar C restatement per thread" % (
+                              N, pairs, T, t_loop, args.nside, T, t_rg),
+                "loop_halos_per_s": N / t_loop, "regrid_pix_per_s": hmap.size / t_rg}
+    n = min(args.cpu_sample, N)
+    sub = {k: v[:n] for k, v in cat.items()}
     t0 = time.time()
     off, counts = O.baryonify_offsets(args.nside, sub, tab, args.eps, bg, return_counts=True)
     t1 = time.time()
     O.regrid(args.nside, hmap, off)
     t2 = time.time()
-    t_loop_full = (t1 - t0) * cat['M'].size / n
+    t_loop_full = (t1 - t0) * N / n
     t_full = t_loop_full + (t2 - t1)
-    return {"value": cat['M'].size / t_full, "unit": "halos/s", "cores": 1, "kind": "port",
+    return {"value": N / t_full, "unit": "halos/s", "cores": 1, "kind": "port",
             "sample": "halo loop on first %d of %d halos (%.2f s, %d pairs) + full NSIDE=%d regrid (%.2f s); "
-                      "loop time scaled to the full catalog" % (n, cat['M'].size, t1 - t0, int(counts.sum()),
-                                                                 args.nside, t2 - t1),
+                      "loop time scaled to the full catalog" % (n, N, t1 - t0, int(counts.sum()), args.nside, t2 - t1),
             "loop_halos_per_s": n / (t1 - t0), "regrid_pix_per_s": hmap.size / (t2 - t1)}
 
 

@@ -504,10 +504,18 @@ i64 bfgo_baryonify_offsets(i64 nside, i64 nhalo,
  * Post-loop regrid, HealpixRunner.py:333-341 + regrid_pixels_hpix :60-64.
  * new_map must be zero-initialised by the caller ([npix], float64).
  */
+void bfgo_regrid_range(i64 nside, i64 p0, i64 p1, const double *orig_map, const double *pix_offsets, double *new_map);
+
 void bfgo_regrid(i64 nside, const double *orig_map, const double *pix_offsets, double *new_map)
 {
+    bfgo_regrid_range(nside, 0, 12 * nside * nside, orig_map, pix_offsets, new_map);
+}
+
+/* source pixels [p0, p1) only (lets a caller spread the map over threads, each with its own new_map) */
+void bfgo_regrid_range(i64 nside, i64 p0, i64 p1, const double *orig_map, const double *pix_offsets, double *new_map)
+{
     hpx_t h = hpx_make(nside);
-    for (i64 p = 0; p < h.npix; ++p) {
+    for (i64 p = p0; p < p1; ++p) {
         if (!(orig_map[p] > 0)) continue;                             /* :335 */
         double v[3], lon, lat, th, ph, w[4];
         i64 cp[4];

@@ -122,6 +122,7 @@ def lib():
                                              C.c_int, vp, vp, vp, C.c_int, dbl, dbl, vp, vp]
         L.bfgo_baryonify_offsets.restype = i64
         L.bfgo_regrid.argtypes = [i64, vp, vp, vp]
+        L.bfgo_regrid_range.argtypes = [i64, i64, i64, vp, vp, vp]
         L.bfgo_paint.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp,
                                  C.c_int, vp, vp, vp, dbl, vp, vp]
         L.bfgo_paint.restype = i64
@@ -266,3 +267,53 @@ def paint_shell(nside, cat, log_table, eps_runner, bg_runner, return_counts=Fals
                      len(extra), _ptr_array(extra), ndim, _ptr(tn), tax, _ptr(log_table.values),
                      float(eps_runner), _ptr(new_map), _ptr(counts))
     return (new_map, counts) if return_counts else new_map
+
+
+def baryonify_shell_threads(nside, orig_map, cat, table, eps_runner, bg_runner, threads, bg_model=None):
+    """The same scalar restatement spread over `threads` host threads (ctypes releases the GIL): halo slices with
+    private pix_offsets buffers that are summed, then pixel ranges with private new_map buffers.  Only used to time a
+    multi-core CPU baseline; returns (new_map, seconds_loop, seconds_regrid, pairs)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    a, R, D, Rmod = (_f8(v) for v in halo_scalars(cat, bg_runner, bg_model))
+    ra, dec, M = _f8(cat['ra']), _f8(cat['dec']), _f8(cat['M'])
+    extra = [_f8(cat[k]) for k in table.p_keys]
+    ndim, tn, tax = table._cargs()
+    npix = 12 * nside * nside
+    n = ra.size
+    cuts = np.linspace(0, n, threads + 1).astype(np.int64)
+    L = lib()
+
+    def loop(i):
+        lo, hi = int(cuts[i]), int(cuts[i + 1])
+        off = np.zeros((npix, 3))
+        ex = [e[lo:hi] for e in extra]
+        tot = L.bfgo_baryonify_offsets(nside, hi - lo, _ptr(ra[lo:hi]), _ptr(dec[lo:hi]), _ptr(M[lo:hi]), _ptr(a[lo:hi]), _ptr(R[lo:hi]),
+                                       _ptr(D[lo:hi]), _ptr(Rmod[lo:hi]), len(ex), _ptr_array(ex), ndim, _ptr(tn), tax,
+                                       _ptr(table.values), int(table.rdelta_sampling), float(eps_runner), table.eps_model,
+                                       _ptr(off), None)
+        return off, tot
+
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex_:
+        parts = list(ex_.map(loop, range(threads)))
+    off = parts[0][0]
+    for o_, _ in parts[1:]:
+        off += o_
+    pairs = sum(t for _, t in parts)
+    t1 = time.time()
+    orig_map = _f8(orig_map)
+    pcuts = np.linspace(0, npix, threads + 1).astype(np.int64)
+
+    def rg(i):
+        nm = np.zeros(npix)
+        L.bfgo_regrid_range(nside, int(pcuts[i]), int(pcuts[i + 1]), _ptr(orig_map), _ptr(off), _ptr(nm))
+        return nm
+
+    with ThreadPoolExecutor(threads) as ex_:
+        maps = list(ex_.map(rg, range(threads)))
+    new_map = maps[0]
+    for m_ in maps[1:]:
+        new_map += m_
+    t2 = time.time()
+    return new_map, t1 - t0, t2 - t1, pairs

@@ -36,5 +36,19 @@ PAR2 = dict(PAR, mu_theta_ej=0.3, nu_theta_ej=0.5, zeta_theta_ej=0.2, mu_delta=0
 out['Gas_scaled'] = bfg.Profiles.Gas(**PAR2).real(cosmo, r, M, a)
 out['par2_keys'] = np.array(sorted(PAR2))
 out['par2_vals'] = np.array([PAR2[k] for k in sorted(PAR2)])
+# thermodynamic scalings built on Pressure (Thermodynamic.py:282-368, :431-457, :662-775), one-halo total matter as in
+# make_golden_tables.py
+r_t = np.geomspace(5e-3, 20, 16)
+M_t = np.array([3e13, 4e14])
+Pgas = bfg.Profiles.Gas(**PAR)
+Ptot = bfg.Profiles.CollisionlessMatter(**PAR) + bfg.Profiles.Stars(**PAR) + bfg.Profiles.Gas(**PAR)
+Pth = bfg.Profiles.Pressure(gas=Pgas, darkmatterbaryon=Ptot, **PAR)
+fnt = bfg.Profiles.NonThermalFrac(**PAR)
+out['thermo_r'], out['thermo_M'] = r_t, M_t
+out['NonThermalFrac'] = fnt.real(cosmo, r_t, M_t, a)
+out['NonThermalFrac_z0'] = fnt.real(cosmo, r_t, M_t, 1.0)
+out['ElectronPressure'] = bfg.Profiles.ElectronPressure(gas=Pgas, darkmatterbaryon=Ptot, **PAR).real(cosmo, r_t, M_t, a)
+out['ThermalSZ'] = bfg.Profiles.ThermalSZ(pressure=Pth * (1 - fnt), **PAR).projected(cosmo, r_t, M_t, a)
+out['ThermalSZ_real'] = bfg.Profiles.ThermalSZ(pressure=Pth, **PAR).real(cosmo, r_t, M_t, a)
 np.savez_compressed(os.path.join(HERE, 'profiles_s19.npz'), **out)
 print({k: np.shape(v) for k, v in out.items()})

@@ -119,3 +119,35 @@ def test_quickstart_flow_with_own_profiles(gpu, T):
     y = bfg.Runners.PaintProfilesShell(Catalog, bfg.utils.LightconeShell(map=np.zeros(12 * 128 ** 2), cosmo=syn.COSMO), 5, press,
                                        verbose=False).process()
     assert y.min() >= 0 and y.max() > 0 and np.isfinite(y).all()
+
+
+# ------------------------------------------------------------------------------------------------- thermodynamic scalings
+def test_nonthermal_fraction_matches_reference(P, T):
+    """pure host formula (Thermodynamic.py:347-368): runs without a GPU"""
+    par = _par(T)
+    cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+    f = bfg.Profiles.NonThermalFrac(**par)
+    for key, a in (('NonThermalFrac', float(P['a'])), ('NonThermalFrac_z0', 1.0)):
+        got = f.real(cosmo, P['thermo_r'], P['thermo_M'], a)
+        assert got.shape == P[key].shape and np.abs(got - P[key]).max() < 1e-13
+    assert np.all((P['NonThermalFrac'] >= 0) & (P['NonThermalFrac'] <= 1))
+    sz = bfg.Profiles.ThermalSZ(pressure=f, **par)
+    assert np.all(sz.real(cosmo, P['thermo_r'], P['thermo_M'], 0.8) == -99)                 # the reference's sentinel (:757-767)
+
+
+@pytest.mark.gpu
+@pytest.mark.filterwarnings('ignore')
+def test_thermal_sz_and_electron_pressure_match_reference(gpu, P, T):
+    """Pressure integrals + line-of-sight projection on the GPU, scalings on the host (quickstart tSZ flow, README.md:84-87
+    without the pixel-window convolution)"""
+    par = _par(T)
+    cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+    a = float(P['a'])
+    gas = bfg.Profiles.Gas(**par)
+    tot = bfg.Profiles.CollisionlessMatter(**par) + bfg.Profiles.Stars(**par) + bfg.Profiles.Gas(**par)
+    pe = bfg.Profiles.ElectronPressure(gas=gas, darkmatterbaryon=tot, **par).real(cosmo, P['thermo_r'], P['thermo_M'], a)
+    assert np.abs(pe / P['ElectronPressure'] - 1).max() < 1e-5                              # CollisionlessMatter port ~1e-6
+    pth = bfg.Profiles.Pressure(gas=gas, darkmatterbaryon=tot, **par)
+    y = bfg.Profiles.ThermalSZ(pressure=pth * (1 - bfg.Profiles.NonThermalFrac(**par)), **par).projected(cosmo, P['thermo_r'], P['thermo_M'], a)
+    assert y.shape == P['ThermalSZ'].shape and np.abs(y / P['ThermalSZ'] - 1).max() < 1e-5
+    assert np.ndim(bfg.Profiles.ThermalSZ(pressure=pth, **par).projected(cosmo, 0.5, 1e14, a)) == 0
