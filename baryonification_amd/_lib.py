@@ -90,6 +90,8 @@ SYMBOLS = {
     'bfgx_plan_destroy': (None, [C.c_void_p]),
     'bfgx_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'bfgx_plan_bands': (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_void_p]),
+    'bfgx_regrid_bands_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
     'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_plan_set_algo': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_status': (C.c_int, [C.c_void_p]),

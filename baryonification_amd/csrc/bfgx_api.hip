@@ -92,6 +92,8 @@ struct bfgx_plan {
             *overflow = nullptr;
     TileRef *tref = nullptr;
     unsigned long long *pair_total = nullptr;
+    int32_t *regrid_oob = nullptr;   // set when a banded regrid dropped a deposit outside its output window
+    std::vector<int32_t> band_tile0_host;   // first tile of every band (+ total)
     int64_t capacity = 0;
     // optional per-kernel HIP-event timing (bfgx_plan_timing_*)
     bool timing = false;
@@ -460,6 +462,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         const void *dv = nullptr;
         if (int rc = plan_upload(p, tile0.data(), sizeof(int32_t) * tile0.size(), &dv)) return bail(rc);
         T.band_tile0 = (const int32_t *)dv;
+        p->band_tile0_host = tile0;
         if (int rc = plan_upload(p, nphi.data(), sizeof(int32_t) * nphi.size(), &dv)) return bail(rc);
         T.band_nphi = (const int32_t *)dv;
         if (int rc = plan_upload(p, nrmin.data(), sizeof(int32_t) * nrmin.size(), &dv)) return bail(rc);
@@ -483,6 +486,10 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         p->tile_cursor = p->tile_count + 2 * (T.ntiles + 1);
         p->tile_start = (int32_t *)d1; p->tref = (TileRef *)d6;
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
+        void *d7 = nullptr;
+        if (dalloc(sizeof(int32_t), &d7)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(flag) failed"));
+        p->regrid_oob = (int32_t *)d7;
+        if (hipMemsetAsync(p->regrid_oob, 0, sizeof(int32_t), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
         if (hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream) != hipSuccess)
             return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
     }
@@ -546,6 +553,62 @@ int bfgx_plan_status(bfgx_plan *p)
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (ov) return fail(BFGX_ERR_INVALID, "halo->tile entry list overflowed its capacity (%lld); results are incomplete",
                         (long long)p->capacity);
+    int32_t oob = 0;
+    HIP_TRY(hipMemcpyAsync(&oob, p->regrid_oob, sizeof(oob), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (oob) {
+        HIP_TRY(hipMemsetAsync(p->regrid_oob, 0, sizeof(int32_t), p->stream));
+        return fail(BFGX_ERR_INVALID, "a banded regrid dropped deposits outside its output window (displacements larger than the window margin): "
+                                      "use a wider margin or the full-map regrid");
+    }
+    return BFGX_OK;
+}
+
+int bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel)
+{
+    if (!p || !nbands) return fail(BFGX_ERR_INVALID, "NULL argument");
+    *nbands = p->tiling.nbands;
+    if (band_first_pixel) {                       // band b = rings [1 + BR b, 1 + BR (b + 1)): a contiguous RING pixel range
+        const int64_t nl4 = 4 * p->hpx.nside;
+        for (int b = 0; b <= p->tiling.nbands; ++b) {
+            const int64_t ring = std::min<int64_t>(1 + (int64_t)p->tiling.BR * b, nl4);
+            if (ring >= nl4) { band_first_pixel[b] = p->hpx.npix; continue; }
+            const int64_t ns = p->hpx.nside, q = nl4 - ring;
+            band_first_pixel[b] = (ring < ns) ? 2 * ring * (ring - 1)
+                                : (ring < 3 * ns) ? p->hpx.ncap + (ring - ns) * 4 * ns
+                                : p->hpx.npix - 2 * q * (q + 1);
+        }
+    }
+    return BFGX_OK;
+}
+
+int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_slice_dev,
+                             int acc_f64, double *window_dev, int64_t wlo, int64_t whi)
+{
+    if (!p || !map_in_dev || !offsets_slice_dev || !window_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "banded regrid needs the tiled algorithm (algo 1)");
+    if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
+    if (wlo < 0 || whi > p->hpx.npix || wlo > whi) return fail(BFGX_ERR_INVALID, "window out of bounds");
+    if (band0 == band1) return BFGX_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<int64_t> first(p->tiling.nbands + 1);
+    int32_t nb = 0;
+    if (int rc = bfgx_plan_bands(p, &nb, first.data())) return rc;
+    const int64_t p0 = first[band0], p1 = first[band1];
+    if (wlo > p0 || whi < p1) return fail(BFGX_ERR_INVALID, "window [%lld, %lld) does not cover the bands' own pixels [%lld, %lld)",
+                                          (long long)wlo, (long long)whi, (long long)p0, (long long)p1);
+    const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
+    KernelTimer kt(p, BFGX_K_REGRID);
+    const size_t lds = regrid_lds_bytes(p->tiling.BR, p->tiling.W);
+    // virtual bases: the kernel indexes every array by global pixel number
+    double *out_base = window_dev - wlo;
+    if (acc_f64)
+        hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
+                           (const double *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob);
+    else
+        hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
+                           (const float *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob);
+    HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
 
@@ -596,10 +659,10 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
         const size_t lds = regrid_lds_bytes(p->tiling.BR, p->tiling.W);
         if (acc_f64)
             hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev);
+                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob);
         else
             hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev);
+                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
         if (acc_f64)

@@ -365,7 +365,7 @@ __device__ inline bool table_corners(const DevTable &tab, double x0, double x1, 
         const int np0 = (K >= 1) ? tab.n[3] : 1, np1 = (K >= 2) ? tab.n[4] : 1;
         for (int c = 0; c < NC; ++c) {
             const int bz = (c >> (K + 1)) & 1, bm = (c >> K) & 1;
-            const int b0 = (K >= 1) ? ((c >> (K - 1)) & 1) : 0, b1 = (K >= 2) ? (c & 1) : 0;
+            const int b0 = (K >= 1) ? ((c >> (K >= 1 ? K - 1 : 0)) & 1) : 0, b1 = (K >= 2) ? (c & 1) : 0;
             double w = (1.0 * (bz ? tz : 1.0 - tz)) * (bm ? tm : 1.0 - tm);
             if (K >= 1) w *= (b0 ? tp[0] : 1.0 - tp[0]);
             if (K >= 2) w *= (b1 ? tp[1] : 1.0 - tp[1]);
@@ -1184,13 +1184,20 @@ __device__ inline double ring_theta_nolibm(const Hpx &h, int ring)
 template <typename ACC>
 __global__ void __launch_bounds__(256)
 tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
-                   double *__restrict__ map_out)
+                   double *__restrict__ map_out, int tile_off, int64_t wlo, int64_t whi, int32_t *__restrict__ oob_flag)
 {
+    // map_out, offsets and map_in are indexed by GLOBAL pixel number; a rank that owns only a range of bands passes
+    // pointers shifted accordingly and the window [wlo, whi) of map_out that really exists.  A deposit outside the
+    // window (a displacement of more than the window margin) is dropped and flagged, never written.
     extern __shared__ __align__(16) unsigned char smem[];
     const int LR = T.BR + 2 * kApronR, LW = T.W + 2 * kApronK;
     double *acc = reinterpret_cast<double *>(smem);            // [LR][LW]
     RegRow *rows = reinterpret_cast<RegRow *>(acc + LR * LW);  // rings rth0 .. rth0 + LR + 1
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x + tile_off;
+    auto out_add = [&](int64_t p, double v) {
+        if (p >= wlo && p < whi) atomicAdd(map_out + p, v);
+        else atomicOr(oob_flag, 1);
+    };
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
@@ -1230,12 +1237,12 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
             if (dk >= LW - kApronK) dk -= rt.nr;
             if (dk < -kApronK) dk += rt.nr;
             if (dk >= -kApronK && dk < LW - kApronK) { atomicAdd(acc + (ti - 1) * LW + dk + kApronK, v); return; }
-            atomicAdd(map_out + rt.start + k_t, v);            // far target in a window ring (rare)
+            out_add(rt.start + k_t, v);                        // far target in a window ring (rare)
             return;
         }
         int64_t st_t, nr64; bool sh_t;
         ring_info_small(h, ring_t, st_t, nr64, sh_t);
-        atomicAdd(map_out + st_t + k_t, v);                    // far target (rare)
+        out_add(st_t + k_t, v);                                // far target (rare)
     };
 
     // source pixels of the tile, 8 per thread; the loads of pixel i+1 are issued before pixel i is processed
@@ -1373,7 +1380,7 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
                 if (k < 0) k += rt.nr;
                 if (k >= rt.nr) k -= rt.nr;
                 if (k < 0 || k >= rt.nr) { k %= rt.nr; if (k < 0) k += rt.nr; }
-                atomicAdd(map_out + rt.start + k, v);
+                out_add(rt.start + k, v);
             }
         }
     }

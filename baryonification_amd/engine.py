@@ -45,6 +45,20 @@ class ShellPlan(object):
                                                  int(acc_f64), C.c_void_p(int(map_out_ptr)),
                                                  C.c_void_p(int(sums_ptr) or None)))
 
+    def bands(self):
+        """first RING pixel of every band of rings the tiling uses (+ npix): the unit of multi-GPU pixel ownership"""
+        nb = C.c_int32(0)
+        _lib.check(_lib.load().bfgx_plan_bands(self._h, C.byref(nb), None))
+        first = np.zeros(nb.value + 1, dtype=np.int64)
+        _lib.check(_lib.load().bfgx_plan_bands(self._h, C.byref(nb), first.ctypes.data))
+        return first
+
+    def regrid_bands(self, band0, band1, map_in_ptr, offsets_slice_ptr, window_ptr, wlo, whi, acc_f64=False):
+        """K2 for the source pixels of bands [band0, band1) only; window = output pixels [wlo, whi), zeroed by the caller"""
+        _lib.check(_lib.load().bfgx_regrid_bands_device(self._h, int(band0), int(band1), C.c_void_p(int(map_in_ptr)),
+                                                       C.c_void_p(int(offsets_slice_ptr)), int(acc_f64), C.c_void_p(int(window_ptr)),
+                                                       int(wlo), int(whi)))
+
     def paint(self, cat_dev, map_out_ptr, acc_f64=True):
         """K0 + K3 (HealpixRunner.py:418-445)"""
         _lib.check(_lib.load().bfgx_paint_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_out_ptr)), int(acc_f64)))

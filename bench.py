@@ -49,6 +49,9 @@ def parse():
     ap.add_argument('--table', choices=['closed-form', 's19'], default='closed-form',
                     help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
                          "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
+    ap.add_argument('--exchange', choices=['slices', 'reduce'], default='slices',
+                    help="N > 1: 'slices' = all_to_all reduce-scatter by pixel slices + banded regrid + windows to rank 0 (default); "
+                         "'reduce' = one reduce(sum) of the whole accumulator to rank 0")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample (single-thread baseline)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (0 = all available cores, at most 16)')
@@ -258,10 +261,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (got WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (libbfgx has no CPU fallback)"
+    # BFGX_DIST_BACKEND=gloo: functional rehearsal of the N > 1 path on a one-GPU box (all ranks share device 0 and the
+    # collectives are staged through the host); timings of such a run mean nothing
+    backend = os.environ.get('BFGX_DIST_BACKEND', 'nccl')
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     nside, npix = args.nside, 12 * args.nside ** 2
     cat = syn.make_catalog(args.halos, seed=syn.SEED_CATALOG + rank)
@@ -286,6 +293,7 @@ def main():
     d_off = torch.zeros(npix * 3, dtype=acc_dtype, device=dev)
     d_out = torch.zeros(npix, dtype=torch.float64, device=dev)
     d_sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    d_fin = torch.zeros(npix if (world > 1 and rank == 0) else 0, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     plan = engine.ShellPlan(model, keep, nside, args.halos, device=local_rank, stream=stream)
     cat_dev = _lib.make_catalog_dev(args.halos, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
@@ -293,11 +301,31 @@ def main():
     n_pairs = plan.count_pairs(cat_dev, fallback4=not paint)
     plan.status()
 
+    # N > 1: slice exchange (utils/Parallelize.py): all_to_all reduce-scatter of the accumulator by pixel slices, every rank
+    # regrids the bands it owns, windows travel to rank 0.  --exchange reduce keeps the single reduce(sum) to rank 0.
+    slices = world > 1 and args.exchange == 'slices' and args.algo == 1
+    if slices:
+        from baryonification_amd.utils.Parallelize import band_partition, gather_windows, sliced_reduce, window_margin
+        first = plan.bands()
+        cuts = band_partition(first, world)
+        pb = first[cuts]
+        margin = 0 if paint else window_margin(nside)
+        wins = [(max(0, int(pb[j]) - margin), min(npix, int(pb[j + 1]) + margin)) for j in range(world)]
+        width = 1 if paint else 3
+        my_len = int(pb[rank + 1] - pb[rank])
+        x_recv = torch.empty(world * my_len * width, dtype=torch.float64 if paint else acc_dtype, device=dev)
+        d_win = torch.zeros(wins[rank][1] - wins[rank][0], dtype=torch.float64, device=dev)
+        w_recv = torch.empty(sum(hi - lo for lo, hi in wins) if rank == 0 else 0, dtype=torch.float64, device=dev)
+        map_sum = float(d_map.sum().item())
+
     def step_paint():
         if args.algo == 0:
             d_out.zero_()
         plan.paint(cat_dev, d_out.data_ptr(), acc_f64=True)
-        if world > 1:
+        if slices:
+            mine = sliced_reduce(d_out, pb, 1, recv=x_recv)
+            gather_windows(mine, wins, npix, recv=w_recv, out=d_fin)
+        elif world > 1:
             dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318
 
     def step():
@@ -305,9 +333,20 @@ def main():
             return step_paint()
         if args.algo == 0:
             d_off.zero_()                      # algo 1 stores every element of pix_offsets exactly once
-        d_out.zero_(); d_sums.zero_()
         plan.offsets(cat_dev, d_off.data_ptr(), acc_f64=args.acc_f64)
+        if slices:
+            my_off = sliced_reduce(d_off, pb, 3, recv=x_recv)
+            d_win.zero_()
+            plan.regrid_bands(int(cuts[rank]), int(cuts[rank + 1]), d_map.data_ptr(), my_off.data_ptr(), d_win.data_ptr(),
+                              wins[rank][0], wins[rank][1], acc_f64=args.acc_f64)
+            full = gather_windows(d_win, wins, npix, recv=w_recv, out=d_fin)
+            if rank == 0:
+                d_sums[0] = map_sum
+                d_sums[1] = full.sum()
+            return
+        d_out.zero_(); d_sums.zero_()
         if world > 1:
+            assert backend == 'nccl', "--exchange reduce needs RCCL"
             dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318 counterpart, before the regrid
         if rank == 0:
             plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=args.acc_f64)
@@ -328,8 +367,9 @@ def main():
     elapsed = time.perf_counter() - t0
     kt = plan.timing_read()
     plan.timing_enable(False)
+    plan.status()                              # entry-list capacity, no regrid deposit outside a window
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -369,7 +409,9 @@ def main():
                                        "profile" if paint else "displacement"),
                        "halos_per_gpu": args.halos, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
-                       "parallelism": "halo shards x%d + RCCL reduce(pix_offsets)->rank0 regrid" % world if world > 1 else "single GPU"},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "halo shards x%d + RCCL all_to_all reduce-scatter by pixel slices, banded regrid on every rank, windows -> rank 0" % world
+                                       if slices else "halo shards x%d + RCCL reduce(accumulator) -> rank 0" % world)},
             "map_pixels_per_s": npix / elapsed * args.steps,
             "kernel_ms": kernels,
             "mass_conserved": None if paint else bool(np.isclose(sums[1], sums[0])),

@@ -149,6 +149,16 @@ int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offset
  * sums_dev (optional, double[2], zeroed by caller) receives {sum(map_in), sum(map_out)} */
 int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
                         double *map_out_dev, double *sums_dev);
+/* Multi-GPU form of K2: the sphere is cut into bands of consecutive rings (contiguous RING pixel ranges); a rank that
+ * owns bands [band0, band1) regrids only their source pixels.  bfgx_plan_bands returns the number of bands and, in
+ * band_first_pixel[nbands + 1] (may be NULL), the first pixel of every band (+ npix).  offsets_slice_dev holds the
+ * summed pix_offsets of the owned pixels only ([p1 - p0][3], p0 = band_first_pixel[band0]); window_dev holds the
+ * output pixels [wlo, whi) (zeroed by the caller), a superset of [p0, p1) widened by a margin of a few rings for the
+ * deposits that cross the band boundary; map_in_dev is the full map.  A deposit outside the window is dropped and
+ * reported by the next bfgx_plan_status (never happens for sub-pixel displacements). */
+int  bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel);
+int  bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev,
+                              const void *offsets_slice_dev, int acc_f64, double *window_dev, int64_t wlo, int64_t whi);
 /* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */
 int  bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *map_out_dev, int acc_f64);
 /* optional per-kernel timing with HIP events recorded on the plan's stream around every launch.

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Functional rehearsal of the N > 1 product path on a ONE-GPU box: every rank uses device 0, the process group is
+gloo and utils/Parallelize stages its two all_to_all steps through the host.  Checks that
+distributed_process(runner, ...) with the HIP engine (halo shards -> sliced reduce-scatter -> banded regrid -> windows to
+rank 0) returns what a single-process runner.process() returns.  Launch:
+
+    GLOO_SOCKET_IFNAME=lo python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29577 scripts/rehearse_multi_gpu.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    from baryonification_amd.utils.Parallelize import distributed_process
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')        # the box's hostname may not resolve
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    ok = True
+    for kind, nside, nh in (('baryonify', 256, 60_000), ('paint', 128, 20_000)):
+        cat = syn.make_catalog(nh)
+        z, M, r = syn.table_grid(cat)
+        cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+        Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+        if kind == 'baryonify':
+            Shell = bfg.utils.LightconeShell(map=syn.make_map(nside), cosmo=syn.COSMO)
+            model = bfg.Profiles.Baryonification2D(None, None, cosmo, epsilon_max=10.0)
+            model.set_table(z, M, r, syn.displacement_table(z, M, r))
+            runner = bfg.Runners.BaryonifyShell(Catalog, Shell, 10.0, model, verbose=False)
+        else:
+            Shell = bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=syn.COSMO)
+            model = bfg.utils.TabulatedProfile(None, cosmo)
+            model.set_table(z, M, r, syn.paint_table(z, M, r))
+            runner = bfg.Runners.PaintProfilesShell(Catalog, Shell, 10.0, model, verbose=False)
+        out = distributed_process(runner, kind, device=0, exchange='slices')
+        if rank == 0:
+            ref = runner.process()
+            tol = 1e-6 * ref.mean() if kind == 'baryonify' else 1e-10 * np.abs(ref).max()     # f32 pix_offsets / f64 painting
+            err = np.abs(out - ref).max()
+            print("rehearsal %-9s world=%d nside=%d halos=%d  max|distributed - single| = %.3e (tol %.1e)  %s" % (
+                kind, world, nside, nh, err, tol, 'OK' if err <= tol else 'FAIL'), flush=True)
+            ok = ok and err <= tol
+        else:
+            assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()

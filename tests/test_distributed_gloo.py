@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from baryonification_amd.utils.Parallelize import distributed_process, shard_slices, shuffled_order
+from baryonification_amd.utils.Parallelize import band_partition, distributed_process, shard_slices, shuffled_order
 from helpers import load_golden, oracle_run, product_runner
 
 
@@ -35,7 +35,42 @@ def _oracle_regrid(runner, ctx, acc, device):
     return O.regrid(g['nside'], g['map_in'], acc.numpy().reshape(-1, 3))
 
 
-def _worker(rank, world, port, name, out_path):
+def _ring_bands(nside, BR=8):
+    """first RING pixel of bands of BR rings (what ShellPlan.bands() reports for the HIP tiling)"""
+    first = []
+    for ring in list(range(1, 4 * nside, BR)):
+        if ring < nside:
+            first.append(2 * ring * (ring - 1))
+        elif ring < 3 * nside:
+            first.append(2 * nside * (nside - 1) + (ring - nside) * 4 * nside)
+        else:
+            q = 4 * nside - ring
+            first.append(12 * nside * nside - 2 * q * (q + 1))
+    return np.array(first + [12 * nside * nside], dtype=np.int64)
+
+
+def _oracle_bounds(runner, ctx, world):
+    first = _ring_bands(runner._golden['nside'])
+    cuts = band_partition(first, world)
+    return cuts, first[cuts]
+
+
+def _oracle_regrid_slice(runner, ctx, my_off, b0, b1, wlo, whi, device):
+    """regrid of the source pixels of this rank's slice only (oracle bfgo_regrid_range), returned as the window"""
+    from oracle import oracle as O
+    g = runner._golden
+    first = _ring_bands(g['nside'])
+    p0, p1 = int(first[b0]), int(first[b1])
+    npix = 12 * g['nside'] ** 2
+    off = np.zeros((npix, 3))
+    off[p0:p1] = my_off.numpy().reshape(-1, 3)
+    new_map = np.zeros(npix)
+    O.lib().bfgo_regrid_range(g['nside'], p0, p1, O._ptr(O._f8(g['map_in'])), O._ptr(off), O._ptr(new_map))
+    assert new_map[:wlo].sum() == 0 and new_map[whi:].sum() == 0         # deposits stay inside the window
+    return torch.from_numpy(new_map[wlo:whi].copy())
+
+
+def _worker(rank, world, port, name, out_path, exchange='slices'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -44,7 +79,8 @@ def _worker(rank, world, port, name, out_path):
         runner = product_runner(g)
         runner._golden = g
         kind = 'baryonify' if g['kind'] == 'baryonify' else 'paint'
-        out = distributed_process(runner, kind, seed=42, device=rank, compute=_oracle_compute, regrid=_oracle_regrid)
+        out = distributed_process(runner, kind, seed=42, device=rank, compute=_oracle_compute, regrid=_oracle_regrid, exchange=exchange,
+                                  bounds=_oracle_bounds, regrid_slice=_oracle_regrid_slice)
         if rank == 0:
             np.save(out_path, out)
         else:
@@ -65,13 +101,23 @@ def test_shard_slices_cover_catalog_like_reference():
     assert np.array_equal(o, np.random.default_rng(42).choice(100, size=100, replace=False))
 
 
+def test_band_partition_balances_pixels():
+    for nside, world in ((64, 2), (64, 3), (128, 8), (16, 5)):
+        first = _ring_bands(nside)
+        cuts = band_partition(first, world)
+        assert cuts[0] == 0 and cuts[-1] == first.size - 1 and np.all(np.diff(cuts) >= 0) and cuts.size == world + 1
+        share = np.diff(first[cuts]) / first[-1]
+        assert abs(share.sum() - 1) < 1e-15 and np.all(np.abs(share - 1 / world) < 0.35 / world + 8 * 4 * nside / first[-1])
+
+
+@pytest.mark.parametrize('world,exchange', [(2, 'slices'), (3, 'slices'), (2, 'reduce')])
 @pytest.mark.parametrize('name', ['lowz_baryonify', 'lowz_paint'])
-def test_two_rank_gloo_equals_single_process(tmp_path, name):
+def test_multi_rank_gloo_equals_single_process(tmp_path, name, world, exchange):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     out_path = str(tmp_path / 'out.npy')
-    mp.spawn(_worker, args=(2, port, name, out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, name, out_path, exchange), nprocs=world, join=True)
     out = np.load(out_path)
     ref = oracle_run(load_golden(name))
     # summation order differs (shuffle + two partial sums): float64 round-off only

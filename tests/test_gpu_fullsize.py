@@ -120,3 +120,49 @@ def test_config3_paint_full_size_properties(gpu):
     got = paint(cdS, 1).cpu().numpy()
     assert np.abs(got - ora).max() <= 1e-10 * np.abs(ora).max()
     plan.close()
+
+
+def test_banded_regrid_equals_full_regrid(gpu):
+    """multi-GPU building block on one GPU: regridding the source pixels band range by band range into windows and
+    adding the windows reproduces the full-map regrid (what N ranks + gather_windows do)"""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    from baryonification_amd.utils.Parallelize import band_partition, window_margin
+    nside, nh = 256, 60_000
+    npix = 12 * nside * nside
+    cat = syn.make_catalog(nh)
+    z, M, r = syn.table_grid(cat)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
+    dev = torch.device('cuda:0')
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}
+    plan = engine.ShellPlan(model, keep, nside, nh, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    cd = _lib.make_catalog_dev(nh, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
+    off = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    plan.offsets(cd, off.data_ptr(), acc_f64=False)
+    hmap = torch.from_numpy(syn.make_map(nside)).to(dev)
+    full = torch.zeros(npix, dtype=torch.float64, device=dev)
+    plan.regrid(hmap.data_ptr(), off.data_ptr(), full.data_ptr(), 0, acc_f64=False)
+    first = plan.bands()
+    assert first[0] == 0 and first[-1] == npix and np.all(np.diff(first) > 0)
+    for world in (2, 5):
+        cuts = band_partition(first, world)
+        pb = first[cuts]
+        m = window_margin(nside)
+        acc = torch.zeros(npix, dtype=torch.float64, device=dev)
+        for rk in range(world):
+            p0, p1 = int(pb[rk]), int(pb[rk + 1])
+            wlo, whi = max(0, p0 - m), min(npix, p1 + m)
+            my_off = off[3 * p0:3 * p1].clone()                     # what sliced_reduce hands to rank rk
+            win = torch.zeros(whi - wlo, dtype=torch.float64, device=dev)
+            plan.regrid_bands(int(cuts[rk]), int(cuts[rk + 1]), hmap.data_ptr(), my_off.data_ptr(), win.data_ptr(), wlo, whi)
+            acc[wlo:whi] += win
+        plan.status()                                              # no deposit fell outside a window
+        torch.cuda.synchronize()
+        assert (acc - full).abs().max().item() <= 1e-12 * full.abs().max().item()
+    # a window without margin must be reported, not silently corrupt memory
+    p0, p1 = int(pb[1]), int(pb[2])
+    win = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
+    plan.regrid_bands(int(cuts[1]), int(cuts[2]), hmap.data_ptr(), off[3 * p0:3 * p1].clone().data_ptr(), win.data_ptr(), p0, p1)
+    with pytest.raises(ValueError, match='window'):
+        plan.status()
+    plan.close()
