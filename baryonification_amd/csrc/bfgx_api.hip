@@ -179,6 +179,10 @@ static int upload_model(std::vector<void *> &owned, hipStream_t stream, const bf
         const void *dv = nullptr;
         if (int rc = owned_upload(owned, stream, src, sizeof(double) * nvals, &dv)) return rc;
         m.tab.values = (const double *)dv;
+        std::vector<float> v32(nvals);                 // fp32 copy for the mixed-precision pair path (pair_value_fast32)
+        for (size_t q = 0; q < nvals; ++q) v32[q] = (float)src[q];
+        if (int rc = owned_upload(owned, stream, v32.data(), sizeof(float) * nvals, &dv)) return rc;
+        m.tab.values32 = (const float *)dv;
         HIP_TRY(hipStreamSynchronize(stream));
         NC = 4 << (t.ndim - 3);
     }

@@ -17,6 +17,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef BFGX_PAIR32
+#define BFGX_PAIR32 1      // 1: fp32 pair tail when pix_offsets are stored as fp32 (pair_value_fast32)
+#endif
 #ifndef BFGX_ABLATE
 #define BFGX_ABLATE 0      // >0: timing-only ablation builds (scripts/ablate.sh); never shipped
 #endif
@@ -251,6 +254,7 @@ struct DevTable {
     int32_t n[BFGX_MAX_DIM];
     const double *axis[BFGX_MAX_DIM];     // device pointers
     const double *values;                 // device pointer
+    const float *values32;                // fp32 copy of the values (same layout) for the mixed-precision pair path
     int32_t rdelta, logv;
     double eps_model;
     int32_t r_uniform;                    // ln r axis is uniform: index guess = (x - r0) * inv_dr
@@ -260,6 +264,7 @@ struct DevTable {
 // what the per-pair read-out needs of the table (kept small: it travels in scalar registers)
 struct PairTable {
     const double *values, *raxis;         // table values (r innermost) and the ln r axis
+    const float *values32;
     double r0, inv_dr, r1;
     int32_t nr, r_uniform, rdelta, _pad;
 };
@@ -267,7 +272,7 @@ struct PairTable {
 __host__ __device__ inline PairTable make_pair_table(const DevTable &t)
 {
     PairTable p;
-    p.values = t.values; p.raxis = t.axis[2];
+    p.values = t.values; p.raxis = t.axis[2]; p.values32 = t.values32;
     p.r0 = t.r0; p.inv_dr = t.inv_dr; p.r1 = t.r1;
     p.nr = t.n[2]; p.r_uniform = t.r_uniform; p.rdelta = t.rdelta; p._pad = 0;
     return p;
@@ -794,6 +799,54 @@ __device__ inline int wave_scan_incl(int v, int lane)
     return v;
 }
 
+// Mixed-precision form of pair_value_fast for MODE_OFFSETS with fp32 pix_offsets output.  The chord -- a difference of
+// nearly equal unit vectors -- and the r < rcut decision stay fp64; everything downstream of r^2 runs in fp32: 1/r and
+// ln r from the hardware v_rsq_f32 / v_log_f32, the table read-out from an fp32 copy of the table, and the renormalised
+// offset as a series in eps = offset / D,
+//     (v + eps) / |v + eps| - v = eps + g (v + eps),   g = -t/2 + 3 t^2/8 - 5 t^3/16,   t = 2 v.eps + eps.eps   (|v| = 1),
+// which has no cancellation left.  Relative error of an offset ~3e-7 (|offset| ~ 1e-5 rad, so ~1e-12 rad absolute): far
+// inside the fp32 storage of pix_offsets and the stated 1e-6 mean(map) bound of the default BaryonifyShell path.
+template <int NC>
+__device__ inline bool pair_value_fast32(const PairTable &tab, const PairHaloT<NC> &r, double z, double sth, double x, double v[3])
+{
+    double sd, cd;
+    sincos_small(x, sd, cd);
+    const double vx = sth * cd, vy = sth * sd;
+    const double dx = r.D * (vx - r.s0), dy = r.D * vy, dz = r.D * (z - r.z0);      // :314-316
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double rc = r.rcut * r.a;                                                 // r_sep / a < rcut  (:321, BaryonCorrection.py:381)
+    bool ok = (r2 > 0.0) && !r.oob && (r2 < rc * rc);
+    const float r2f = (float)((r2 > 0.0) ? r2 : 1.0);
+    float inv_r = __builtin_amdgcn_rsqf(r2f);
+    inv_r = inv_r * __builtin_fmaf(-0.5f * r2f * inv_r, inv_r, 1.5f);               // one Newton step
+    const float lx = __builtin_fmaf(0.34657359027997264f, __builtin_amdgcn_logf(r2f), (float)r.lnoff);   // 0.5 ln 2 * log2(r^2)
+    const float r0f = (float)tab.r0;
+    ok = ok && (lx >= r0f) && (lx <= (float)tab.r1);                                // RGI fill_value = nan
+    const float u = (lx - r0f) * (float)tab.inv_dr;
+    const int i = max(0, min((int)u, tab.nr - 2));
+    const float tr = u - (float)i, t0 = 1.0f - tr;
+    float d = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float *row = tab.values32 + r.rowoff[c] + i;
+        const float w = (float)r.w[c];
+        d = __builtin_fmaf(row[0], w * t0, d);
+        d = __builtin_fmaf(row[1], w * tr, d);
+    }
+    ok = ok && isfinite(d) && d != 0.0f;                                            // :323
+    const float sc = d * (float)r.a * inv_r * __builtin_amdgcn_rcpf((float)r.D);    // offset / D = d a diff / (r D)
+    const float ex0 = sc * (float)dx, ey0 = sc * (float)dy, ez0 = sc * (float)dz;
+    const float fx = (float)vx, fy = (float)vy, fz = (float)z;
+    const float t = 2.0f * (fx * ex0 + fy * ey0 + fz * ez0) + (ex0 * ex0 + ey0 * ey0 + ez0 * ez0);
+    const float g = t * __builtin_fmaf(t, __builtin_fmaf(t, -0.3125f, 0.375f), -0.5f);
+    const float ex = __builtin_fmaf(g, fx + ex0, ex0), ey = __builtin_fmaf(g, fy + ey0, ey0), ez = __builtin_fmaf(g, fz + ez0, ez0);   // :326-328
+    const float cp = (float)r.cph0, sp = (float)r.sph0;
+    v[0] = (double)(ex * cp - ey * sp);                                             // rotate back by +phi0
+    v[1] = (double)(ex * sp + ey * cp);
+    v[2] = (double)ez;
+    return ok;
+}
+
 template <int MODE, typename ACC>
 __global__ void __launch_bounds__(kWave * kWavesPerBlock)
 halo_scatter_kernel(PairTable pt, Hpx h, int64_t nhalo, const HaloRec *__restrict__ recs,
@@ -1055,8 +1108,13 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                     if (true) { okA = okB = true; vA[0] = vA[1] = vA[2] = xA; vB[0] = vB[1] = vB[2] = xB; } else
 #endif
                     if (fastok && __all(small)) {
-                        okA = pair_value_fast<MODE, NC>(pt, hA, L.z[rowA], L.sth[rowA], xA, vA);
-                        okB = pair_value_fast<MODE, NC>(pt, hB, L.z[rowB], L.sth[rowB], xB, vB);
+                        if (MODE == MODE_OFFSETS && sizeof(ACC) == 4 && BFGX_PAIR32) {
+                            okA = pair_value_fast32<NC>(pt, hA, L.z[rowA], L.sth[rowA], xA, vA);
+                            okB = pair_value_fast32<NC>(pt, hB, L.z[rowB], L.sth[rowB], xB, vB);
+                        } else {
+                            okA = pair_value_fast<MODE, NC>(pt, hA, L.z[rowA], L.sth[rowA], xA, vA);
+                            okB = pair_value_fast<MODE, NC>(pt, hB, L.z[rowB], L.sth[rowB], xB, vB);
+                        }
                     } else {
                         // generic path (non-uniform ln r axis or a wide azimuth span): one pair per pass of a
                         // deliberately rolled loop so that its code and registers exist only once
