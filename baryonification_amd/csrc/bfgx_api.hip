@@ -92,6 +92,7 @@ struct bfgx_plan {
             *overflow = nullptr;
     TileRef *tref = nullptr;
     unsigned long long *pair_total = nullptr;
+    double *tile_sums = nullptr;     // [ntiles][2] per-tile {sum of source values, sum of deposits} of the tiled regrid
     int32_t *regrid_oob = nullptr;   // set when a banded regrid dropped a deposit outside its output window
     std::vector<int32_t> band_tile0_host;   // first tile of every band (+ total)
     int64_t capacity = 0;
@@ -493,6 +494,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         void *d7 = nullptr;
         if (dalloc(sizeof(int32_t), &d7)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(flag) failed"));
         p->regrid_oob = (int32_t *)d7;
+        void *d8 = nullptr;
+        if (dalloc(sizeof(double) * 2 * (size_t)(T.ntiles + 1), &d8)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(tile sums) failed"));
+        p->tile_sums = (double *)d8;
         if (hipMemsetAsync(p->regrid_oob, 0, sizeof(int32_t), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
         if (hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream) != hipSuccess)
             return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
@@ -608,10 +612,10 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
     double *out_base = window_dev - wlo;
     if (acc_f64)
         hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
-                           (const double *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob);
+                           (const double *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob, (double *)nullptr);
     else
         hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
-                           (const float *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob);
+                           (const float *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob, (double *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -663,10 +667,10 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
         const size_t lds = regrid_lds_bytes(p->tiling.BR, p->tiling.W);
         if (acc_f64)
             hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob);
+                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob, sums_dev ? p->tile_sums : nullptr);
         else
             hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob);
+                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob, sums_dev ? p->tile_sums : nullptr);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
         if (acc_f64)
@@ -680,8 +684,11 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
     HIP_TRY(hipGetLastError());
     if (sums_dev) {
         KernelTimer kt(p, BFGX_K_SUM);
-        hipLaunchKernelGGL(sum2_kernel, dim3(1024), dim3(256), 0, p->stream, p->hpx.npix, map_in_dev,
-                           (const double *)map_out_dev, sums_dev);
+        if (p->algo == 1)       // the tiled regrid left per-tile {sum of source values, sum of deposits}: no second pass over the maps
+            hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(256), 0, p->stream, p->tiling.ntiles, (const double *)p->tile_sums, sums_dev);
+        else
+            hipLaunchKernelGGL(sum2_kernel, dim3(1024), dim3(256), 0, p->stream, p->hpx.npix, map_in_dev,
+                               (const double *)map_out_dev, sums_dev);
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;

@@ -1242,7 +1242,8 @@ __device__ inline double ring_theta_nolibm(const Hpx &h, int ring)
 template <typename ACC>
 __global__ void __launch_bounds__(256)
 tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
-                   double *__restrict__ map_out, int tile_off, int64_t wlo, int64_t whi, int32_t *__restrict__ oob_flag)
+                   double *__restrict__ map_out, int tile_off, int64_t wlo, int64_t whi, int32_t *__restrict__ oob_flag,
+                   double *__restrict__ tile_sums)
 {
     // map_out, offsets and map_in are indexed by GLOBAL pixel number; a rank that owns only a range of bands passes
     // pointers shifted accordingly and the window [wlo, whi) of map_out that really exists.  A deposit outside the
@@ -1252,8 +1253,11 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     double *acc = reinterpret_cast<double *>(smem);            // [LR][LW]
     RegRow *rows = reinterpret_cast<RegRow *>(acc + LR * LW);  // rings rth0 .. rth0 + LR + 1
     const int tile = blockIdx.x + tile_off;
+    // optional mass-conservation sums (HealpixRunner.py:344-345) without another pass over the maps: every thread adds up
+    // the source values it read and the values it deposited; per-tile totals go to tile_sums[2 tile + {0, 1}]
+    double sum_in = 0.0, sum_out = 0.0;
     auto out_add = [&](int64_t p, double v) {
-        if (p >= wlo && p < whi) atomicAdd(map_out + p, v);
+        if (p >= wlo && p < whi) { atomicAdd(map_out + p, v); sum_out += v; }
         else atomicOr(oob_flag, 1);
     };
     const int band = T.tile_band[tile];
@@ -1329,6 +1333,7 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     for (int idx = tid; idx < T.BR * T.W; idx += 256) {
         const Src cur = nxt;
         nxt = fetch(idx + 256);
+        if (cur.ok) sum_in += cur.val;
         if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
         const RegRow &rw = rows[cur.ti];
         const double val = cur.val;
@@ -1441,6 +1446,37 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
                 out_add(rt.start + k, v);
             }
         }
+    }
+    if (tile_sums) {
+        __syncthreads();                                   // acc is free again: reuse its first words for the block reduction
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) { sum_in += __shfl_down(sum_in, sft, kWave); sum_out += __shfl_down(sum_out, sft, kWave); }
+        if (lane == 0) { acc[2 * wid] = sum_in; acc[2 * wid + 1] = sum_out; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < 256 / kWave; ++w) { a += acc[2 * w]; b += acc[2 * w + 1]; }
+            tile_sums[2 * (int64_t)tile] = a; tile_sums[2 * (int64_t)tile + 1] = b;
+        }
+    }
+}
+
+// sums[0] += sum of tile_sums[2 t], sums[1] += sum of tile_sums[2 t + 1]   (one workgroup)
+__global__ void __launch_bounds__(256)
+sum_tiles_kernel(int ntiles, const double *__restrict__ tile_sums, double *__restrict__ sums)
+{
+    __shared__ double sa[256 / kWave], sb[256 / kWave];
+    double xa = 0.0, xb = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) { xa += tile_sums[2 * t]; xb += tile_sums[2 * t + 1]; }
+#pragma unroll
+    for (int s = kWave >> 1; s > 0; s >>= 1) { xa += __shfl_down(xa, s, kWave); xb += __shfl_down(xb, s, kWave); }
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) { sa[wid] = xa; sb[wid] = xb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; }
+        sums[0] += ta; sums[1] += tb;
     }
 }
 
