@@ -483,8 +483,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     const double theta = kHalfPi - dec[j] * kDeg2Rad;
     const double phi = ra[j] * kDeg2Rad;
     double st, ct, sp, cp;
-    sincos(theta, &st, &ct);
-    sincos(phi, &sp, &cp);
+    sincos_bounded(theta, st, ct);                                        // libm-free (bfgx_math.hpp): K0 is latency-bound
+    sincos_bounded(phi, sp, cp);
     const double thq = theta;
     double phq = phi - kTwoPi * floor(phi * kInvTwoPi);
     if (phq >= kTwoPi) phq -= kTwoPi;
@@ -511,7 +511,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         pole = true;
     } else {
         double cr_;
-        sincos(radius, &sr_, &cr_);
+        sincos_bounded(radius, sr_, cr_);
         r.cosr = cr_;
         const double rlat1 = thq - radius;
         const double rlat2 = thq + radius;
@@ -537,8 +537,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     const double Rmod = (m.same_model ? R : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
     r.rcut = m.tab.eps_model * Rmod;
     r.inv_a = 1.0 / a;
-    const double x0 = log(1.0 / a), x1 = log(M_j);
-    r.lnoff = m.tab.rdelta ? (x0 - log(Rmod)) : x0;
+    const double x0 = fast_log(1.0 / a), x1 = fast_log(M_j);
+    r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
     double wv[NC];
     int32_t ro[NC];
     const bool oob = table_corners<NC>(m.tab, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
