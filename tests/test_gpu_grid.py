@@ -208,3 +208,31 @@ def test_grid_plan_resident_path(gpu):
     s = sums.cpu().numpy()
     assert np.isclose(s[0], c['map'].sum()) and np.isclose(s[1], s[0], rtol=1e-12)
     plan.close()
+
+
+def test_grid_edge_cases(gpu):
+    """empty catalog, a single halo whose cutout is clipped to half the box, an all-zero map"""
+    import baryonification_amd as bfg
+    from oracle import grid as G
+    from oracle import oracle as O
+    c = _big_case(3, 32, 4, 11)
+    cos = c['cosmo']
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(cos), epsilon_max=50.0)
+    model.set_table(c['z'], c['Mt'], c['r'], c['d'])
+    prof = bfg.utils.TabulatedProfile(None, bfg.utils.Cosmology.from_dict(cos))
+    prof.set_table(c['z'], c['Mt'], c['r'], c['P'])
+    GMap = bfg.utils.GriddedMap(map=c['map'], redshift=c['redshift'], bins=c['bins'], cosmo=cos)
+    none = bfg.utils.HaloNDCatalog(x=np.zeros(0), y=np.zeros(0), z=np.zeros(0), M=np.zeros(0), redshift=c['redshift'], cosmo=cos)
+    out = bfg.Runners.BaryonifyGrid(none, GMap, 5.0, model, verbose=False).process()
+    assert np.array_equal(out, c['map'])                                  # zero offsets: every pixel deposits into itself
+    assert np.all(bfg.Runners.PaintProfilesGrid(none, GMap, 5.0, prof, verbose=False).process() == 0)
+    # one cluster with epsilon_max = 40: R_q is clipped to max(bins)/2 and the cutout spans (almost) the whole box
+    one = bfg.utils.HaloNDCatalog(x=np.array([31.0]), y=np.array([3.0]), z=np.array([60.0]), M=np.array([9e14]), redshift=c['redshift'], cosmo=cos)
+    used = {k: np.array(one.cat[k], dtype=np.float64) for k in ('M', 'x', 'y', 'z')}
+    r1 = bfg.Runners.BaryonifyGrid(one, GMap, 40.0, model, verbose=False)
+    out = r1.process()
+    tab = O.Table([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], c['d'], False, 50.0)
+    ora = G.baryonify_grid(c['map'], c['bins'], used, c['redshift'], tab, 40.0, G.grid_background(cos))
+    assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max() and r1.last_stats['n_pairs'] > 20000
+    zero = bfg.utils.GriddedMap(map=np.zeros((32,) * 3), redshift=c['redshift'], bins=c['bins'], cosmo=cos)
+    assert np.all(bfg.Runners.BaryonifyGrid(one, zero, 40.0, model, verbose=False).process() == 0)

@@ -104,3 +104,17 @@ def test_snapshot_device_resident_and_errors(gpu):
     g2 = dict(g, part=bad)
     with pytest.raises(ValueError):
         H.snapshot_product_runner(g2).process()
+
+
+def test_snapshot_edge_cases(gpu):
+    """no halos: particles come back unchanged; no particles: an empty catalog comes back"""
+    import baryonification_amd as bfg
+    g = H.load_snapshot_golden('snap2d_baryonify')
+    runner = H.snapshot_product_runner(g)
+    cos = g['cosmo_runner']
+    runner.HaloNDCatalog = bfg.utils.HaloNDCatalog(x=np.zeros(0), y=np.zeros(0), M=np.zeros(0), redshift=g['redshift'], cosmo=cos)
+    out = runner.process()
+    assert np.array_equal(out['x'], g['part'][:, 0]) and np.array_equal(out['y'], g['part'][:, 1])
+    runner2 = H.snapshot_product_runner(g)
+    runner2.ParticleSnapshot = bfg.utils.ParticleSnapshot(x=np.zeros(0), y=np.zeros(0), z=None, M=np.zeros(0), L=g['L'], redshift=g['redshift'], cosmo=cos)
+    assert runner2.process().size == 0
