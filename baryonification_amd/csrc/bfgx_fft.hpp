@@ -3,8 +3,9 @@
 //
 // The map is real, so only the kz <= N/2 half of the spectrum is computed (r2c along the contiguous axis, then two
 // in-place c2c passes along the strided axes); the mirrored half enters the bin sums through a weight of 2.
-// Every 1-D transform runs in LDS: radix-2 decimation in time, bit-reversed on the way in, log2(N) butterfly stages
-// with a barrier each, twiddles from a host-built fp64 table.  The strided passes move tiles of kFftTile lines that
+// Every 1-D transform runs in LDS: decimation in time, bit-reversed on the way in, two radix-2 stages fused per
+// barrier (radix-4 data movement), twiddles from a host-built fp64 table; the r2c pass packs two real lines into one
+// complex transform.  The strided passes move tiles of kFftTile lines that
 // are adjacent in memory, so that global accesses stay contiguous (kFftTile * 16 B) and LDS accesses conflict-free
 // (line index fastest).  N must be a power of two, 8 <= N <= 1024.
 #pragma once
@@ -19,39 +20,70 @@ constexpr int kFftTile = 8;           // lines per workgroup in the strided pass
 
 __device__ inline int bit_reverse(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
 
-// in-place radix-2 butterflies over `nl` interleaved lines held in LDS as buf[i * nl + l]
+__device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// in-place decimation-in-time butterflies over `nl` interleaved lines held in LDS as buf[i * nl + l] (input already in
+// bit-reversed order).  Two radix-2 stages (half sizes m and 2m) are fused per barrier: a thread takes the four elements
+// p, p+m, p+2m, p+3m of a 4m-block, so every element crosses LDS once per TWO stages; a last single stage follows when
+// log2(N) is odd.  tw[k] = exp(-2 pi i k / N), k < N/2.
 __device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2 *__restrict__ tw)
 {
-    const int nb = (N >> 1) * nl;
-    for (int m = 1; m < N; m <<= 1) {
+    int m = 1;
+    const int nq = (N >> 2) * nl;
+    for (; 4 * m <= N; m <<= 2) {
         __syncthreads();
+        const int ts1 = (N >> 1) / m, ts2 = (N >> 2) / m;           // twiddle strides of the stages m and 2m
+        for (int t = threadIdx.x; t < nq; t += kFftBlock) {
+            const int l = t % nl, b = t / nl;                       // b: butterfly quad index
+            const int pos = b & (m - 1);
+            const int p = ((b - pos) << 2) + pos;
+            const double2 w1 = tw[pos * ts1], w2 = tw[pos * ts2];
+            const double2 w3 = make_double2(w2.y, -w2.x);           // W_4m^(pos + m) = -i W_4m^pos
+            double2 a0 = buf[p * nl + l], a1 = buf[(p + m) * nl + l], a2 = buf[(p + 2 * m) * nl + l], a3 = buf[(p + 3 * m) * nl + l];
+            const double2 t1 = cmul(w1, a1), t3 = cmul(w1, a3);     // stage m: (a0, a1) and (a2, a3)
+            const double2 b0 = make_double2(a0.x + t1.x, a0.y + t1.y), b1 = make_double2(a0.x - t1.x, a0.y - t1.y);
+            const double2 b2 = make_double2(a2.x + t3.x, a2.y + t3.y), b3 = make_double2(a2.x - t3.x, a2.y - t3.y);
+            const double2 u2 = cmul(w2, b2), u3 = cmul(w3, b3);     // stage 2m: (b0, b2) and (b1, b3)
+            buf[p * nl + l] = make_double2(b0.x + u2.x, b0.y + u2.y);
+            buf[(p + 2 * m) * nl + l] = make_double2(b0.x - u2.x, b0.y - u2.y);
+            buf[(p + m) * nl + l] = make_double2(b1.x + u3.x, b1.y + u3.y);
+            buf[(p + 3 * m) * nl + l] = make_double2(b1.x - u3.x, b1.y - u3.y);
+        }
+    }
+    if (m < N) {                                                    // remaining single stage (m = N/2)
+        __syncthreads();
+        const int nb = (N >> 1) * nl;
         const int tstep = (N >> 1) / m;
         for (int t = threadIdx.x; t < nb; t += kFftBlock) {
             const int l = t % nl, b = t / nl;
             const int pos = b & (m - 1);
             const int i = ((b - pos) << 1) + pos, j = i + m;
-            const double2 w = tw[pos * tstep];
-            const double2 u = buf[i * nl + l], v = buf[j * nl + l];
-            const double tr = w.x * v.x - w.y * v.y, ti = w.x * v.y + w.y * v.x;
-            buf[i * nl + l] = make_double2(u.x + tr, u.y + ti);
-            buf[j * nl + l] = make_double2(u.x - tr, u.y - ti);
+            const double2 u = buf[i * nl + l], v = cmul(tw[pos * tstep], buf[j * nl + l]);
+            buf[i * nl + l] = make_double2(u.x + v.x, u.y + v.y);
+            buf[j * nl + l] = make_double2(u.x - v.x, u.y - v.y);
         }
     }
     __syncthreads();
 }
 
-// pass 1: real lines along the contiguous axis -> first N/2 + 1 coefficients.  One workgroup per line.
+// pass 1: real lines along the contiguous axis -> first N/2 + 1 coefficients.  One workgroup transforms TWO adjacent
+// lines a, b as the single complex sequence a + i b and separates the spectra afterwards:
+//   A_k = (Z_k + conj(Z_{N-k})) / 2,   B_k = (Z_k - conj(Z_{N-k})) / (2i).
 __global__ void __launch_bounds__(kFftBlock)
 fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, int N, int log2n, const double2 *__restrict__ tw)
 {
     extern __shared__ double2 fbuf[];
-    const int64_t line = blockIdx.x;
-    const double *src = map + line * N;
-    for (int i = threadIdx.x; i < N; i += kFftBlock) fbuf[bit_reverse(i, log2n)] = make_double2(src[i], 0.0);
+    const int64_t line = 2 * (int64_t)blockIdx.x;
+    const double *sa = map + line * N, *sb = sa + N;
+    for (int i = threadIdx.x; i < N; i += kFftBlock) fbuf[bit_reverse(i, log2n)] = make_double2(sa[i], sb[i]);
     lds_fft_stages(fbuf, N, 1, tw);
     const int nz = (N >> 1) + 1;
-    double2 *dst = out + line * nz;
-    for (int i = threadIdx.x; i < nz; i += kFftBlock) dst[i] = fbuf[i];
+    double2 *da = out + line * nz, *db = da + nz;
+    for (int k = threadIdx.x; k < nz; k += kFftBlock) {
+        const double2 z = fbuf[k], zc = fbuf[(N - k) & (N - 1)];    // Z_{N-k}, with Z_N = Z_0
+        da[k] = make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
+        db[k] = make_double2(0.5 * (z.y + zc.y), 0.5 * (zc.x - z.x));
+    }
 }
 
 // passes 2 and 3: in-place complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
