@@ -265,8 +265,9 @@ __device__ inline AxisSplit split_axis(double pos, int N)
 }
 
 template <int DIM>
-__device__ inline void deposit_cell(const double pos[3], double v, int N, double *__restrict__ grid)
+__device__ inline double deposit_cell(const double pos[3], double v, int N, double *__restrict__ grid)
 {
+    double dep = 0.0;                     // what was actually added to the grid
     // pos[0] moves along the SECOND array axis (j), pos[1] along the first (i), pos[2] along the third (k)
     const AxisSplit sx = split_axis(pos[0], N), sy = split_axis(pos[1], N);
     if (DIM == 3) {
@@ -278,8 +279,11 @@ __device__ inline void deposit_cell(const double pos[3], double v, int N, double
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double dy = sy.w[a], dx = sx.w[b], dz = sz.w[c];
-                    if (dx > 0.0 && dy > 0.0 && dz > 0.0)
-                        atomicAdd(grid + ((int64_t)sy.cell[a] * N + sx.cell[b]) * N + sz.cell[c], mul_nc(mul_nc(mul_nc(dx, dy), dz), v));
+                    if (dx > 0.0 && dy > 0.0 && dz > 0.0) {
+                        const double w = mul_nc(mul_nc(mul_nc(dx, dy), dz), v);
+                        atomicAdd(grid + ((int64_t)sy.cell[a] * N + sx.cell[b]) * N + sz.cell[c], w);
+                        dep += w;
+                    }
                 }
     } else {
 #pragma unroll
@@ -287,33 +291,79 @@ __device__ inline void deposit_cell(const double pos[3], double v, int N, double
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const double dy = sy.w[a], dx = sx.w[b];
-                if (dx > 0.0 && dy > 0.0) atomicAdd(grid + (int64_t)sy.cell[a] * N + sx.cell[b], mul_nc(mul_nc(dx, dy), v));
+                if (dx > 0.0 && dy > 0.0) {
+                    const double w = mul_nc(mul_nc(dx, dy), v);
+                    atomicAdd(grid + (int64_t)sy.cell[a] * N + sx.cell[b], w);
+                    dep += w;
+                }
             }
     }
+    return dep;
 }
 
-// Map2DRunner.py:577-599: offsets -> finite or 0, plus the pixel's own (x, y[, z]) = (second, first[, third]) index
+// Map2DRunner.py:577-599: offsets -> finite or 0, plus the pixel's own (x, y[, z]) = (second, first[, third]) index.
+// A pixel whose offsets are all exactly zero (most of a map: everything outside the halos' balls) overlaps only its
+// own cell with weight 1, so it skips the modulo / split arithmetic.  block_sums (optional, [gridDim.x][2]) receives
+// the workgroup's {sum of source values, sum of deposited values} for the mass-conservation check (:601-605).
 template <int DIM>
 __global__ void __launch_bounds__(256)
 grid_regrid_kernel(int N, int64_t ntot, const double *__restrict__ offsets, const double *__restrict__ map_in,
-                   double *__restrict__ map_out)
+                   double *__restrict__ map_out, double *__restrict__ block_sums)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= ntot) return;
-    const double v = map_in[p];
-    if (v == 0.0) return;                         // adds exactly nothing
-    int p0, p1, p2 = 0;
-    if (DIM == 3) { p2 = (int)(p % N); const int64_t q = p / N; p1 = (int)(q % N); p0 = (int)(q / N); }
-    else { p1 = (int)(p % N); p0 = (int)(p / N); }
-    double pos[3] = {0.0, 0.0, 0.0};
-    const int base[3] = {p1, p0, p2};
+    double sum_in = 0.0, sum_out = 0.0;
+    if (p < ntot) {
+        const double v = map_in[p];
+        sum_in = v;
+        if (v != 0.0) {                           // an empty cell adds exactly nothing
+            double o[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) {
-        double o = offsets[DIM * p + c];
-        if (!isfinite(o)) o = 0.0;
-        pos[c] = o + (double)base[c];
+            for (int c = 0; c < DIM; ++c) { o[c] = offsets[DIM * p + c]; if (!isfinite(o[c])) o[c] = 0.0; }
+            if (o[0] == 0.0 && o[1] == 0.0 && o[2] == 0.0) {
+                atomicAdd(map_out + p, v);
+                sum_out = v;
+            } else {
+                int p0, p1, p2 = 0;
+                if (DIM == 3) { p2 = (int)(p % N); const int64_t q = p / N; p1 = (int)(q % N); p0 = (int)(q / N); }
+                else { p1 = (int)(p % N); p0 = (int)(p / N); }
+                const double pos[3] = {o[0] + (double)p1, o[1] + (double)p0, o[2] + (double)p2};
+                sum_out = deposit_cell<DIM>(pos, v, N, map_out);
+            }
+        }
     }
-    deposit_cell<DIM>(pos, v, N, map_out);
+    if (block_sums) {
+        __shared__ double sa[256 / kWave], sb[256 / kWave];
+#pragma unroll
+        for (int s = kWave >> 1; s > 0; s >>= 1) { sum_in += __shfl_down(sum_in, s, kWave); sum_out += __shfl_down(sum_out, s, kWave); }
+        const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+        if (lane == 0) { sa[wid] = sum_in; sb[wid] = sum_out; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ta = 0.0, tb = 0.0;
+            for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; }
+            block_sums[2 * (int64_t)blockIdx.x] = ta; block_sums[2 * (int64_t)blockIdx.x + 1] = tb;
+        }
+    }
+}
+
+// sums[0] += sum of block_sums[2 b], sums[1] += sum of block_sums[2 b + 1]   (grid-stride, one atomic pair per workgroup)
+__global__ void __launch_bounds__(256)
+sum_blocks_kernel(int64_t nblocks, const double *__restrict__ block_sums, double *__restrict__ sums)
+{
+    __shared__ double sa[256 / kWave], sb[256 / kWave];
+    double xa = 0.0, xb = 0.0;
+    const double2 *bs = reinterpret_cast<const double2 *>(block_sums);
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * 256) { const double2 v = bs[b]; xa += v.x; xb += v.y; }
+#pragma unroll
+    for (int s = kWave >> 1; s > 0; s >>= 1) { xa += __shfl_down(xa, s, kWave); xb += __shfl_down(xb, s, kWave); }
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) { sa[wid] = xa; sb[wid] = xb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; }
+        atomicAdd(sums + 0, ta); atomicAdd(sums + 1, tb);
+    }
 }
 
 // regrid_pixels_2D / regrid_pixels_3D on caller-given positions [n][DIM] and values [n]
@@ -327,7 +377,7 @@ pixel_deposit_kernel(int N, int64_t n, const double *__restrict__ positions, con
     double pos[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < DIM; ++c) pos[c] = positions[DIM * p + c];
-    deposit_cell<DIM>(pos, values[p], N, grid);
+    (void)deposit_cell<DIM>(pos, values[p], N, grid);
 }
 
 // np.histogramdd(coords, bins = (edges,) * DIM, weights = mass): bin b holds edges[b] <= v < edges[b + 1], the last
