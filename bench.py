@@ -389,11 +389,13 @@ def main():
                  "paint": "tile_scatter_kernel<PAINT>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
         traffic = None           # HBM bytes per launch from a separate rocprofv3 --pmc run of this same configuration
+        valu = None              # wave-level VALU instructions per launch (SQ_INSTS_VALU) from the same run
         try:
             tj = json.load(open(os.path.join(HERE, 'profiles', 'traffic_latest.json')))
             c = tj['config']
             if (c['halos_per_gpu'], c['nside'], c['algo'], c['mode']) == (args.halos, nside, args.algo, args.mode) and not args.acc_f64:
                 traffic = tj['kernels'].get(dom)
+                valu = tj.get('valu_wave_insts', {}).get(dom)
         except Exception:
             traffic = None
         out = {
@@ -419,6 +421,9 @@ def main():
                          "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom],
+                         # what really bounds the kernel: VALU issue.  1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+                         "valu_issue": None if not valu else {"wave_insts_per_launch": valu, "achieved_per_s": valu / (kernels[dom] * 1e-3),
+                                                              "peak_per_s": 1024 * 2.4e9 / 4, "frac": valu / (kernels[dom] * 1e-3) / (1024 * 2.4e9 / 4)},
                          "note": ("tile-owned LDS accumulation, no global atomics: ~20 B of algorithmic HBM traffic per "
                                   "~180 fp64 VALU ops per (halo, pixel) pair, so the kernel sits far below the HBM roof "
                                   "and is bounded by fp64 issue/latency at 2 waves/SIMD (DESIGN.md section 4)") if args.algo == 1 else
