@@ -126,7 +126,8 @@ class DefaultRunnerGrid(object):
         is2D = self.GriddedMap.is2D
         # the read-out takes np.log of the float32 catalog mass, i.e. a float32 logarithm (BaryonCorrection.py:369,
         # Tabulate.py:283); evaluated here with the caller's numpy so that its last bit is the reference's
-        lnM = np.log(np.asarray(cat['M'], dtype=np.float32)).astype(np.float64)
+        with np.errstate(invalid='ignore', divide='ignore'):      # invalid masses are skipped by the kernels
+            lnM = np.log(np.asarray(cat['M'], dtype=np.float32)).astype(np.float64)
         return _lib.make_grid_catalog_host(cat['M'], cat['x'], cat['y'], None if is2D else cat['z'], lnM, rmat,
                                            [cat[k] for k in keys])
 

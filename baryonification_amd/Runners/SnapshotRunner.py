@@ -56,7 +56,8 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
         model, p_keys, keep = build_model(self, 'displacement', cosmo)
         if p_keys:
             raise NotImplementedError("BaryonifySnapshot passes no halo properties to the model (SnapshotRunner.py:240)")
-        lnM = np.log(np.asarray(hcat['M'], dtype=np.float32)).astype(np.float64)     # float32 log, as BaryonifyGrid
+        with np.errstate(invalid='ignore', divide='ignore'):
+            lnM = np.log(np.asarray(hcat['M'], dtype=np.float32)).astype(np.float64)     # float32 log, as BaryonifyGrid
         cat, cols = _lib.make_grid_catalog_host(hcat['M'], hcat['x'], hcat['y'], None if is2D else hcat['z'], lnM)
         x, y = _lib.f8(snap.cat['x']), _lib.f8(snap.cat['y'])
         z = None if is2D else _lib.f8(snap.cat['z'])
