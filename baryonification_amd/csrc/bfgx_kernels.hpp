@@ -204,6 +204,31 @@ struct RowSpan {
     double z, sth;
 };
 
+// the pixel span [lo, lo + cnt) (mod nr) of a disc in one ring whose geometry is already known (tiled kernels: per-tile
+// ring table); same arithmetic as disc_row
+__device__ inline void disc_row_span(int nr, bool shifted, double z, double fnr, int ring, double z0, double xa, double cosr,
+                                     double phi0, int irmin, int irmax, int &lo, int &cnt)
+{
+    lo = 0; cnt = 0;
+    if (ring < irmin || ring > irmax) { cnt = nr; return; }              // polar-cap row: whole ring inside
+    const double x = (cosr - z * z0) * xa;
+    const double ysq = 1.0 - z * z - x * x;
+    if (!(ysq > 0.0)) return;
+    const double dphi = atan2(sqrt(ysq), x);
+    if (!(dphi > 0.0)) return;
+    const double sh = shifted ? 0.5 : 0.0;
+    const int64_t ip_lo = (int64_t)floor(fnr * (phi0 - dphi) - sh) + 1;
+    const int64_t ip_hi = (int64_t)floor(fnr * (phi0 + dphi) - sh);
+    int64_t c = ip_hi - ip_lo + 1;
+    c = c < 0 ? 0 : (c > nr ? nr : c);
+    cnt = (int)c;
+    int64_t l = ip_lo;
+    if (l < 0) l += nr;
+    if (l >= nr) l -= nr;
+    if (l < 0) l += nr;
+    lo = (int)l;
+}
+
 __device__ inline void disc_row(const Hpx &h, int ring, double z0, double xa, double cosr, double phi0,
                                 int irmin, int irmax, RowSpan &s)
 {
@@ -918,11 +943,15 @@ halo_scatter_kernel(PairTable pt, Hpx h, int64_t nhalo, const HaloRec *__restric
 constexpr int kChunk = 16;
 constexpr int kMaskWords = 66;           // 64 rows x up to 64 pixels (W <= 64) = 4096 pairs -> 64 words (+2 spare)
 
-struct RingSlot {                    // ring-phase view of one entry
+struct RingSlot {                    // ring-phase view of one entry (the rare <4-pixel fallback pixels stay in the HaloRec)
     double z0, xa, cosr, phi0;
-    int32_t irmin, irmax, ring_lo, prefix, fb;
-    int32_t fb_ring[4], fb_k[4];
-    int32_t _pad;
+    int32_t irmin, irmax, ring_lo, prefix, fb, hidx;
+};
+
+// one ring of a tile: what the ring-row phase needs of it, computed once per workgroup instead of once per (halo, ring)
+struct TileRow {
+    double z, sth, dphi, fnr;         // cos / sin of the colatitude, 2 pi / nr, nr / (2 pi)
+    int32_t nr, ks, ke, shifted;      // ring length, the tile's pixel span [ks, ke) in the ring, half-pixel shift flag
 };
 
 template <int NC>
@@ -941,7 +970,7 @@ __host__ __device__ inline size_t tile_lds_bytes(int BR, int W, int ncomp)
 {
     size_t a = (size_t)BR * W * ncomp * sizeof(double);
     a = (a + 15) & ~(size_t)15;
-    return a + sizeof(TileWaveLdsT<NC>) * kWavesPerBlock + 16;
+    return a + sizeof(TileWaveLdsT<NC>) * kWavesPerBlock + 16 + sizeof(TileRow) * (size_t)BR;
 }
 
 template <int MODE, typename ACC, int NC>
@@ -967,6 +996,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
     using PairH = PairHaloT<NC>;
     TileWaveLds *wl = reinterpret_cast<TileWaveLds *>(smem + acc_bytes);
     int *next_chunk = reinterpret_cast<int *>(wl + kWavesPerBlock);
+    TileRow *rowtab = reinterpret_cast<TileRow *>(reinterpret_cast<unsigned char *>(next_chunk) + 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -974,6 +1004,18 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
     if (MODE != MODE_COUNT)
         for (int i = tid; i < acc_n; i += kWave * kWavesPerBlock) acc[i] = 0.0;
     if (tid == 0) *next_chunk = 0;
+    if (tid < T.BR && i0 + tid < i1) {
+        const int ring = i0 + tid;
+        int64_t st, n64; bool shf;
+        TileRow tr;
+        ring_info_small(h, ring, st, n64, shf);
+        ring_z_sth(h, ring, tr.z, tr.sth);
+        tr.nr = (int)n64; tr.shifted = shf ? 1 : 0;
+        tr.dphi = kTwoPi / (double)tr.nr;
+        tr.fnr = (double)n64 * kInvTwoPi;
+        tr.ks = tile_ks(tj, tr.nr, nphi); tr.ke = tile_ks(tj + 1, tr.nr, nphi);
+        rowtab[tid] = tr;
+    }
     __syncthreads();
 
     const int64_t e0 = tile_start[tile];
@@ -997,8 +1039,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
             const HaloRec &r = recs[hidx];
             RingSlot rs;
             rs.z0 = r.z0; rs.xa = r.xa; rs.cosr = r.cosr; rs.phi0 = r.phi0;
-            rs.irmin = r.irmin; rs.irmax = r.irmax; rs.fb = r.fb; rs._pad = 0;
-            for (int q = 0; q < 4; ++q) { rs.fb_ring[q] = r.fb_ring[q]; rs.fb_k[q] = r.fb_k[q]; }
+            rs.irmin = r.irmin; rs.irmax = r.irmax; rs.fb = r.fb; rs.hidx = hidx;
             if (r.fb) { nrows = 4; rs.ring_lo = 0; }
             else {
                 const int lo = max(r.rfirst, i0), hi = min(r.rlast, i1 - 1);
@@ -1018,7 +1059,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
             // ---- lanes = ring rows (clipped to this tile)
             const int R = rb + lane;
             int firstA = 0, cntA = 0, firstB = 0, cntB = 0, nr = 1, ldsbase = 0, es = 0;
-            double z = 0.0, sth = 0.0, shift = 0.0;
+            double z = 0.0, sth = 0.0, shift = 0.0, dphv = 0.0;
             if (R < total_rows) {
                 int e = 0;                                        // largest entry with prefix <= R
 #pragma unroll
@@ -1028,26 +1069,25 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                 const RingSlot &rs = L.ring[e];
                 const int q = R - rs.prefix;
                 if (rs.fb) {
-                    const int ring = rs.fb_ring[q];
+                    const HaloRec &hr = recs[rs.hidx];            // rare: the 4 fallback pixels live in the halo record
+                    const int ring = hr.fb_ring[q], fk = hr.fb_k[q];
                     if (ring >= i0 && ring < i1) {
-                        int64_t st, n64; bool shf;
-                        ring_info_small(h, ring, st, n64, shf);
-                        ring_z_sth(h, ring, z, sth);
-                        nr = (int)n64; shift = shf ? 0.5 : 0.0;
-                        const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
-                        if (rs.fb_k[q] >= ks && rs.fb_k[q] < ke) { firstA = rs.fb_k[q]; cntA = 1; }
-                        ldsbase = (ring - i0) * T.W - ks;
+                        const TileRow &tr = rowtab[ring - i0];
+                        z = tr.z; sth = tr.sth; nr = tr.nr; shift = tr.shifted ? 0.5 : 0.0; dphv = tr.dphi;
+                        if (fk >= tr.ks && fk < tr.ke) { firstA = fk; cntA = 1; }
+                        ldsbase = (ring - i0) * T.W - tr.ks;
                     }
                 } else {
                     const int ring = rs.ring_lo + q;
-                    RowSpan s;
-                    disc_row(h, ring, rs.z0, rs.xa, rs.cosr, rs.phi0, rs.irmin, rs.irmax, s);
-                    nr = (int)s.nr; z = s.z; sth = s.sth; shift = s.shifted ? 0.5 : 0.0;
-                    const int ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
-                    const int endA = min(s.lo + s.cnt, nr);
-                    firstA = max(s.lo, ks);
+                    const TileRow &tr = rowtab[ring - i0];
+                    int slo, scnt;
+                    disc_row_span(tr.nr, tr.shifted != 0, tr.z, tr.fnr, ring, rs.z0, rs.xa, rs.cosr, rs.phi0, rs.irmin, rs.irmax, slo, scnt);
+                    nr = tr.nr; z = tr.z; sth = tr.sth; shift = tr.shifted ? 0.5 : 0.0; dphv = tr.dphi;
+                    const int ks = tr.ks, ke = tr.ke;
+                    const int endA = min(slo + scnt, nr);
+                    firstA = max(slo, ks);
                     cntA = max(0, min(endA, ke) - firstA);
-                    const int endB = s.lo + s.cnt - nr;           // > 0 when the row wraps past phi = 2 pi
+                    const int endB = slo + scnt - nr;             // > 0 when the row wraps past phi = 2 pi
                     firstB = ks;                                  // max(0, ks)
                     cntB = max(0, min(endB, ke) - firstB);
                     ldsbase = (ring - i0) * T.W - ks;
@@ -1071,8 +1111,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                     L.firstA[slot] = firstA; L.cntA[slot] = cntA; L.firstB[slot] = firstB;
                     L.ldsbase[slot] = ldsbase; L.eslot[slot] = es;
                     L.z[slot] = z; L.sth[slot] = sth;
-                    const double dph = kTwoPi / (double)nr;
-                    L.dphi[slot] = dph; L.xoff[slot] = shift * dph - L.pair[es].phi0;
+                    L.dphi[slot] = dphv; L.xoff[slot] = shift * dphv - L.pair[es].phi0;
                     atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
                 }
                 __builtin_amdgcn_wave_barrier();
