@@ -167,3 +167,51 @@ def test_entry_list_regrowth(gpu, monkeypatch):
     with pytest.raises(ValueError, match='overflowed'):
         plan.status()
     plan.close()
+
+
+@pytest.mark.parametrize('seed,nside,zr,logM,eps', [
+    (1, 1, (0.01, 0.05), (14.0, 15.5), 8.0),       # 12 pixels: every disc takes the <4-pixel fallback or covers whole rings
+    (2, 2, (0.005, 0.02), (14.5, 15.8), 30.0),     # discs of tens of degrees, poles inside, radius > pi/2 for some
+    (3, 8, (0.02, 0.2), (13.0, 15.5), 12.0),
+    (4, 32, (0.05, 1.5), (12.0, 15.0), 10.0),      # wide redshift range: D_A spline, (1+z) scalings
+    (5, 128, (0.3, 3.0), (11.5, 14.5), 20.0),      # high z: sub-pixel discs -> fallback for nearly all
+    (6, 512, (0.1, 0.2), (13.5, 15.5), 6.0),       # several tiles per halo, >4-tile halos
+])
+def test_randomized_regimes_vs_oracle(gpu, seed, nside, zr, logM, eps):
+    """random catalogs far from the benchmark's regime, both BaryonifyShell accumulator types and PaintProfilesShell,
+    against the CPU oracle on the same inputs"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    from oracle import oracle as O
+    N = 600
+    cat = syn.make_catalog(N, seed=1000 + seed, z_lo=zr[0], z_hi=zr[1], logM_lo=logM[0], logM_hi=logM[1])
+    rng = np.random.default_rng(seed)
+    cat['dec'][:4] = [90.0 - 1e-8, -90.0 + 1e-8, 89.99, 0.0]          # poles and the phi = 0 seam
+    cat['ra'][:4] = [0.0, 123.0, 359.999, 1e-9]
+    z, M, r = syn.table_grid(cat, Nz=5, NM=6, NR=96, R_min=1e-3, R_max=1e3, pad=1e-9)
+    d = syn.displacement_table(z, M, r) * (1 + 0.3 * np.sin(3 * np.log(r))[None, None, :])     # not monotone in r
+    P = syn.paint_table(z, M, r)
+    cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    hmap = syn.make_map(nside, seed=seed)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    bg = O.Background.from_dict(syn.COSMO)
+    used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}
+    # BaryonifyShell, model epsilon < runner epsilon (the r < eps R mask bites)
+    model = bfg.Profiles.Baryonification2D(None, None, cosmo, epsilon_max=0.7 * eps)
+    model.set_table(z, M, r, d)
+    Shell = bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO)
+    ora = O.baryonify_shell(nside, hmap, used, O.Table(axes, d, False, 0.7 * eps), eps, bg)
+    for acc64, tol in ((True, 1e-10 * np.abs(ora).max()), (False, 1e-6 * ora.mean())):
+        runner = bfg.Runners.BaryonifyShell(Catalog, Shell, eps, model, verbose=False)
+        runner.acc_f64 = acc64
+        out = runner.process()
+        assert np.abs(out - ora).max() <= tol, (acc64, np.abs(out - ora).max(), tol)
+    # PaintProfilesShell
+    prof = bfg.utils.TabulatedProfile(None, cosmo)
+    prof.set_table(z, M, r, P)
+    pshell = bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=syn.COSMO)
+    out = bfg.Runners.PaintProfilesShell(Catalog, pshell, eps, prof, verbose=False).process()
+    with np.errstate(divide='ignore'):
+        orap = O.paint_shell(nside, used, O.Table(axes, np.log(P)), eps, bg)
+    assert np.abs(out - orap).max() <= 1e-10 * np.abs(orap).max()
