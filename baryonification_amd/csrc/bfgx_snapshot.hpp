@@ -36,6 +36,13 @@ struct SnapHaloRec {
     int32_t oob, valid;
 };
 
+// one halo of a cell's list: what the containment test needs sits in the list itself (contiguous per cell), the full
+// record is only fetched on a hit.  The displace kernel is bound by random 64-byte requests, not by bytes.
+struct SnapEntry {
+    double pos[3], Rq2;
+    int32_t idx, _pad;
+};
+
 __device__ inline int snap_cell(double v, const SnapGeom &g)
 {
     const int c = (int)floor(v * g.inv_cell);
@@ -117,13 +124,15 @@ snap_halo_prep_kernel(DevModel m, SnapGeom g, int64_t nh, const double *__restri
 
 __global__ void __launch_bounds__(256)
 snap_halo_fill_kernel(SnapGeom g, int64_t nh, const SnapHaloRec *__restrict__ recs, const int32_t *__restrict__ cell_start,
-                      int32_t *__restrict__ cell_cursor, int32_t *__restrict__ entries)
+                      int32_t *__restrict__ cell_cursor, SnapEntry *__restrict__ entries)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nh) return;
     const SnapHaloRec &r = recs[j];
     if (!r.valid) return;
-    snap_for_each_cell(g, r, [&](int64_t c) { entries[cell_start[c] + atomicAdd(cell_cursor + c, 1)] = (int32_t)j; });
+    SnapEntry en;
+    en.pos[0] = r.pos[0]; en.pos[1] = r.pos[1]; en.pos[2] = r.pos[2]; en.Rq2 = r.Rq2; en.idx = (int32_t)j; en._pad = 0;
+    snap_for_each_cell(g, r, [&](int64_t c) { entries[cell_start[c] + atomicAdd(cell_cursor + c, 1)] = en; });
 }
 
 // ---- exclusive scan of int32 counts (n up to 2^31): 4096 elements per block, block sums scanned by one block
@@ -171,6 +180,22 @@ scan_add_kernel(int64_t n, int32_t *__restrict__ out, const int32_t *__restrict_
     if (i < n) out[i] += block_sums[i / kScanPerBlock];
 }
 
+// one bit per cell: does any halo list the cell?  nc^3 bits (256 KB at 128^3) stay cache-resident, so the ~60 % of the
+// particles that sit in empty cells never touch the 8 MB cell_start table (random 64-byte requests are what bounds the
+// displace kernel, not bytes)
+__global__ void __launch_bounds__(256)
+cell_bitmap_kernel(int64_t ncell, const int32_t *__restrict__ cell_count, uint32_t *__restrict__ bitmap)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32 >= ncell) return;
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int64_t c = w * 32 + b;
+        if (c < ncell && cell_count[c] > 0) bits |= (1u << b);
+    }
+    bitmap[w] = bits;
+}
+
 // min-image of a coordinate difference (SnapshotRunner.py:87-91)
 __device__ inline double min_image(double dx, double L)
 {
@@ -183,8 +208,8 @@ __device__ inline double min_image(double dx, double L)
 template <int DIM>
 __global__ void __launch_bounds__(256)
 snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restrict__ px, const double *__restrict__ py,
-                     const double *__restrict__ pz, const SnapHaloRec *__restrict__ recs, const int32_t *__restrict__ cell_start,
-                     const int32_t *__restrict__ entries, double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz,
+                     const double *__restrict__ pz, const SnapHaloRec *__restrict__ recs, const uint32_t *__restrict__ bitmap,
+                     const int32_t *__restrict__ cell_start, const SnapEntry *__restrict__ entries, double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz,
                      int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total)
 {
     unsigned long long npairs = 0;
@@ -197,23 +222,33 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
         if (!inside) atomicOr(flags, 2);
         else {
             const int64_t c = snap_cell_index(g, snap_cell(x, g), snap_cell(y, g), (DIM == 3) ? snap_cell(z, g) : 0);
-            const int e0 = cell_start[c], e1 = cell_start[c + 1];
+            int e0 = 0, e1 = 0;
+            if ((bitmap[c >> 5] >> (c & 31)) & 1u) { e0 = cell_start[c]; e1 = cell_start[c + 1]; }
             for (int e = e0; e < e1; ++e) {
-                const SnapHaloRec &r = recs[entries[e]];
-                const double dx = min_image(x - r.pos[0], g.L), dy = min_image(y - r.pos[1], g.L);
-                const double dz = (DIM == 3) ? min_image(z - r.pos[2], g.L) : 0.0;
+                const SnapEntry &en = entries[e];
+                const double dx = min_image(x - en.pos[0], g.L), dy = min_image(y - en.pos[1], g.L);
+                const double dz = (DIM == 3) ? min_image(z - en.pos[2], g.L) : 0.0;
                 double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
                 if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
-                if (!(d2 <= r.Rq2)) continue;                                            // :225 / :237 query_ball_point
-                const double d = sqrt(d2);                                               // :228 compute_distance
-                double disp = radial_readout<kNC>(pt, r.rowoff, r.w, log(d) + r.lnoff);  // BaryonCorrection.py:356-379
+                if (!(d2 <= en.Rq2)) continue;                                           // :225 / :237 query_ball_point
+                const SnapHaloRec &r = recs[en.idx];
+                // libm-free (bfgx_math.hpp): every lane of a wave pays for this block as soon as one lane has a hit
+                const double inv_d = (d2 > 0.0) ? fast_rsq(d2) : 0.0;
+                const double d = d2 * inv_d;                                             // :228 compute_distance
+                const double lnd = (d2 > 0.0) ? 0.5 * fast_log(d2) : -1.0e300;           // ln 0 -> below any table: NaN read-out
+                double disp = radial_readout<kNC>(pt, r.rowoff, r.w, lnd + r.lnoff);     // BaryonCorrection.py:356-379
                 if (!(d < r.rcut)) disp = 0.0;                                           // :381-382
                 double off = disp * g.a;                                                 // :240 displacement * a
                 if (!isfinite(off)) off = 0.0;                                           // :241
                 if (off == 0.0 && d > 0.0) continue;
                 ++npairs;
-                tx += off * (dx / d); ty += off * (dy / d);                              // :242-244 (0 * NaN stays NaN at d = 0)
-                if (DIM == 3) tz += off * (dz / d);
+                if (d2 > 0.0) {
+                    const double oi = off * inv_d;                                       // :242-244 offset * (dx / d)
+                    tx += oi * dx; ty += oi * dy;
+                    if (DIM == 3) tz += oi * dz;
+                } else {                                                                 // d = 0: 0 * (0 / 0) = NaN, as the reference
+                    tx = ty = tz = __builtin_nan("");
+                }
             }
         }
         double nx = x + tx, ny = y + ty, nz = z + tz;                                    // :254-257
