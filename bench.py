@@ -356,6 +356,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if slices:
+        # one untimed trial of the slice exchange: an exception here (argument validation of the collective is identical
+        # on every rank) switches all ranks to the plain reduce instead of losing the run
+        try:
+            step()
+            fence()
+        except Exception as e:        # noqa: BLE001
+            if rank == 0:
+                print("bench: slice exchange failed (%s: %s); falling back to --exchange reduce" % (type(e).__name__, e), file=sys.stderr, flush=True)
+            slices = False
     for _ in range(args.warmup):
         step()
     fence()
