@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--ngrid', type=int, default=512, help='grid3d: cells per side (power of two)')
     ap.add_argument('--particles', type=int, default=0, help='grid3d: particles in the snapshot (default ngrid^3 / 2)')
     ap.add_argument('--grid-halos', type=int, default=100_000, help='grid3d: halos per GPU')
+    ap.add_argument('--sorted-particles', action='store_true',
+                    help='grid3d / snapshot: order the synthetic particles by coarse cell (as snapshot files stored along a space-filling '
+                         'curve are) instead of uniformly random order')
     ap.add_argument('--table', choices=['closed-form', 's19'], default='closed-form',
                     help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
                          "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
@@ -146,6 +149,10 @@ def main_grid(args):
     cat_dev = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
     torch.manual_seed(syn.SEED_MAP)
     part = torch.rand((3, npart), dtype=torch.float64, device=dev) * L       # synthetic snapshot, unit particle mass
+    if args.sorted_particles:            # setup, untimed: raster order of 64^3 coarse cells
+        key = ((part[0] * (64 / L)).long().clamp_(0, 63) * 64 + (part[1] * (64 / L)).long().clamp_(0, 63)) * 64 + (part[2] * (64 / L)).long().clamp_(0, 63)
+        part = part[:, torch.argsort(key)].contiguous()
+        del key
     d_edges = torch.from_numpy(edges).to(dev)
     d_map = torch.empty(N ** 3, dtype=torch.float64, device=dev)
     d_off = torch.empty(N ** 3 * 3, dtype=torch.float64, device=dev)
@@ -232,7 +239,7 @@ def main_grid(args):
                "config": {"workload": "BASELINE config 5 (single-node form): %d^3 grid of a %.1f Mpc box at z=0, %d uniform particles, %d halos "
                                       "per GPU (SURVEY 8d mass function, float32 catalog), epsilon_max=%g, closed-form displacement table, "
                                       "P(k) in %d linear bins" % (N, L, npart, nh, eps, Nk),
-                          "ngrid": N, "particles": npart, "halos_per_gpu": nh, "contributing_pairs_per_gpu": pairs[0],
+                          "particle_order": "coarse-cell raster" if args.sorted_particles else "random", "ngrid": N, "particles": npart, "halos_per_gpu": nh, "contributing_pairs_per_gpu": pairs[0],
                           "parallelism": "halo shards x%d + RCCL reduce(pix_offsets) -> rank 0 regrid + P(k)" % world if world > 1 else "single GPU"},
                "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
                "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),
