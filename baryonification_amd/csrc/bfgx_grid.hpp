@@ -216,7 +216,7 @@ grid_scatter_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restrict__ re
                 atomicAdd(out + DIM * flat + 1, off * (Y / rr));
                 if (DIM == 3) atomicAdd(out + DIM * flat + 2, off * (Z / rr));
             } else {
-                const double P = exp(d);                                          // Tabulate.py:285-286
+                const double P = fast_exp(d);                                          // Tabulate.py:285-286
                 if (!(isfinite(P) && r_eval < R.rcut) || P == 0.0) continue;      // :800-801
                 ++npairs;
                 atomicAdd(out + flat, P);

@@ -734,7 +734,7 @@ __device__ inline bool pair_value(const PairTable &tab, const PairHaloT<NC> &r, 
     const double lx = __builtin_fma(0.5, fast_log(r2), r.lnoff);                    // ln(r_sep/a) [- ln R when Rdelta]
     double d = r.oob ? __builtin_nan("") : radial_readout<NC>(tab, r.rowoff, r.w, lx);
     if (MODE == MODE_PAINT) {
-        const double paint = exp(d);                                                // Tabulate.py:286
+        const double paint = fast_exp(d);                                                // Tabulate.py:286
         v[0] = paint;
         return isfinite(paint) && paint != 0.0;                                     // :442
     }
@@ -782,7 +782,7 @@ __device__ inline bool pair_value_fast(const PairTable &tab, const PairHaloT<NC>
     }
 #endif
     if (MODE == MODE_PAINT) {
-        const double paint = exp(d);                                                // Tabulate.py:286
+        const double paint = fast_exp(d);                                                // Tabulate.py:286
         v[0] = paint;
         return ok && isfinite(paint) && paint != 0.0;                               // :442
     }

@@ -55,6 +55,34 @@ __device__ inline double fast_log(double x)
     return __builtin_fma(fe, 0.693147180369123816490, __builtin_fma(fe, 1.90821492927058770002e-10, lm));
 }
 
+// exp(x) for any double: x = k ln2 + r, |r| <= ln2 / 2 (two-term ln 2, FMA), Taylor to r^13 (truncation < 3e-18 relative),
+// scaling by ldexp.  Branch-free; +inf above 709.78, 0 below -745.2, NaN stays NaN.  ~1 ulp.
+__device__ inline double fast_exp(double x)
+{
+    const double xc = fmin(fmax(x, -746.0), 710.0);                         // keeps k in int range; NaN propagates through fmin/fmax? no:
+    const double xx = (x != x) ? x : xc;                                    // fmin/fmax drop NaN, so put it back
+    const double k = __builtin_rint(xx * 1.44269504088896338700);           // 1 / ln 2
+    double r = __builtin_fma(-k, 0.693147180369123816490, xx);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;                                          // r^13 / 13!
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    // two-step scaling so that results in the subnormal range round once
+    const int ki = (int)k, k1 = ki / 2, k2 = ki - k1;
+    return __builtin_amdgcn_ldexp(__builtin_amdgcn_ldexp(p, k1), k2);
+}
+
 // sin/cos for |x| <= 0.5 (Taylor to x^15 / x^16: truncation < 3e-20)
 __device__ inline void sincos_small(double x, double &s, double &c)
 {
