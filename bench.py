@@ -274,7 +274,7 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1':
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     nside, npix = args.nside, 12 * args.nside ** 2
@@ -300,7 +300,7 @@ def main():
     d_off = torch.zeros(npix * 3, dtype=acc_dtype, device=dev)
     d_out = torch.zeros(npix, dtype=torch.float64, device=dev)
     d_sums = torch.zeros(2, dtype=torch.float64, device=dev)
-    d_fin = torch.zeros(npix if (world > 1 and rank == 0) else 0, dtype=torch.float64, device=dev)
+    d_fin = torch.zeros(npix if ((world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1') and rank == 0) else 0, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     plan = engine.ShellPlan(model, keep, nside, args.halos, device=local_rank, stream=stream)
     cat_dev = _lib.make_catalog_dev(args.halos, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
@@ -310,7 +310,9 @@ def main():
 
     # N > 1: slice exchange (utils/Parallelize.py): all_to_all reduce-scatter of the accumulator by pixel slices, every rank
     # regrids the bands it owns, windows travel to rank 0.  --exchange reduce keeps the single reduce(sum) to rank 0.
-    slices = world > 1 and args.exchange == 'slices' and args.algo == 1
+    # BFGX_FORCE_EXCHANGE=1: run the N > 1 exchange code with a single rank too (exercises the RCCL calls on a one-GPU box)
+    force_x = os.environ.get('BFGX_FORCE_EXCHANGE') == '1'
+    slices = (world > 1 or force_x) and args.exchange == 'slices' and args.algo == 1
     if slices:
         from baryonification_amd.utils.Parallelize import band_partition, gather_windows, sliced_reduce, window_margin
         first = plan.bands()
@@ -451,7 +453,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
         print(json.dumps(out), flush=True)
     plan.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
