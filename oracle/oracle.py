@@ -66,9 +66,11 @@ class Background(object):
         """physical critical density, Msun / Mpc^3"""
         return RHO_CRITICAL * self.h ** 2 * self.E2(a)
 
-    def get_radius(self, M, a, Delta=200.0):
-        """ccl MassDef(Delta,'critical').get_radius: physical Mpc"""
-        return (np.asarray(M, dtype=np.float64) / (4.18879020479 * Delta * self.rho_crit(a))) ** (1.0 / 3.0)
+    def get_radius(self, M, a, Delta=200.0, rho_type='critical'):
+        """ccl MassDef(Delta, rho_type).get_radius: physical Mpc (rho_x(a, 'critical' | 'matter'), not comoving)"""
+        a = np.asarray(a, dtype=np.float64)
+        rho = self.rho_crit(a) if rho_type == 'critical' else RHO_CRITICAL * self.h ** 2 * self.Omega_m / a ** 3
+        return (np.asarray(M, dtype=np.float64) / (4.18879020479 * Delta * rho)) ** (1.0 / 3.0)
 
     def comoving_distance_z(self, z):
         """chi(z) in Mpc by Gauss-Legendre panels on [0, z] (sorted ascending input)."""
@@ -210,20 +212,21 @@ class Table(object):
         return lib().bfgo_rgi_eval(ndim, _ptr(n), ax, _ptr(self.values), _ptr(x))
 
 
-def halo_scalars(cat, bg_runner, bg_model=None):
+def halo_scalars(cat, bg_runner, bg_model=None, md_runner=(200.0, 'critical'), md_model=(200.0, 'critical')):
     """a_j, R_j (phys), D_j (phys), Rmod_j (comoving, model cosmology): HealpixRunner.py:293-297,
-    BaryonCorrection.py:370."""
+    BaryonCorrection.py:370.  md_* = (Delta, rho_type) of the runner's and the model's mass definitions."""
     bg_model = bg_model or bg_runner
     M, z = _f8(cat['M']), _f8(cat['z'])
     a = 1.0 / (1.0 + z)
-    R = bg_runner.get_radius(M, a)
+    R = bg_runner.get_radius(M, a, *md_runner)
     D = bg_runner.Da_spline()(z)
-    Rmod = bg_model.get_radius(M, a) / a
+    Rmod = bg_model.get_radius(M, a, *md_model) / a
     return a, R, D, Rmod
 
 
-def baryonify_offsets(nside, cat, table, eps_runner, bg_runner, bg_model=None, return_counts=False):
-    a, R, D, Rmod = halo_scalars(cat, bg_runner, bg_model)
+def baryonify_offsets(nside, cat, table, eps_runner, bg_runner, bg_model=None, return_counts=False, md_runner=(200.0, 'critical'),
+                      md_model=(200.0, 'critical')):
+    a, R, D, Rmod = halo_scalars(cat, bg_runner, bg_model, md_runner, md_model)
     ra, dec, M = _f8(cat['ra']), _f8(cat['dec']), _f8(cat['M'])
     extra = [_f8(cat[k]) for k in table.p_keys]
     ndim, tn, tax = table._cargs()
@@ -245,19 +248,20 @@ def regrid(nside, orig_map, pix_offsets):
     return new_map
 
 
-def baryonify_shell(nside, orig_map, cat, table, eps_runner, bg_runner, bg_model=None):
+def baryonify_shell(nside, orig_map, cat, table, eps_runner, bg_runner, bg_model=None, md_runner=(200.0, 'critical'),
+                    md_model=(200.0, 'critical')):
     """BaryonifyShell.process(), HealpixRunner.py:240-349 (incl. the mass-conservation assert)."""
-    off = baryonify_offsets(nside, cat, table, eps_runner, bg_runner, bg_model)
+    off = baryonify_offsets(nside, cat, table, eps_runner, bg_runner, bg_model, md_runner=md_runner, md_model=md_model)
     new_map = regrid(nside, orig_map, off)
     new_sum, old_sum = np.sum(new_map), np.sum(orig_map)
     assert np.isclose(new_sum, old_sum), "ERROR in pixel regridding"
     return new_map
 
 
-def paint_shell(nside, cat, log_table, eps_runner, bg_runner, return_counts=False):
+def paint_shell(nside, cat, log_table, eps_runner, bg_runner, return_counts=False, md_runner=(200.0, 'critical')):
     """PaintProfilesShell.process(), HealpixRunner.py:366-447, for a (Param)TabulatedProfile whose
     interpolator holds log(raw_input_2D)."""
-    a, R, D, _ = halo_scalars(cat, bg_runner)
+    a, R, D, _ = halo_scalars(cat, bg_runner, None, md_runner)
     ra, dec, M = _f8(cat['ra']), _f8(cat['dec']), _f8(cat['M'])
     extra = [_f8(cat[k]) for k in log_table.p_keys]
     ndim, tn, tax = log_table._cargs()

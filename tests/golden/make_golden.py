@@ -120,7 +120,8 @@ def special_catalog(N, seed, z_lo, z_hi, logM_lo, logM_hi):
 
 
 def run_case(name, kind, nside, cat, eps_runner, eps_model, table_axes, table, rdelta=False,
-             cosmo_runner=syn.COSMO, cosmo_model=syn.COSMO, map_seed=syn.SEED_MAP):
+             cosmo_runner=syn.COSMO, cosmo_model=syn.COSMO, map_seed=syn.SEED_MAP, md_runner=(200.0, 'critical'),
+             md_model=(200.0, 'critical')):
     z, M, r_axis = table_axes
     Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=cosmo_runner)
     cat_used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}      # after pole clipping
@@ -129,18 +130,21 @@ def run_case(name, kind, nside, cat, eps_runner, eps_model, table_axes, table, r
         hmap = syn.make_map(nside, seed=map_seed)
         Shell = bfg.utils.LightconeShell(map=hmap, cosmo=cosmo_runner)
         model = ref_displacement_model(z, M, r_axis, table, rdelta, eps_model, cosmo_model)
-        out = bfg.Runners.BaryonifyShell(Catalog, Shell, eps_runner, model, verbose=False).process()
+        model.mass_def = ccl.halos.massdef.MassDef(*md_model)
+        out = bfg.Runners.BaryonifyShell(Catalog, Shell, eps_runner, model, mass_def=ccl.halos.massdef.MassDef(*md_runner),
+                                         verbose=False).process()
         otab = O.Table([np.log(1 + z), np.log(M), np.log(r_axis)], table, rdelta, eps_model)
         oout = O.baryonify_shell(nside, hmap, cat_used, otab, eps_runner, O.Background.from_dict(cosmo_runner),
-                                 O.Background.from_dict(cosmo_model))
+                                 O.Background.from_dict(cosmo_model), md_runner, md_model)
     else:
         hmap = np.zeros(12 * nside * nside)
         Shell = bfg.utils.LightconeShell(map=hmap, cosmo=cosmo_runner)
         model = ref_tabulated_profile(z, M, r_axis, table, cosmo_model)
-        out = bfg.Runners.PaintProfilesShell(Catalog, Shell, eps_runner, model, verbose=False).process()
+        out = bfg.Runners.PaintProfilesShell(Catalog, Shell, eps_runner, model, mass_def=ccl.halos.massdef.MassDef(*md_runner),
+                                             verbose=False).process()
         with np.errstate(divide='ignore'):
             otab = O.Table([np.log(1 + z), np.log(M), np.log(r_axis)], np.log(table))
-        oout = O.paint_shell(nside, cat_used, otab, eps_runner, O.Background.from_dict(cosmo_runner))
+        oout = O.paint_shell(nside, cat_used, otab, eps_runner, O.Background.from_dict(cosmo_runner), md_runner=md_runner)
     dt = time.time() - t0
     scale = np.abs(out).max()
     print(f"{name:14s} {kind:9s} nside={nside:4d} N={cat['M'].size:5d} ref+oracle {dt:6.1f}s  "
@@ -153,7 +157,19 @@ def run_case(name, kind, nside, cat, eps_runner, eps_model, table_axes, table, r
         map_in=hmap.astype(np.uint8) if kind == 'baryonify' else np.zeros(0, dtype=np.uint8),
         cosmo_runner=np.array([cosmo_runner[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
         cosmo_model=np.array([cosmo_model[k] for k in ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')]),
+        md_runner=np.array([md_runner[0], 0.0 if md_runner[1] == 'critical' else 1.0]),
+        md_model=np.array([md_model[0], 0.0 if md_model[1] == 'critical' else 1.0]),
         expected=out)
+
+
+def main_massdef():
+    """runner mass definition 500c, model mass definition 200m (HealpixRunner.py:296, BaryonCorrection.py:370)"""
+    pad = 1e-9
+    cat = special_catalog(200, 31, 0.02, 0.08, 13.0, 15.2)
+    ax = syn.table_grid(cat, Nz=5, NM=6, NR=100, pad=pad)
+    run_case('massdef_baryonify', 'baryonify', 64, cat, 14.0, 9.0, ax, syn.displacement_table(*ax), md_runner=(500.0, 'critical'),
+             md_model=(200.0, 'matter'))
+    run_case('massdef_paint', 'paint', 64, cat, 12.0, 0.0, ax, syn.paint_table(*ax), md_runner=(180.0, 'matter'))
 
 
 def main():
@@ -212,5 +228,7 @@ def main_params():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'params':
         main_params()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'massdef':
+        main_massdef()
     else:
         main()

@@ -5,7 +5,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, 'golden')
-GOLDEN_CASES = ['c1_baryonify', 'lowz_baryonify', 'rdelta_baryonify', 'lowz_paint', 'c1_paint', 'param1_paint', 'param2_paint']
+GOLDEN_CASES = ['c1_baryonify', 'lowz_baryonify', 'rdelta_baryonify', 'massdef_baryonify', 'lowz_paint', 'c1_paint', 'massdef_paint',
+                'param1_paint', 'param2_paint']
 COSMO_KEYS = ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')
 
 
@@ -25,6 +26,8 @@ def load_golden(name):
     for k in g['p_keys']:
         g['cat'][k] = g['cat_' + k]
     g['map_in'] = g['map_in'].astype(np.float64)
+    for k in ('md_runner', 'md_model'):          # (Delta, rho_type); fixtures older than the mass-definition cases are 200c
+        g[k] = (float(g[k][0]), 'critical' if g[k][1] == 0 else 'matter') if k in g else (200.0, 'critical')
     return g
 
 
@@ -34,10 +37,10 @@ def oracle_run(g):
     bg_r, bg_m = O.Background.from_dict(g['cosmo_runner']), O.Background.from_dict(g['cosmo_model'])
     if g['kind'] == 'baryonify':
         tab = O.Table(axes, g['tab_values'], g['rdelta'], g['eps_model'], p_keys=g['p_keys'])
-        return O.baryonify_shell(g['nside'], g['map_in'], g['cat'], tab, g['eps_runner'], bg_r, bg_m)
+        return O.baryonify_shell(g['nside'], g['map_in'], g['cat'], tab, g['eps_runner'], bg_r, bg_m, g['md_runner'], g['md_model'])
     with np.errstate(divide='ignore'):
         tab = O.Table(axes, np.log(g['tab_values']), p_keys=g['p_keys'])
-    return O.paint_shell(g['nside'], g['cat'], tab, g['eps_runner'], bg_r)
+    return O.paint_shell(g['nside'], g['cat'], tab, g['eps_runner'], bg_r, md_runner=g['md_runner'])
 
 
 def product_runner(g, acc_f64=None):
@@ -49,9 +52,9 @@ def product_runner(g, acc_f64=None):
     cosmo_model = bfg.utils.Cosmology.from_dict(g['cosmo_model'])
     if g['kind'] == 'baryonify':
         Shell = bfg.utils.LightconeShell(map=g['map_in'], cosmo=g['cosmo_runner'])
-        model = bfg.Profiles.Baryonification2D(None, None, cosmo_model, epsilon_max=g['eps_model'])
+        model = bfg.Profiles.Baryonification2D(None, None, cosmo_model, epsilon_max=g['eps_model'], mass_def=bfg.utils.MassDef(*g['md_model']))
         model.set_table(g['tab_z'], g['tab_M'], g['tab_r'], g['tab_values'], Rdelta_sampling=g['rdelta'])
-        runner = bfg.Runners.BaryonifyShell(Catalog, Shell, g['eps_runner'], model, verbose=False)
+        runner = bfg.Runners.BaryonifyShell(Catalog, Shell, g['eps_runner'], model, mass_def=bfg.utils.MassDef(*g['md_runner']), verbose=False)
     else:
         Shell = bfg.utils.LightconeShell(map=np.zeros(12 * g['nside'] ** 2), cosmo=g['cosmo_runner'])
         if g['p_keys']:
@@ -60,7 +63,7 @@ def product_runner(g, acc_f64=None):
         else:
             model = bfg.utils.TabulatedProfile(None, cosmo_model)
             model.set_table(g['tab_z'], g['tab_M'], g['tab_r'], g['tab_values'])
-        runner = bfg.Runners.PaintProfilesShell(Catalog, Shell, g['eps_runner'], model, verbose=False)
+        runner = bfg.Runners.PaintProfilesShell(Catalog, Shell, g['eps_runner'], model, mass_def=bfg.utils.MassDef(*g['md_runner']), verbose=False)
     runner.acc_f64 = acc_f64
     return runner
 
