@@ -197,3 +197,36 @@ def baryonify_snapshot_device(model, halos_dev, part_ptrs, n_part, L, redshift, 
                                                          C.byref(s), C.c_void_p(int(out_ptrs[0])), C.c_void_p(int(out_ptrs[1])),
                                                          C.c_void_p(int(out_ptrs[2])) if ndim == 3 else None, C.byref(n)))
     return int(n.value)
+
+
+class SnapshotPlan(object):
+    """Resident front-end of the particle-snapshot path (`bfgx_snapshot_plan`): the model and the halo-cell workspace stay
+    on the device between calls."""
+
+    def __init__(self, model, keepalive, ndim, L, redshift, max_halos, device=0, stream=0):
+        self._keep = keepalive
+        self.ndim = int(ndim)
+        h = C.c_void_p()
+        _lib.check(_lib.load().bfgx_snapshot_plan_create(int(device), C.c_void_p(int(stream) or None), C.byref(model), self.ndim,
+                                                        float(L), float(redshift), int(max_halos), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            try:
+                _lib.load().bfgx_snapshot_plan_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def displace(self, halos_dev, n_part, part_ptrs, out_ptrs):
+        """BaryonifySnapshot.process (SnapshotRunner.py:199-262) on device columns; returns the number of displaced pairs"""
+        n = C.c_int64(0)
+        z_in = C.c_void_p(int(part_ptrs[2])) if self.ndim == 3 else None
+        z_out = C.c_void_p(int(out_ptrs[2])) if self.ndim == 3 else None
+        _lib.check(_lib.load().bfgx_snapshot_displace_device(self._h, C.byref(halos_dev), int(n_part), C.c_void_p(int(part_ptrs[0])),
+                                                            C.c_void_p(int(part_ptrs[1])), z_in, C.c_void_p(int(out_ptrs[0])),
+                                                            C.c_void_p(int(out_ptrs[1])), z_out, C.byref(n)))
+        return int(n.value)

@@ -165,6 +165,7 @@ def main_grid(args):
     if snapshot:
         assert world == 1, "--mode snapshot is single-GPU (particles are not sharded)"
         part_out = torch.empty_like(part)
+        splan = engine.SnapshotPlan(model, keep, 3, L, zr, nh, device=local_rank, stream=stream)
     ev = {k: [] for k in (('displace', 'deposit', 'pk') if snapshot else ('deposit', 'pk'))}
     pairs = [0]
 
@@ -175,8 +176,8 @@ def main_grid(args):
 
     def step_snapshot():
         def displace():
-            pairs[0] = engine.baryonify_snapshot_device(model, cat_dev, (part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr()), npart, L, zr,
-                                                        (part_out[0].data_ptr(), part_out[1].data_ptr(), part_out[2].data_ptr()), local_rank, stream)
+            pairs[0] = splan.displace(cat_dev, npart, (part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr()),
+                                      (part_out[0].data_ptr(), part_out[1].data_ptr(), part_out[2].data_ptr()))
         timed('displace', displace)
         timed('deposit', lambda: engine.deposit_particles_device(part_out[0].data_ptr(), part_out[1].data_ptr(), part_out[2].data_ptr(), 0, npart, N,
                                                                  d_edges.data_ptr(), d_out.data_ptr(), 3, local_rank, stream))

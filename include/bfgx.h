@@ -281,7 +281,16 @@ typedef struct bfgx_snapshot {
 
 int bfgx_baryonify_snapshot(const bfgx_grid_catalog *halos_host, const bfgx_model *model, const bfgx_snapshot *snap_host,
                             double *x_out_host, double *y_out_host, double *z_out_host, const bfgx_opts *opts, bfgx_stats *stats);
-/* the same with halo columns, particle columns and outputs resident in HBM (out may not alias in); blocking */
+/* resident form: the model and the halo-cell workspace live in a plan (one per box / redshift / model); all columns and
+ * outputs are device pointers (out may not alias in); blocking (two small read-backs) */
+typedef struct bfgx_snapshot_plan bfgx_snapshot_plan;
+int  bfgx_snapshot_plan_create(int device, void *hip_stream, const bfgx_model *model, int32_t ndim, double L, double redshift,
+                               int64_t max_halos, bfgx_snapshot_plan **out);
+void bfgx_snapshot_plan_destroy(bfgx_snapshot_plan *p);
+int  bfgx_snapshot_displace_device(bfgx_snapshot_plan *p, const bfgx_grid_catalog *halos_dev, int64_t n_part, const double *x_dev,
+                                   const double *y_dev, const double *z_dev, double *x_out_dev, double *y_out_dev, double *z_out_dev,
+                                   int64_t *n_pairs_host);
+/* one call = plan create + displace + destroy */
 int bfgx_baryonify_snapshot_device(int device, void *hip_stream, const bfgx_grid_catalog *halos_dev, const bfgx_model *model,
                                    const bfgx_snapshot *snap_dev, double *x_out_dev, double *y_out_dev, double *z_out_dev,
                                    int64_t *n_pairs_host);

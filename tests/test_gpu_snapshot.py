@@ -98,6 +98,16 @@ def test_snapshot_device_resident_and_errors(gpu):
     torch.cuda.synchronize()
     assert out > 0
     assert np.nanmax(np.abs(o.cpu().numpy().T - host)) <= 1e-13 * g['L']
+    # resident plan: same answer on repeated calls (workspace reuse), entry storage regrown when a later call needs more
+    plan = engine.SnapshotPlan(m, keep, 3, g['L'], g['redshift'], cat['M'].size, 0, torch.cuda.current_stream().cuda_stream)
+    dcat = _lib.make_grid_catalog_dev(cat['M'].size, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
+    for _ in range(2):
+        o.zero_()
+        assert plan.displace(dcat, g['npart'], (p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr()),
+                             (o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())) == out
+        torch.cuda.synchronize()
+        assert np.nanmax(np.abs(o.cpu().numpy().T - host)) <= 1e-13 * g['L']
+    plan.close()
     # particles outside the box are refused (scipy's periodic KDTree raises ValueError there too)
     bad = g['part'].copy()
     bad[5, 0] = -1.0
