@@ -6,7 +6,7 @@
 // Every 1-D transform runs in LDS: decimation in time, bit-reversed on the way in, two radix-2 stages fused per
 // barrier (radix-4 data movement), twiddles from a host-built fp64 table; the r2c pass packs two real lines into one
 // complex transform.  The strided passes move tiles of kFftTile lines that
-// are adjacent in memory, so that global accesses stay contiguous (kFftTile * 16 B) and LDS accesses conflict-free
+// are adjacent in memory, so that global accesses stay contiguous (tile * 16 B) and LDS accesses conflict-free
 // (line index fastest).  N must be a power of two, 8 <= N <= 1024.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -16,7 +16,7 @@
 namespace bfgx {
 
 constexpr int kFftBlock = 256;
-constexpr int kFftTile = 8;           // lines per workgroup in the strided passes
+constexpr int kFftTile = 4;           // lines per workgroup in the strided passes (measured best of 1..16 at 512^3; BFGX_FFT_TILE overrides)
 
 __device__ inline int bit_reverse(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
 
@@ -90,11 +90,11 @@ fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, 
 // data[o * outer_stride + i * stride + kz0 + l]; blockIdx.x = kz tile, blockIdx.y = o.
 __global__ void __launch_bounds__(kFftBlock)
 fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
-                       const double2 *__restrict__ tw)
+                       const double2 *__restrict__ tw, int tile)
 {
     extern __shared__ double2 fbuf[];
-    const int kz0 = blockIdx.x * kFftTile;
-    const int nl = min(kFftTile, nz - kz0);
+    const int kz0 = blockIdx.x * tile;
+    const int nl = min(tile, nz - kz0);
     double2 *base = data + (int64_t)blockIdx.y * outer_stride + kz0;
     for (int t = threadIdx.x; t < N * nl; t += kFftBlock) {
         const int l = t % nl, i = t / nl;
