@@ -61,7 +61,7 @@ def test_make_map_vs_reference_golden(gpu, name):
     assert np.array_equal(out != 0, g['expected'] != 0)            # bin membership is exact (edges, inclusive last edge)
 
 
-@pytest.mark.parametrize('N,Nk', [(32, 12), (64, 180), (128, 60)])
+@pytest.mark.parametrize('N,Nk', [(8, 3), (16, 5), (32, 12), (64, 180), (128, 60)])
 def test_power_spectrum_vs_numpy_restatement(gpu, N, Nk):
     from baryonification_amd.engine import power_spectrum
     from oracle import grid as G
