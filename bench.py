@@ -444,9 +444,9 @@ def main():
                          # what really bounds the kernel: VALU issue.  1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
                          "valu_issue": None if not valu else {"wave_insts_per_launch": valu, "achieved_per_s": valu / (kernels[dom] * 1e-3),
                                                               "peak_per_s": 1024 * 2.4e9 / 4, "frac": valu / (kernels[dom] * 1e-3) / (1024 * 2.4e9 / 4)},
-                         "note": ("tile-owned LDS accumulation, no global atomics: ~20 B of algorithmic HBM traffic per "
-                                  "~180 fp64 VALU ops per (halo, pixel) pair, so the kernel sits far below the HBM roof "
-                                  "and is bounded by fp64 issue/latency at 2 waves/SIMD (DESIGN.md section 4)") if args.algo == 1 else
+                         "note": ("tile-owned LDS accumulation, no global atomics: 12 B of algorithmic HBM traffic against ~300 VALU "
+                                  "instructions per (halo, pixel) pair (fp64 chord, fp32 tail), so the kernel sits far below the HBM "
+                                  "roof; it is bounded by VALU issue and latency at 2 waves/SIMD (valu_issue, DESIGN.md section 4)") if args.algo == 1 else
                                  ("scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "
                                   "(gfx950 memory-side float atomics), not the 8 TB/s stream peak")},
         }
