@@ -122,3 +122,15 @@ def test_multi_rank_gloo_equals_single_process(tmp_path, name, world, exchange):
     ref = oracle_run(load_golden(name))
     # summation order differs (shuffle + two partial sums): float64 round-off only
     assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_five_rank_slice_exchange(tmp_path):
+    """more ranks than a fixture usually sees: interior ranks have windows overlapping both neighbours"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / 'out.npy')
+    mp.spawn(_worker, args=(5, port, 'lowz_baryonify', out_path, 'slices'), nprocs=5, join=True)
+    out = np.load(out_path)
+    ref = oracle_run(load_golden('lowz_baryonify'))
+    assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
