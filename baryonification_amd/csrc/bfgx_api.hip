@@ -474,6 +474,14 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         T.band_nrmin = (const int32_t *)dv;
         if (int rc = plan_upload(p, tband.data(), sizeof(int32_t) * tband.size(), &dv)) return bail(rc);
         T.tile_band = (const int32_t *)dv;
+        std::vector<int32_t> order(tband.size());
+        {   // launch order: tiles by their shortest ring / azimuth slices (~ pixels per tile), descending; stable
+            std::vector<double> weight(tband.size());
+            for (size_t q = 0; q < tband.size(); ++q) { order[q] = (int32_t)q; weight[q] = (double)nrmin[tband[q]] / (double)nphi[tband[q]]; }
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return weight[x] > weight[y]; });
+        }
+        if (int rc = plan_upload(p, order.data(), sizeof(int32_t) * order.size(), &dv)) return bail(rc);
+        T.tile_order = (const int32_t *)dv;
         if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
         p->capacity = 8 * max_halos + 4096;
         if (const char *e = std::getenv("BFGX_ENTRY_CAP")) p->capacity = std::max<int64_t>(16, std::atoll(e));   // tests: force regrowth

@@ -419,6 +419,7 @@ struct Tiling {
     const int32_t *band_nphi;             // [nbands]
     const int32_t *band_nrmin;            // [nbands] shortest ring of the band
     const int32_t *tile_band;             // [ntiles]
+    const int32_t *tile_order;            // [ntiles] launch order of the scatter kernel: largest tiles (in pixels) first
 };
 
 // first ring-local pixel of azimuth slice j: ceil(j nr / nphi); j nr < 2^31 for nside <= 8192
@@ -981,7 +982,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    const int tile = blockIdx.x;
+    const int tile = T.tile_order[blockIdx.x];        // heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
