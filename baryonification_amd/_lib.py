@@ -12,7 +12,7 @@ import numpy as np
 
 BFGX_MAX_EXTRA = 2
 BFGX_MAX_DIM = 3 + BFGX_MAX_EXTRA
-KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin')
+KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin', 'wide')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BFGX_LIB', os.path.join(_HERE, 'csrc', 'libbfgx.so'))   # BFGX_LIB: ablation builds only
@@ -39,7 +39,7 @@ class bfgx_table(C.Structure):
 
 class bfgx_catalog(C.Structure):
     _fields_ = [('n', C.c_int64), ('M', C.c_void_p), ('z', C.c_void_p), ('ra', C.c_void_p), ('dec', C.c_void_p),
-                ('extra', C.c_void_p * BFGX_MAX_EXTRA)]
+                ('extra', C.c_void_p * BFGX_MAX_EXTRA), ('ln1pz', C.c_void_p), ('lnM', C.c_void_p)]
 
 
 class bfgx_model(C.Structure):

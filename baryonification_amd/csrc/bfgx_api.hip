@@ -14,11 +14,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bfgx.h"
 #include "bfgx_cosmo.hpp"
 #include "bfgx_kernels.hpp"
+#include "bfgx_scatter2.hpp"
 #include "bfgx_tables.hpp"
 #include "bfgx_grid.hpp"
 #include "bfgx_fft.hpp"
@@ -88,9 +90,16 @@ struct bfgx_plan {
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
     Tiling tiling;
-    int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_start = nullptr, *tile_cursor = nullptr, *entries = nullptr,
-            *overflow = nullptr;
+    int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
+            *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
     TileRef *tref = nullptr;
+    // fast tiled scatter (bfgx_scatter2.hpp): slim per-halo records + interleaved copies of the table
+    bool fast_ok = false;            // 3-axis table with a uniform ln r axis, small enough to interleave
+    RowRec *rowrec = nullptr;
+    void *pairrec = nullptr;         // PairRecT<float> or PairRecT<double>, whichever the last K0 wrote
+    FbRec *fbrec = nullptr;
+    const float *tab8f = nullptr;
+    const double *tab8d = nullptr;
     unsigned long long *pair_total = nullptr;
     double *tile_sums = nullptr;     // [ntiles][2] per-tile {sum of source values, sum of deposits} of the tiled regrid
     int32_t *regrid_oob = nullptr;   // set when a banded regrid dropped a deposit outside its output window
@@ -232,41 +241,55 @@ static int check_catalog(const bfgx_plan *p, const bfgx_catalog *c)
     return BFGX_OK;
 }
 
-static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool bin)
+static bool use_fast(const bfgx_plan *p) { return p->fast_ok && p->algo == 1; }
+
+// K0.  bin: also reserve the halo's slots in the tile entry lists; f64: precision of the fast kernel's pair records;
+// rec_all: write the full HaloRec of every halo (halo-centric kernels), otherwise only of the wide ones
+static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool bin, bool f64, bool rec_all)
 {
     if (c->n == 0) return BFGX_OK;
     const unsigned grid = (unsigned)((c->n + 255) / 256);
     KernelTimer kt(p, BFGX_K_PREP);
-    int32_t *tc = bin ? p->tile_count : (int32_t *)nullptr;
-    int32_t *tcb = bin ? p->tile_count_b : (int32_t *)nullptr;
-#define BFGX_PREP(NCV)                                                                                              \
-    hipLaunchKernelGGL(halo_prep_kernel<NCV>, dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
-                       c->ra, c->dec, c->extra[0], c->extra[1], p->recs, p->rowsx, fallback4, p->tiling, tc, tcb, p->tref)
-    if (p->NC == 4) BFGX_PREP(4);
-    else if (p->NC == 8) BFGX_PREP(8);
-    else BFGX_PREP(16);
+    PrepOut o;
+    std::memset(&o, 0, sizeof(o));
+    o.rec = p->recs; o.rowsx = p->rowsx;
+    o.fast = (bin && use_fast(p)) ? 1 : 0;
+    o.rec_all = (rec_all || !o.fast) ? 1 : 0;
+    o.rowrec = p->rowrec; o.pairrec = p->pairrec; o.fbrec = p->fbrec;
+    if (bin) { o.tref = p->tref; o.cnt_a = p->tile_count; o.cnt_b = p->tile_count_b; o.cnt_w = p->tile_count_w; }
+    o.ncell_m = p->model.tab.n[1] - 1; o.nrm1 = p->model.tab.n[2] - 1;
+#define BFGX_PREP(NCV, REAL)                                                                                        \
+    hipLaunchKernelGGL((halo_prep_kernel<NCV, REAL>), dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
+                       c->ra, c->dec, c->extra[0], c->extra[1], c->ln1pz, c->lnM, fallback4, p->tiling, o)
+    if (p->NC == 4) { if (f64) BFGX_PREP(4, double); else BFGX_PREP(4, float); }
+    else if (p->NC == 8) BFGX_PREP(8, float);
+    else BFGX_PREP(16, float);
 #undef BFGX_PREP
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
 
+static int launch_place(bfgx_plan *p, const bfgx_catalog *c)
+{
+    const unsigned grid = (unsigned)((c->n + 255) / 256);
+    hipLaunchKernelGGL(tile_place_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
+                       (const TileRef *)p->tref, (const int32_t *)p->tile_start, (const int32_t *)p->tile_count,
+                       (const int32_t *)p->tile_count_b, p->tile_cursor, p->tile_cursor_w, p->entries, p->capacity, p->overflow);
+    HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
 // halo -> tile entry lists: zero counters, K0 (counts), scan, fill
-static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4)
+static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool f64)
 {
     const size_t nt = (size_t)p->tiling.ntiles;
-    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 3 * (nt + 1), p->stream));     // count, count_b, cursor
-    if (int rc = launch_prep(p, c, fallback4, true)) return rc;
+    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 5 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w
+    if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, p->tile_count,
-                       p->tile_count_b, p->tile_start);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, (const int32_t *)p->tile_count,
+                       (const int32_t *)p->tile_count_b, (const int32_t *)p->tile_count_w, p->tile_start);
     HIP_TRY(hipGetLastError());
-    if (c->n > 0) {
-        const unsigned grid = (unsigned)((c->n + 255) / 256);
-        hipLaunchKernelGGL(tile_place_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
-                           (const HaloRec *)p->recs, (const TileRef *)p->tref, (const int32_t *)p->tile_start,
-                           (const int32_t *)p->tile_count, p->tile_cursor, p->entries, p->capacity, p->overflow);
-        HIP_TRY(hipGetLastError());
-    }
+    if (c->n > 0) if (int rc = launch_place(p, c)) return rc;
     return BFGX_OK;
 }
 
@@ -283,27 +306,56 @@ static int launch_scatter(bfgx_plan *p, int64_t n, ACC *out, int64_t *counts)
 }
 
 template <int MODE, typename ACC, int NC>
-static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out)
+static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out, bool wide_only)
 {
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
     const size_t lds = tile_lds_bytes<NC>(p->tiling.BR, p->tiling.W, NCOMP);
     auto kern = tile_scatter_kernel<MODE, ACC, NC>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
+    KernelTimer kt(p, wide_only ? BFGX_K_WIDE : (MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT)));
     hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kWavesPerBlock), lds, p->stream,
                        make_pair_table(p->model.tab), p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
-                       (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total);
+                       (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total,
+                       wide_only ? (const int32_t *)p->tile_count : (const int32_t *)nullptr,
+                       wide_only ? (const int32_t *)p->tile_count_b : (const int32_t *)nullptr, wide_only ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
 
+// fast kernel over the narrow-halo region of every tile (stores the tile)
+template <int MODE, typename ACC, typename real>
+static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
+{
+    constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
+    const size_t lds = tile2_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
+    auto kern = tile_scatter2_kernel<MODE, ACC, real>;
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    Tab8T<real> tb;
+    tb.v = (sizeof(real) == 4) ? (const real *)p->tab8f : (const real *)p->tab8d;
+    tb.r0 = (real)p->model.tab.r0; tb.r1 = (real)p->model.tab.r1; tb.inv_dr = (real)p->model.tab.inv_dr;
+    tb.nr = p->model.tab.n[2]; tb._pad = 0;
+    KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
+    hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
+                       (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
+                       (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
+                       (const int32_t *)p->entries, p->capacity, out, p->pair_total);
+    HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
+// the tiled scatter: fast kernel for the narrow halos (if the table allows) + generic kernel for the rest
 template <int MODE, typename ACC>
 static int launch_tile_scatter(bfgx_plan *p, ACC *out)
 {
-    if (p->NC == 4) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out);
-    if (MODE == MODE_COUNT) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out);      // census never reads the rows
-    if (p->NC == 8) return launch_tile_scatter_nc<MODE, ACC, 8>(p, out);
-    return launch_tile_scatter_nc<MODE, ACC, 16>(p, out);
+    if (use_fast(p)) {
+        using real = typename std::conditional<sizeof(ACC) == 8, double, float>::type;
+        if (int rc = launch_tile_scatter2<MODE, ACC, real>(p, out)) return rc;
+        return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);
+    }
+    if (p->NC == 4) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, false);
+    if (MODE == MODE_COUNT) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, false);      // census never reads the rows
+    if (p->NC == 8) return launch_tile_scatter_nc<MODE, ACC, 8>(p, out, false);
+    return launch_tile_scatter_nc<MODE, ACC, 16>(p, out, false);
 }
 
 // blocking: if the entry list overflowed, grow it to the exact size and redo the fill pass
@@ -320,13 +372,27 @@ static int ensure_entry_capacity(bfgx_plan *p, const bfgx_catalog *c)
     p->entries = (int32_t *)d;
     p->capacity = (int64_t)total + 16;
     HIP_TRY(hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream));
-    HIP_TRY(hipMemsetAsync(p->tile_cursor, 0, sizeof(int32_t) * (size_t)p->tiling.ntiles, p->stream));
-    const unsigned grid = (unsigned)((c->n + 255) / 256);
-    hipLaunchKernelGGL(tile_place_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
-                       (const HaloRec *)p->recs, (const TileRef *)p->tref, (const int32_t *)p->tile_start,
-                       (const int32_t *)p->tile_count, p->tile_cursor, p->entries, p->capacity, p->overflow);
-    HIP_TRY(hipGetLastError());
-    return BFGX_OK;
+    HIP_TRY(hipMemsetAsync(p->tile_cursor, 0, sizeof(int32_t) * 2 * ((size_t)p->tiling.ntiles + 1), p->stream));   // cur_b, cur_w
+    return launch_place(p, c);
+}
+
+// interleaved copy of a 3-axis table for the fast kernel (Tab8T): [(nz-1)(nm-1)][nr-1][8] = {A_c, B_c}, c = 2 bz + bm,
+// A_c = T[iz+bz][im+bm][i], B_c = T[iz+bz][im+bm][i+1] - A_c  (differences formed in fp64)
+template <typename real>
+static void build_tab8(const bfgx_table &t, std::vector<real> &out)
+{
+    const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2];
+    out.resize((nz - 1) * (nm - 1) * (nr - 1) * 8);
+    for (size_t iz = 0; iz + 1 < nz; ++iz)
+        for (size_t im = 0; im + 1 < nm; ++im)
+            for (size_t i = 0; i + 1 < nr; ++i) {
+                real *o = out.data() + ((iz * (nm - 1) + im) * (nr - 1) + i) * 8;
+                for (int c = 0; c < 4; ++c) {
+                    const double *row = t.values + ((iz + (c >> 1)) * nm + im + (c & 1)) * nr;
+                    o[2 * c] = (real)row[i];
+                    o[2 * c + 1] = (real)(row[i + 1] - row[i]);
+                }
+            }
 }
 
 // host-side construction of the tiling tables for one nside
@@ -458,6 +524,30 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             p->rowsx = (RowSetX *)d;
         }
     }
+    {   // fast tiled scatter: possible for a 3-axis table with a uniform ln r axis whose interleaved copy stays small
+        const size_t n8 = (size_t)(t.n[0] - 1) * (size_t)(t.n[1] - 1) * (size_t)(t.n[2] - 1) * 8;
+        p->fast_ok = (t.ndim == 3) && p->model.tab.r_uniform && n8 * sizeof(double) <= ((size_t)256 << 20) && !std::getenv("BFGX_NO_FAST");
+        if (p->fast_ok) {
+            std::vector<float> v32;
+            std::vector<double> v64;
+            build_tab8<float>(t, v32);
+            build_tab8<double>(t, v64);
+            const void *dv = nullptr;
+            if (int rc = plan_upload(p, v32.data(), sizeof(float) * v32.size(), &dv)) return bail(rc);
+            p->tab8f = (const float *)dv;
+            if (int rc = plan_upload(p, v64.data(), sizeof(double) * v64.size(), &dv)) return bail(rc);
+            p->tab8d = (const double *)dv;
+            if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
+            const size_t nh = (size_t)(max_halos > 0 ? max_halos : 1);
+            void *d = nullptr;
+            if (hipMalloc(&d, sizeof(RowRec) * nh) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMalloc(row records) failed"));
+            p->owned.push_back(d); p->rowrec = (RowRec *)d;
+            if (hipMalloc(&d, sizeof(PairRecT<double>) * nh) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMalloc(pair records) failed"));
+            p->owned.push_back(d); p->pairrec = d;
+            if (hipMalloc(&d, sizeof(FbRec) * nh) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMalloc(fallback records) failed"));
+            p->owned.push_back(d); p->fbrec = (FbRec *)d;
+        }
+    }
     {   // tiling tables and halo -> tile binning workspace
         int BR, W;
         std::vector<int32_t> tile0, nphi, nrmin, tband;
@@ -491,12 +581,13 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             return 0;
         };
         void *d0 = nullptr, *d1 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr, *d6 = nullptr;
-        if (dalloc(sizeof(int32_t) * 3 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
+        if (dalloc(sizeof(int32_t) * 5 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
             dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
             dalloc(sizeof(unsigned long long), &d5) || dalloc(sizeof(TileRef) * (size_t)(max_halos > 0 ? max_halos : 1), &d6))
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(binning workspace) failed"));
         p->tile_count = (int32_t *)d0; p->tile_count_b = p->tile_count + (T.ntiles + 1);
-        p->tile_cursor = p->tile_count + 2 * (T.ntiles + 1);
+        p->tile_count_w = p->tile_count + 2 * (T.ntiles + 1);
+        p->tile_cursor = p->tile_count + 3 * (T.ntiles + 1); p->tile_cursor_w = p->tile_count + 4 * (T.ntiles + 1);
         p->tile_start = (int32_t *)d1; p->tref = (TileRef *)d6;
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
         void *d7 = nullptr;
@@ -635,13 +726,13 @@ int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev
     if (p->model.tab.logv) return fail(BFGX_ERR_INVALID, "displacement read-out needs a table with log_values = 0");
     HIP_TRY(hipSetDevice(p->device));
     if (p->algo == 1) {      // tile-owned: every element of offsets is overwritten, no zero-fill needed
-        if (int rc = launch_prep_and_bin(p, cat, 1)) return rc;
+        if (int rc = launch_prep_and_bin(p, cat, 1, acc_f64 != 0)) return rc;
         if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
         if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)offsets_dev);
         return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)offsets_dev);
     }
     if (p->NC != 4) return fail(BFGX_ERR_UNSUPPORTED, "tables with extra parameter axes need algo 1 (LDS tiles)");
-    if (int rc = launch_prep(p, cat, 1, false)) return rc;
+    if (int rc = launch_prep(p, cat, 1, false, false, true)) return rc;
     if (acc_f64) return launch_scatter<MODE_OFFSETS, double>(p, cat->n, (double *)offsets_dev, nullptr);
     return launch_scatter<MODE_OFFSETS, float>(p, cat->n, (float *)offsets_dev, nullptr);
 }
@@ -653,13 +744,13 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
     if (!p->model.tab.logv) return fail(BFGX_ERR_INVALID, "profile painting needs a table with log_values = 1");
     HIP_TRY(hipSetDevice(p->device));
     if (p->algo == 1) {
-        if (int rc = launch_prep_and_bin(p, cat, 0)) return rc;
+        if (int rc = launch_prep_and_bin(p, cat, 0, acc_f64 != 0)) return rc;
         if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
         if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)map_out_dev);
         return launch_tile_scatter<MODE_PAINT, float>(p, (float *)map_out_dev);
     }
     if (p->NC != 4) return fail(BFGX_ERR_UNSUPPORTED, "tables with extra parameter axes need algo 1 (LDS tiles)");
-    if (int rc = launch_prep(p, cat, 0, false)) return rc;
+    if (int rc = launch_prep(p, cat, 0, false, false, true)) return rc;
     if (acc_f64) return launch_scatter<MODE_PAINT, double>(p, cat->n, (double *)map_out_dev, nullptr);
     return launch_scatter<MODE_PAINT, float>(p, cat->n, (float *)map_out_dev, nullptr);
 }
@@ -708,7 +799,7 @@ int bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat, int fallback4
     HIP_TRY(hipSetDevice(p->device));
     if (p->algo == 1 && !counts_dev) {       // census through the tile path (checks the binning is complete)
         HIP_TRY(hipMemsetAsync(p->pair_total, 0, sizeof(unsigned long long), p->stream));
-        if (int rc = launch_prep_and_bin(p, cat, fallback4)) return rc;
+        if (int rc = launch_prep_and_bin(p, cat, fallback4, false)) return rc;
         if (int rc = launch_tile_scatter<MODE_COUNT, float>(p, (float *)nullptr)) return rc;
         unsigned long long tot = 0;
         HIP_TRY(hipMemcpyAsync(&tot, p->pair_total, sizeof(tot), hipMemcpyDeviceToHost, p->stream));
@@ -722,7 +813,7 @@ int bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat, int fallback4
         HIP_TRY(hipMalloc(&tmp, sizeof(int64_t) * (size_t)(cat->n > 0 ? cat->n : 1)));
         counts = (int64_t *)tmp;
     }
-    int rc = launch_prep(p, cat, fallback4, false);
+    int rc = launch_prep(p, cat, fallback4, false, false, true);
     if (!rc) rc = launch_scatter<MODE_COUNT, float>(p, cat->n, (float *)nullptr, counts);
     if (!rc && total_host) {
         std::vector<int64_t> h((size_t)cat->n);

@@ -432,16 +432,32 @@ __device__ inline int ring_len(const Hpx &h, int ring)
 }
 
 // where K0 already reserved this halo's slots in its tiles' entry lists (n <= kRefMax), or n > kRefMax: the
-// placement pass enumerates the tiles again and takes slots from the tiles' second ("many-tile halo") region
+// placement pass enumerates the tiles again (from the span kept in the same bytes) and takes slots by cursor
 constexpr int kRefMax = 4;
 struct TileRef {
-    int32_t tile[kRefMax], slot[kRefMax];
-    int32_t n, _pad[3];
+    union {
+        struct { int32_t tile[kRefMax], slot[kRefMax]; } few;                       // n <= kRefMax
+        struct { int32_t rfirst, rlast, allphi, _p; double flo, fhi; } many;        // n >  kRefMax (never a fallback halo)
+    };
+    int32_t n;
+    int32_t cls;                           // kClsNone / kClsNarrow / kClsWide
+    int32_t _pad[2];
+};
+
+// halo classes of the tiled scatter: narrow discs (|azimuth difference| <= 0.45 for every pixel, no pole inside) go to the
+// fast kernel (bfgx_scatter2.hpp), everything else (polar caps, very low z) to the generic tile kernel below
+enum { kClsNone = 0, kClsNarrow = 1, kClsWide = 2 };
+
+// what the tile enumeration needs of a disc
+struct DiscSpan {
+    int32_t fb, rfirst, rlast, allphi;
+    int32_t fb_ring[4], fb_k[4];
+    double flo, fhi;
 };
 
 // calls f(tile) once for every tile that may hold pixels of the halo's disc (conservative superset)
 template <typename F>
-__device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const HaloRec &r, F &&f)
+__device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const DiscSpan &r, F &&f)
 {
     if (r.fb) {
         int seen[4], ns = 0;
@@ -475,17 +491,64 @@ __device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const HaloRe
     }
 }
 
+// ---------------------------------------------------------------------------------- records of the fast tiled scatter
+// (bfgx_scatter2.hpp).  K0 writes them for narrow halos; the 272-byte HaloRec is only written for wide halos.
+struct alignas(16) RowRec {                // what the ring-row phase needs of a halo
+    double z0, s0, xa, cosr, phi0;         // query_disc pointing: cos / sin colatitude, 1 / sin, cos(radius), azimuth
+    int32_t rfirst, rlast;                 // ring range of the disc (no pole inside: every row is phi-tested)
+    int32_t fb;                            // 1: the rows are the 4 fallback pixels of FbRec (HealpixRunner.py:309-310)
+    int32_t _pad;
+    double cut2;                           // (rcut a / D)^2 in fp64, for the rare ambiguous fp32 cut decisions
+};
+struct FbRec { int32_t ring[4], k[4]; };   // the 4 get_interp_weights neighbours as (ring, index in ring)
+
+template <typename real>
+struct alignas(16) PairRecT {              // what the pair phase needs of a halo, in the precision of the pair math
+    real lnoffD;                           // ln(1/a) [- ln R_model] + ln D:  ln r axis coordinate = ln|u| + lnoffD,  u = diff / D
+    real cut2;                             // (rcut a / D)^2, or a huge number when the disc itself implies r < eps R
+    real aD;                               // a / D: offset / D = d aD u / |u|
+    real cph0, sph0;                       // rotation back by +phi0
+    real w[4];                             // (z, M) corner weights
+    int32_t cell;                          // element offset of the (z, M) cell's block in the interleaved table
+    int32_t oob;                           // (z, M) outside the table -> NaN read-out
+    int32_t hidx, _pad;
+};
+
+// interleaved copy of a 3-axis table for the fast kernel: for every (z, M) cell and radial interval i the 8 numbers
+// {A_c, B_c} (c = 2 bz + bm),  A_c = T[iz + bz][im + bm][i],  B_c = T[..][i + 1] - A_c, so that one pair reads 2 x 16 B (f32)
+template <typename real>
+struct Tab8T {
+    const real *v;                         // [(nz - 1)(nm - 1)][nr - 1][8]
+    real r0, r1, inv_dr;                   // uniform ln r axis
+    int32_t nr, _pad;
+};
+
 // ---------------------------------------------------------------------------------- K0
-// thread per halo.  tile_count != nullptr: also counts the halo into every tile it may touch.
-// NC = 4 * 2^K corner rows (K extra parameter axes): for NC > 4 the rows go to rowsx[j] instead of the record.
-template <int NC>
+// where K0 writes (device pointers; nullptr = not wanted)
+struct PrepOut {
+    HaloRec *rec;                 // wide halos (or every halo when rec_all)
+    RowSetX *rowsx;               // NC > 4
+    RowRec *rowrec;               // fast path records (fast != 0)
+    void *pairrec;                // PairRecT<real> *
+    FbRec *fbrec;
+    TileRef *tref;                // tile binning (nullptr: no binning)
+    int32_t *cnt_a, *cnt_b, *cnt_w;
+    int32_t fast;                 // 1: narrow halos are class kClsNarrow (fast kernel), 0: every halo is kClsWide (generic kernel)
+    int32_t rec_all;              // 1: HaloRec for every halo (halo-centric algo 0)
+    int32_t ncell_m, nrm1;        // (nm - 1), (nr - 1) of the interleaved table
+};
+
+// thread per halo.  NC = 4 * 2^K corner rows (K extra parameter axes): for NC > 4 the rows go to rowsx[j] instead of the
+// record.  `real` = precision of the fast kernel's pair records.  lnz1 / lnM (optional): ln(1 + z), ln M computed by the
+// caller (numpy on the host), so that halos on a table edge are classified exactly as the reference does (README.md:78-80).
+template <int NC, typename real>
 __global__ void __launch_bounds__(256)
 halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ M, const double *__restrict__ z,
                  const double *__restrict__ ra, const double *__restrict__ dec,
                  const double *__restrict__ ex0, const double *__restrict__ ex1,
-                 HaloRec *__restrict__ rec, RowSetX *__restrict__ rowsx, int fallback4, Tiling T,
-                 int32_t *__restrict__ cnt_a, int32_t *__restrict__ cnt_b, TileRef *__restrict__ tref)
+                 const double *__restrict__ lnz1, const double *__restrict__ lnM,
+                 int fallback4, Tiling T, PrepOut o)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
@@ -551,10 +614,11 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         pole = (rlat1 <= 0) || (rlat2 >= kPi);
     }
     // azimuthal extent of the disc (for tile binning): half-width asin(sin r / sin theta0) when no pole inside
+    double dmax;
     {
         const double sr = (radius >= kHalfPi) ? 1.0 : sr_;
         r.allphi = (pole || radius >= kHalfPi || !(sr < 0.999 * r.s0)) ? 1 : 0;
-        const double dmax = r.allphi ? kPi : asin(sr / r.s0);
+        dmax = r.allphi ? kPi : asin(sr / r.s0);
         r.flo = (phq - dmax) * kInvTwoPi;
         r.fhi = (phq + dmax) * kInvTwoPi;
     }
@@ -563,7 +627,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     const double Rmod = (m.same_model ? R : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
     r.rcut = m.tab.eps_model * Rmod;
     r.inv_a = 1.0 / a;
-    const double x0 = fast_log(1.0 / a), x1 = fast_log(M_j);
+    const double x0 = lnz1 ? lnz1[j] : fast_log(1.0 / a), x1 = lnM ? lnM[j] : fast_log(M_j);
     r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
     double wv[NC];
     int32_t ro[NC];
@@ -575,7 +639,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         for (int c = 0; c < 4; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
         RowSetX rx;
         for (int c = 0; c < kNCmax; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
-        rowsx[j] = rx;
+        o.rowsx[j] = rx;
     }
 
     // <4-pixel fallback (HealpixRunner.py:309-310): only discs of a few pixels can qualify -> exact census
@@ -593,35 +657,89 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
             interp_neighbours(h, theta, phi, r.fb_ring, r.fb_k);
         }
     }
-    rec[j] = r;
-    if (cnt_a) {            // tile binning, pass 1: reserve one slot per touched tile
+
+    // class: the fast kernel takes discs without a pole inside whose pixels all lie within 0.45 rad of the halo's azimuth
+    // (fallback pixels: within one pixel of it, so rings of at least 64 pixels are narrow enough)
+    int cls = kClsWide;
+    if (bad) cls = kClsNone;
+    else if (o.fast && NC == 4 && !r.allphi && dmax <= 0.45) {
+        cls = kClsNarrow;
+        if (r.fb) for (int q = 0; q < 4; ++q) if (r.fb_ring[q] < 16 || r.fb_ring[q] > (int)nl4 - 16) cls = kClsWide;
+    }
+    if (o.rec && (o.rec_all || cls == kClsWide)) o.rec[j] = r;
+    if (cls == kClsNarrow) {
+        RowRec rr;
+        rr.z0 = r.z0; rr.s0 = r.s0; rr.xa = r.xa; rr.cosr = r.cosr; rr.phi0 = r.phi0;
+        rr.rfirst = r.rfirst; rr.rlast = r.rlast; rr.fb = r.fb; rr._pad = 0;
+        // r_sep / a < rcut  <=>  |u|^2 < (rcut a / D)^2,  u = diff / D.  Every pixel of the disc has a chord
+        // D |u| <= 2 D sin(radius / 2); when that is below rcut a the cut can never fire (eps_model >= eps_runner)
+        const double cut = r.rcut * a / D;
+        rr.cut2 = cut * cut;
+        double sh, chh;
+        sincos_bounded(0.5 * radius, sh, chh);
+        const bool implied = (m.tab.logv != 0) || (!r.fb && cut >= 2.0 * sh * (1.0 + 1e-9));     // paint: no model-side cut at all
+        o.rowrec[j] = rr;
+        PairRecT<real> pr;
+        pr.lnoffD = (real)(r.lnoff + fast_log(D));
+        pr.cut2 = implied ? (real)3.0e38 : (real)rr.cut2;
+        pr.aD = (real)(a / D);
+        pr.cph0 = (real)r.cph0; pr.sph0 = (real)r.sph0;
+        for (int c = 0; c < 4; ++c) pr.w[c] = (real)wv[c < NC ? c : 0];
+        // cell (iz, im) from the first corner's row offset: ro[0] = (iz nm + im) nr
+        const int nr = o.nrm1 + 1, nm = o.ncell_m + 1;
+        const int row0 = oob ? 0 : ro[0] / nr;
+        const int iz = row0 / nm, im = row0 - iz * nm;
+        pr.cell = (iz * o.ncell_m + im) * o.nrm1 * 8;
+        pr.oob = oob ? 1 : 0;
+        pr.hidx = (int32_t)j; pr._pad = 0;
+        reinterpret_cast<PairRecT<real> *>(o.pairrec)[j] = pr;
+        if (r.fb) {
+            FbRec f;
+            for (int q = 0; q < 4; ++q) { f.ring[q] = r.fb_ring[q]; f.k[q] = r.fb_k[q]; }
+            o.fbrec[j] = f;
+        }
+    }
+    if (o.tref) {           // tile binning, pass 1: reserve one slot per touched tile
+        DiscSpan ds;
+        ds.fb = r.fb; ds.rfirst = r.rfirst; ds.rlast = r.rlast; ds.allphi = r.allphi; ds.flo = r.flo; ds.fhi = r.fhi;
+        for (int q = 0; q < 4; ++q) { ds.fb_ring[q] = r.fb_ring[q]; ds.fb_k[q] = r.fb_k[q]; }
         TileRef ref;
+        int tl[kRefMax] = {0, 0, 0, 0};
         int nt = 0;
-        for_each_tile(h, T, r, [&](int t) { if (nt < kRefMax) ref.tile[nt] = t; ++nt; });
-        ref.n = nt; ref._pad[0] = ref._pad[1] = ref._pad[2] = 0;
+        if (cls != kClsNone) for_each_tile(h, T, ds, [&](int t) { if (nt < kRefMax) tl[nt] = t; ++nt; });
+        ref.n = nt; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
         if (nt <= kRefMax) {
+            // narrow halos take their slot now (returning atomic); wide ones are placed by cursor after the scan
             for (int i = 0; i < kRefMax; ++i) {
-                if (i < nt) ref.slot[i] = atomicAdd(cnt_a + ref.tile[i], 1);
-                else { ref.tile[i] = 0; ref.slot[i] = 0; }
+                ref.few.tile[i] = (i < nt) ? tl[i] : 0;
+                ref.few.slot[i] = 0;
+                if (i < nt) {
+                    if (cls == kClsNarrow) ref.few.slot[i] = atomicAdd(o.cnt_a + tl[i], 1);
+                    else atomicAdd(o.cnt_w + tl[i], 1);
+                }
             }
         } else {
-            for (int i = 0; i < kRefMax; ++i) ref.slot[i] = 0;
-            for_each_tile(h, T, r, [&](int t) { atomicAdd(cnt_b + t, 1); });
+            ref.many.rfirst = r.rfirst; ref.many.rlast = r.rlast; ref.many.allphi = r.allphi; ref.many._p = 0;
+            ref.many.flo = r.flo; ref.many.fhi = r.fhi;
+            int32_t *cnt = (cls == kClsNarrow) ? o.cnt_b : o.cnt_w;
+            for_each_tile(h, T, ds, [&](int t) { atomicAdd(cnt + t, 1); });
         }
-        tref[j] = ref;
+        o.tref[j] = ref;
     }
 }
 
-// exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total
+// exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total.  A tile's list is laid out as
+// [narrow, slots reserved by K0 | narrow, many-tile halos | wide]
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(int ntiles, const int32_t *__restrict__ count, const int32_t *__restrict__ count_b, int32_t *__restrict__ start)
+tile_scan_kernel(int ntiles, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, const int32_t *__restrict__ cnt_w,
+                 int32_t *__restrict__ start)
 {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (ntiles + 1023) / 1024;
     const int lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
     int32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += count[i] + count_b[i];
+    for (int i = lo; i < hi; ++i) s += cnt_a[i] + cnt_b[i] + cnt_w[i];
     part[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -631,30 +749,37 @@ tile_scan_kernel(int ntiles, const int32_t *__restrict__ count, const int32_t *_
         __syncthreads();
     }
     int32_t run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i] + count_b[i]; }
+    for (int i = lo; i < hi; ++i) { start[i] = run; run += cnt_a[i] + cnt_b[i] + cnt_w[i]; }
     if (tid == 1023) start[ntiles] = part[1023];
 }
 
-// tile binning, pass 2 (thread per halo): the slots were reserved by K0, so this is a plain scatter of halo indices;
-// only halos touching more than kRefMax tiles enumerate their tiles again and draw slots from the second region
+// tile binning, pass 2 (thread per halo): narrow halos with reserved slots are a plain scatter of halo indices; the others
+// draw slots from their region's cursor (many-tile halos enumerate their tiles again from the span kept in the TileRef)
 __global__ void __launch_bounds__(256)
-tile_place_kernel(Hpx h, Tiling T, int64_t nhalo, const HaloRec *__restrict__ rec, const TileRef *__restrict__ tref,
-                  const int32_t *__restrict__ start, const int32_t *__restrict__ cnt_a, int32_t *__restrict__ cur_b,
+tile_place_kernel(Hpx h, Tiling T, int64_t nhalo, const TileRef *__restrict__ tref,
+                  const int32_t *__restrict__ start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
+                  int32_t *__restrict__ cur_b, int32_t *__restrict__ cur_w,
                   int32_t *__restrict__ entries, int64_t capacity, int32_t *__restrict__ overflow)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
     const TileRef ref = tref[j];
+    if (ref.cls == kClsNone) return;
+    auto put = [&](int64_t pos) { if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1; };
     if (ref.n <= kRefMax) {
         for (int i = 0; i < kRefMax; ++i) if (i < ref.n) {
-            const int64_t pos = (int64_t)start[ref.tile[i]] + ref.slot[i];
-            if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1;
+            const int t = ref.few.tile[i];
+            if (ref.cls == kClsNarrow) put((int64_t)start[t] + ref.few.slot[i]);
+            else put((int64_t)start[t] + cnt_a[t] + cnt_b[t] + atomicAdd(cur_w + t, 1));
         }
     } else {
-        const HaloRec r = rec[j];
-        for_each_tile(h, T, r, [&](int t) {
-            const int64_t pos = (int64_t)start[t] + cnt_a[t] + atomicAdd(cur_b + t, 1);
-            if (pos < capacity) entries[pos] = (int32_t)j; else *overflow = 1;
+        DiscSpan ds;
+        ds.fb = 0; ds.rfirst = ref.many.rfirst; ds.rlast = ref.many.rlast; ds.allphi = ref.many.allphi;
+        ds.flo = ref.many.flo; ds.fhi = ref.many.fhi;
+        for (int q = 0; q < 4; ++q) { ds.fb_ring[q] = 0; ds.fb_k[q] = 0; }
+        for_each_tile(h, T, ds, [&](int t) {
+            if (ref.cls == kClsNarrow) put((int64_t)start[t] + cnt_a[t] + atomicAdd(cur_b + t, 1));
+            else put((int64_t)start[t] + cnt_a[t] + cnt_b[t] + atomicAdd(cur_w + t, 1));
         });
     }
 }
@@ -978,11 +1103,20 @@ template <int MODE, typename ACC, int NC>
 __global__ void __launch_bounds__(kWave * kWavesPerBlock)
 tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ recs, const RowSetX *__restrict__ rowsx,
                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
-                    ACC *__restrict__ out, unsigned long long *__restrict__ pair_total)
+                    ACC *__restrict__ out, unsigned long long *__restrict__ pair_total,
+                    const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, int addmode)
 {
+    // cnt_a / cnt_b != nullptr: only the wide-halo region of every tile's entry list is processed (the narrow halos went
+    // through the fast kernel, bfgx_scatter2.hpp); addmode: that kernel has already stored the tile, so add to it
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
     const int tile = T.tile_order[blockIdx.x];        // heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
+    {
+        const int64_t skip = cnt_a ? (int64_t)cnt_a[tile] + cnt_b[tile] : 0;
+        int64_t e1x = tile_start[tile + 1];
+        if (e1x > capacity) e1x = capacity;
+        if (addmode && tile_start[tile] + skip >= e1x) return;          // block-uniform: nothing to add to this tile
+    }
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
@@ -1019,7 +1153,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
     }
     __syncthreads();
 
-    const int64_t e0 = tile_start[tile];
+    const int64_t e0 = (int64_t)tile_start[tile] + (cnt_a ? (int64_t)cnt_a[tile] + cnt_b[tile] : 0);
     int64_t e1 = tile_start[tile + 1];
     if (e1 > capacity) e1 = capacity;
     const int ne = (int)(e1 > e0 ? e1 - e0 : 0);
@@ -1206,7 +1340,8 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
         const int n = (ke - ks) * NCOMP;
         ACC *dst = out + NCOMP * (st + ks);
         const double *src = acc + NCOMP * rr * T.W;
-        for (int x = lane; x < (BFGX_ABLATE == 5 ? 0 : n); x += kWave) dst[x] = (ACC)src[x];
+        if (addmode) { for (int x = lane; x < n; x += kWave) dst[x] = (ACC)((double)dst[x] + src[x]); }
+        else { for (int x = lane; x < n; x += kWave) dst[x] = (ACC)src[x]; }
     }
 }
 

@@ -1,0 +1,398 @@
+// Fast tiled scatter for gfx950 (MI355X): K1 (BaryonifyShell halo loop, HealpixRunner.py:306-331) and K3
+// (PaintProfilesShell, HealpixRunner.py:432-445) for the common case -- "narrow" discs (no pole inside, every pixel within
+// 0.45 rad of the halo's azimuth), a 3-axis table with a uniform ln r axis.  Everything else (polar caps, very low
+// redshift, property-axis tables, non-uniform radial axes) stays on the generic tile kernel of bfgx_kernels.hpp, which
+// then only processes the "wide" region of every tile's entry list and adds into the stored tile.
+//
+// One 512-thread workgroup owns one tile (BR rings x <= W pixels) of the output: its accumulators are fp64 planes in LDS
+// (one plane per component, so that consecutive pixels hit consecutive banks), every pixel is stored exactly once.
+// Each wave takes 16 entries (halos touching the tile) at a time:
+//   lanes = entries   -> ring range clipped to the tile, pair records staged in LDS
+//   lanes = ring rows -> the exact fp64 query_disc span of the row (healpix_cxx arithmetic), clipped to the tile; per row
+//                        the differences that the chord needs are formed ONCE in fp64:  dz = z_ring - z0,
+//                        ds = sin(theta_ring) - sin(theta0), x0 = azimuth difference of the row's first pixel
+//   lanes = pairs     -> with u = (v_pix - v_halo) in the frame rotated by -phi0,
+//                            u = (ds - sth (1 - cos x), sth sin x, dz),   x = x0 + j dphi,
+//                        nothing in the pair phase subtracts nearly equal numbers any more, so it runs in the precision of
+//                        the output (fp32 for the default fp32 pix_offsets, fp64 otherwise): r = D |u|, ln r from one
+//                        v_log_f32, the (z, M)-blended radial read-out from ONE 32-byte record of an interleaved copy of the
+//                        table, and the renormalised offset (v + e)/|v + e| - v as a series in e = offset / D.
+// 4 waves/SIMD: <= 128 VGPRs, 76 KB of LDS per workgroup (fp32 pix_offsets).
+#pragma once
+#include "bfgx_kernels.hpp"
+
+namespace bfgx {
+
+constexpr int kW2 = 8;            // waves per workgroup
+constexpr int kChunk2 = 16;       // entries a wave takes at a time
+constexpr int kPlanePad = 11;     // doubles between accumulator planes: plane stride = 22 banks mod 64 (conflict-free flush)
+
+// ---------------------------------------------------------------------------------- pair-phase math per precision
+template <typename real> struct PMath;
+
+template <> struct PMath<float> {
+    static constexpr float kHuge = 1.0e37f;
+    static __device__ inline float rsq(float x)
+    {
+        const float y = __builtin_amdgcn_rsqf(x);
+        return y * __builtin_fmaf(-0.5f * x * y, y, 1.5f);                 // one Newton step
+    }
+    static __device__ inline float half_ln(float x) { return 0.34657359027997264f * __builtin_amdgcn_logf(x); }   // 0.5 ln 2 log2 x
+    static __device__ inline float expv(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
+    // sin x and 1 - cos x for |x| <= 0.5 (truncation < 3e-9 relative)
+    static __device__ inline void sin_omc(float x, float &sn, float &omc)
+    {
+        const float u = x * x;
+        float ps = 1.0f / 362880.0f;
+        ps = __builtin_fmaf(ps, u, -1.0f / 5040.0f);
+        ps = __builtin_fmaf(ps, u, 1.0f / 120.0f);
+        ps = __builtin_fmaf(ps, u, -1.0f / 6.0f);
+        sn = __builtin_fmaf(x * u, ps, x);
+        float pc = -1.0f / 40320.0f;
+        pc = __builtin_fmaf(pc, u, 1.0f / 720.0f);
+        pc = __builtin_fmaf(pc, u, -1.0f / 24.0f);
+        pc = __builtin_fmaf(pc, u, 0.5f);
+        omc = u * pc;
+    }
+    static __device__ inline bool finite(float v) { return __builtin_isfinite(v); }
+};
+
+template <> struct PMath<double> {
+    static constexpr double kHuge = 1.0e37;
+    static __device__ inline double rsq(double x) { return fast_rsq(x); }
+    static __device__ inline double half_ln(double x) { return 0.5 * fast_log(x); }
+    static __device__ inline double expv(double d) { return fast_exp(d); }
+    static __device__ inline void sin_omc(double x, double &sn, double &omc)
+    {
+        double sh, ch;
+        sincos_small(0.5 * x, sh, ch);                                     // half angle: 1 - cos x = 2 sin^2(x/2), no cancellation
+        sn = 2.0 * sh * ch;
+        omc = 2.0 * sh * sh;
+    }
+    static __device__ inline bool finite(double v) { return __builtin_isfinite(v); }
+};
+
+// ---------------------------------------------------------------------------------- LDS records
+// one clipped ring row (a contiguous pixel run inside the tile) as the pair phase sees it
+template <typename real>
+struct alignas(16) RowC2 {
+    uint32_t pk;                  // pair prefix (12 bits) | LDS offset of the first pixel (12) | entry slot (4)
+    real dz, ds, sth;             // z_ring - z0, sin(theta_ring) - sin(theta0), sin(theta_ring)
+    real zf, x0, dphi;            // cos(theta_ring), azimuth difference of the first pixel, 2 pi / nr
+    real _pad;
+};
+
+template <typename real>
+struct Wave2Lds {
+    PairRecT<real> pair[kChunk2];
+    RowC2<real> rows[kWave];
+    unsigned long long mask[kWave + 2];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
+};
+
+template <typename real>
+__host__ __device__ inline size_t tile2_lds_bytes(int BR, int W, int ncomp)
+{
+    size_t a = (size_t)ncomp * ((size_t)BR * W + kPlanePad) * sizeof(double);
+    a = (a + 15) & ~(size_t)15;
+    return a + sizeof(Wave2Lds<real>) * kW2 + 16 + sizeof(TileRow) * (size_t)BR;
+}
+
+// the pixel span [lo, lo + cnt) (mod nr) of a disc in one ring: healpix_cxx query_disc_internal (fact = 0) for a ring
+// inside [irmin, irmax] (narrow discs have no polar-cap rows); same arithmetic as disc_row_span
+__device__ inline void disc_row_span_narrow(int nr, bool shifted, double z, double fnr, double z0, double xa, double cosr,
+                                            double phi0, int &lo, int &cnt)
+{
+    lo = 0; cnt = 0;
+    const double x = (cosr - z * z0) * xa;
+    const double ysq = 1.0 - z * z - x * x;
+    if (!(ysq > 0.0)) return;
+    const double dphi = atan2(sqrt(ysq), x);
+    if (!(dphi > 0.0)) return;
+    const double sh = shifted ? 0.5 : 0.0;
+    const int64_t ip_lo = (int64_t)floor(fnr * (phi0 - dphi) - sh) + 1;
+    const int64_t ip_hi = (int64_t)floor(fnr * (phi0 + dphi) - sh);
+    int64_t c = ip_hi - ip_lo + 1;
+    c = c < 0 ? 0 : (c > nr ? nr : c);
+    cnt = (int)c;
+    int64_t l = ip_lo;
+    if (l < 0) l += nr;
+    if (l >= nr) l -= nr;
+    if (l < 0) l += nr;
+    lo = (int)l;
+}
+
+__device__ inline unsigned long long wave_uniform64(unsigned long long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------------- the kernel
+template <int MODE, typename ACC, typename real>
+__global__ void __launch_bounds__(kWave * kW2, (sizeof(real) == 4 ? 4 : 2))
+tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
+                     const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
+                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
+                     const int32_t *__restrict__ entries, int64_t capacity,
+                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
+    using PM = PMath<real>;
+    const int tile = T.tile_order[blockIdx.x];        // heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
+    const int band = T.tile_band[tile];
+    const int nphi = T.band_nphi[band];
+    const int tj = tile - T.band_tile0[band];
+    const int i0 = 1 + band * T.BR;
+    const int i1 = min(i0 + T.BR, (int)(4 * h.nside));            // exclusive
+    const int PL = T.BR * T.W + kPlanePad;                        // accumulator plane stride (doubles)
+    // LDS accumulators are always fp64: on gfx950 ds_add_f64 runs at ~7 lanes/clk/CU while ds_add_f32 manages only
+    // ~0.3 (profiles/r01_ubench_lds_atomics.txt); ACC is only the type of the global output.
+    double *acc = reinterpret_cast<double *>(smem);
+    size_t off = ((size_t)NCOMP * PL * sizeof(double) + 15) & ~(size_t)15;
+    using WaveLds = Wave2Lds<real>;
+    WaveLds *wl = reinterpret_cast<WaveLds *>(smem + off);
+    off += sizeof(WaveLds) * kW2;
+    int *next_chunk = reinterpret_cast<int *>(smem + off);
+    off += 16;
+    TileRow *rowtab = reinterpret_cast<TileRow *>(smem + off);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    if (MODE != MODE_COUNT)
+        for (int i = tid; i < NCOMP * PL; i += kWave * kW2) acc[i] = 0.0;
+    if (tid == 0) *next_chunk = 0;
+    if (tid < T.BR && i0 + tid < i1) {
+        const int ring = i0 + tid;
+        int64_t st, n64; bool shf;
+        TileRow tr;
+        ring_info_small(h, ring, st, n64, shf);
+        ring_z_sth(h, ring, tr.z, tr.sth);
+        tr.nr = (int)n64; tr.shifted = shf ? 1 : 0;
+        tr.dphi = kTwoPi / (double)tr.nr;
+        tr.fnr = (double)n64 * kInvTwoPi;
+        tr.ks = tile_ks(tj, tr.nr, nphi); tr.ke = tile_ks(tj + 1, tr.nr, nphi);
+        rowtab[tid] = tr;
+    }
+    __syncthreads();
+
+    const int64_t e0 = tile_start[tile];
+    int64_t ne64 = (int64_t)cnt_a[tile] + cnt_b[tile];            // the narrow-halo region of the tile's entry list
+    if (e0 + ne64 > capacity) ne64 = capacity > e0 ? capacity - e0 : 0;
+    const int ne = (int)ne64;
+    const int nchunks = (ne + kChunk2 - 1) / kChunk2;
+    WaveLds &L = wl[wid];
+    unsigned long long npairs = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    while (true) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(next_chunk, 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= nchunks) break;
+
+        // ---- lanes = entries of this chunk
+        int hidx = 0, nrows = 0, ring_lo = 0, isfb = 0;
+        if (lane < kChunk2 && c * kChunk2 + lane < ne) {
+            hidx = entries[e0 + c * kChunk2 + lane];
+            const RowRec &rr = rowrecs[hidx];
+            isfb = rr.fb;
+            if (isfb) nrows = 4;
+            else {
+                const int lo = max(rr.rfirst, i0), hi = min(rr.rlast, i1 - 1);
+                nrows = max(0, hi - lo + 1);
+                ring_lo = lo;
+            }
+            if (MODE != MODE_COUNT) L.pair[lane] = pairrecs[hidx];
+        }
+        const int incl_e = wave_scan_incl(nrows, lane);
+        const int total_rows = __builtin_amdgcn_readlane(incl_e, kWave - 1);
+        const int prefix_e = incl_e - nrows;
+        int pe[kChunk2];                               // entry row prefixes as wave-uniform scalars
+#pragma unroll
+        for (int i = 0; i < kChunk2; ++i) pe[i] = __builtin_amdgcn_readlane(prefix_e, i);
+        __builtin_amdgcn_wave_barrier();
+
+        for (int rb = 0; rb < total_rows; rb += kWave) {
+            // ---- lanes = ring rows (clipped to this tile): up to two pixel runs per row (a disc across phi = 0 in a
+            // tile that spans the whole ring), handled as two passes over the pair phase
+            const int R = rb + lane;
+            int es = 0;                                // largest entry with prefix <= R
+#pragma unroll
+            for (int i = 1; i < kChunk2; ++i) es += (R >= pe[i]) ? 1 : 0;
+            const int eh = __shfl(hidx, es, kWave), ep = __shfl(prefix_e, es, kWave);
+            const int erl = __shfl(ring_lo, es, kWave), efb = __shfl(isfb, es, kWave);
+            int kA = 0, cA = 0, kB = 0, cB = 0, rloc = 0;
+            double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0, sthv = 0.0, zv = 0.0, dphv = 0.0;
+            if (R < total_rows) {
+                const int q = R - ep;
+                const RowRec &rr = rowrecs[eh];
+                if (efb) {
+                    const int ring = fbrecs[eh].ring[q], fk = fbrecs[eh].k[q];
+                    if (ring >= i0 && ring < i1) {
+                        const TileRow &tr = rowtab[ring - i0];
+                        rloc = ring - i0;
+                        zv = tr.z; sthv = tr.sth; dphv = tr.dphi;
+                        dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
+                        if (fk >= tr.ks && fk < tr.ke) {
+                            kA = fk - tr.ks; cA = 1;
+                            x0A = fold_dphi(__builtin_fma((double)fk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
+                        }
+                    }
+                } else {
+                    const int ring = erl + q;
+                    const TileRow &tr = rowtab[ring - i0];
+                    int slo, scnt;
+                    disc_row_span_narrow(tr.nr, tr.shifted != 0, tr.z, tr.fnr, rr.z0, rr.xa, rr.cosr, rr.phi0, slo, scnt);
+                    rloc = ring - i0;
+                    zv = tr.z; sthv = tr.sth; dphv = tr.dphi;
+                    dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
+                    const int nr = tr.nr, ks = tr.ks, ke = tr.ke;
+                    const double xoff = (tr.shifted ? 0.5 : 0.0) * tr.dphi - rr.phi0;
+                    const int endA = min(slo + scnt, nr);
+                    const int firstA = max(slo, ks);
+                    cA = max(0, min(endA, ke) - firstA);
+                    kA = firstA - ks;
+                    x0A = fold_dphi(__builtin_fma((double)firstA, tr.dphi, xoff));
+                    const int endB = slo + scnt - nr;              // > 0 when the row wraps past phi = 2 pi
+                    cB = max(0, min(endB, ke) - ks);
+                    kB = 0;
+                    x0B = fold_dphi(__builtin_fma((double)ks, tr.dphi, xoff));
+                }
+            }
+#pragma unroll 1
+            for (int part = 0; part < 2; ++part) {
+                const int cnt = part ? cB : cA;
+                if (part && !__any(cnt > 0)) break;
+                const int incl = wave_scan_incl(cnt, lane);
+                const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+                npairs += (unsigned long long)total;
+                if (MODE == MODE_COUNT || total == 0) continue;
+                // compact the non-empty rows and mark each row's first pair in a bit mask
+                const int pre = incl - cnt;
+                const int nwords = (total + kWave - 1) / kWave + 1;
+                for (int wI = lane; wI < nwords; wI += kWave) L.mask[wI] = 0ull;
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long nz = __ballot(cnt > 0);
+                if (cnt > 0) {
+                    const int slot = __popcll(nz & lt);
+                    RowC2<real> rc;
+                    rc.pk = (uint32_t)pre | ((uint32_t)(rloc * T.W + (part ? kB : kA)) << 12) | ((uint32_t)es << 24);
+                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.sth = (real)sthv;
+                    rc.zf = (real)zv; rc.x0 = (real)(part ? x0B : x0A); rc.dphi = (real)dphv; rc._pad = (real)0;
+                    L.rows[slot] = rc;
+                    atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
+                }
+                __builtin_amdgcn_wave_barrier();
+
+                // ---- lanes = (halo, pixel) pairs
+                int base = 0;                                      // rows started before the current 64 pairs
+                for (int T0 = 0; T0 < total; T0 += kWave) {
+                    const unsigned long long m = wave_uniform64(L.mask[T0 >> 6]);
+                    const int t = T0 + lane;
+                    const bool act = t < total;
+                    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    const int row = base + below + (int)((m >> lane) & 1ull) - 1;
+                    base += __popcll(m);
+                    const RowC2<real> rc = L.rows[row];
+                    const int jj = t - (int)(rc.pk & 0xFFFu);
+                    const int la = (int)((rc.pk >> 12) & 0xFFFu) + jj;            // LDS pixel offset in the plane
+                    const PairRecT<real> ph = L.pair[(rc.pk >> 24) & 15u];
+                    const real x = __builtin_fma((real)jj, rc.dphi, rc.x0);
+                    real sn, omc;
+                    PM::sin_omc(x, sn, omc);
+                    const real ux = __builtin_fma(-rc.sth, omc, rc.ds), uy = rc.sth * sn, uz = rc.dz;   // (v_pix - v_halo), HealpixRunner.py:314-316 / D
+                    const real u2 = ux * ux + uy * uy + uz * uz;
+                    bool ok = act && (u2 > (real)0) && !ph.oob;    // r_sep = 0: diff / r_sep is NaN -> 0 (:322-323)
+                    if (MODE == MODE_OFFSETS && ph.cut2 < PM::kHuge) {             // BaryonCorrection.py:381-382
+                        bool in = u2 < ph.cut2;
+                        if (sizeof(real) == 4 && act && fabs((double)(u2 - ph.cut2)) <= 4e-6 * (double)ph.cut2) {
+                            // fp32 cannot decide: redo the chord of this one pair in fp64 (rare)
+                            const int rl = la / T.W;
+                            const TileRow &tr = rowtab[rl];
+                            const RowRec &rr = rowrecs[ph.hidx];
+                            const int kk = tr.ks + (la - rl * T.W);
+                            const double xx = fold_dphi(__builtin_fma((double)kk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
+                            double s2, o2;
+                            PMath<double>::sin_omc(xx, s2, o2);
+                            const double wx = (tr.sth - rr.s0) - tr.sth * o2, wy = tr.sth * s2, wz = tr.z - rr.z0;
+                            in = (wx * wx + wy * wy + wz * wz) < rr.cut2;
+                        }
+                        ok = ok && in;
+                    }
+                    const real u2s = (u2 > (real)0) ? u2 : (real)1;
+                    const real rinv = PM::rsq(u2s);                                   // 1 / |u|
+                    const real lx = PM::half_ln(u2s) + ph.lnoffD;                     // ln(r_sep / a) [- ln R when Rdelta]
+                    ok = ok && (lx >= tb.r0) && (lx <= tb.r1);                        // RGI fill_value = nan
+                    const real uu = (lx - tb.r0) * tb.inv_dr;
+                    const int i = max(0, min((int)uu, tb.nr - 2));
+                    const real tr_ = uu - (real)i;
+                    const real *tp = tb.v + ph.cell + i * 8;
+                    real q[8];
+                    if (sizeof(real) == 4) {
+                        const float4 a0 = reinterpret_cast<const float4 *>(tp)[0], a1 = reinterpret_cast<const float4 *>(tp)[1];
+                        q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const double2 a = reinterpret_cast<const double2 *>(tp)[k];
+                            q[2 * k] = a.x; q[2 * k + 1] = a.y;
+                        }
+                    }
+                    real d = (real)0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d = __builtin_fma(ph.w[k], __builtin_fma(tr_, q[2 * k + 1], q[2 * k]), d);
+                    if (MODE == MODE_PAINT) {
+                        const real paint = PM::expv(d);                               // Tabulate.py:286
+                        ok = ok && PM::finite(paint) && paint != (real)0;              // :442
+                        if (ok) atomicAdd(acc + la, (double)paint);                   // ds_add_f64
+                    } else {
+                        ok = ok && PM::finite(d) && d != (real)0;                     // :323
+                        // offset / D = d a diff / (r_sep D) = (d a / D) u / |u|; renormalised (v + e)/|v + e| - v (:326-328) as a
+                        // series in t = 2 v.e + e.e (|v| = 1): e + g (v + e), g = -t/2 + 3 t^2/8 - 5 t^3/16 + 35 t^4/128
+                        const real sc = d * ph.aD * rinv;
+                        const real ex0 = sc * ux, ey0 = sc * uy, ez0 = sc * uz;
+                        const real fx = __builtin_fma(-rc.sth, omc, rc.sth), fy = uy, fz = rc.zf;   // pixel unit vector, rotated frame
+                        const real tt = (real)2 * (fx * ex0 + fy * ey0 + fz * ez0) + (ex0 * ex0 + ey0 * ey0 + ez0 * ez0);
+                        real g = (real)(35.0 / 128.0);
+                        g = __builtin_fma(g, tt, (real)-0.3125);
+                        g = __builtin_fma(g, tt, (real)0.375);
+                        g = __builtin_fma(g, tt, (real)-0.5);
+                        g = g * tt;
+                        const real ex = __builtin_fma(g, fx + ex0, ex0), ey = __builtin_fma(g, fy + ey0, ey0), ez = __builtin_fma(g, fz + ez0, ez0);
+                        if (ok) {
+                            atomicAdd(acc + la, (double)(ex * ph.cph0 - ey * ph.sph0));           // rotate back by +phi0
+                            atomicAdd(acc + PL + la, (double)(ex * ph.sph0 + ey * ph.cph0));
+                            atomicAdd(acc + 2 * PL + la, (double)ez);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+
+    if (MODE == MODE_COUNT) {
+        if (lane == 0 && npairs) atomicAdd(pair_total, npairs);
+        return;
+    }
+    // ---- flush: every pixel of the tile is stored exactly once (plain, row-contiguous stores of [pixel][component])
+    for (int rr = wid; rr < i1 - i0; rr += kW2) {
+        const int ring = i0 + rr;
+        int64_t st, n64; bool shf;
+        ring_info_small(h, ring, st, n64, shf);
+        const TileRow &tr = rowtab[rr];
+        const int n = (tr.ke - tr.ks) * NCOMP;
+        ACC *dst = out + NCOMP * (st + tr.ks);
+        const double *src = acc + rr * T.W;
+        for (int x = lane; x < n; x += kWave) {
+            const int px = (NCOMP == 3) ? (int)(((unsigned)x * 43691u) >> 17) : x;      // x / 3 for x < 2^15
+            const int cc = x - px * NCOMP;
+            dst[x] = (ACC)src[cc * PL + px];
+        }
+    }
+}
+
+}  // namespace bfgx

@@ -77,6 +77,11 @@ typedef struct bfgx_catalog {
     int64_t n;
     const double *M, *z, *ra, *dec;
     const double *extra[BFGX_MAX_EXTRA];  /* cat[p_keys[k]], in table-axis order; NULL if unused */
+    /* optional (NULL = derive on the device): the halo's table coordinates np.log(1 + z) and np.log(M) as the CALLER's
+     * numpy computes them (BaryonCorrection.py:364-366, Tabulate.py:279-281).  README.md:78-80 builds tables whose edges
+     * are exactly the catalog's min/max, so whether an edge halo is inside the table hangs on the last bit of these logs.
+     * The one-shot host API fills them itself when they are NULL. */
+    const double *ln1pz, *lnM;
 } bfgx_catalog;
 
 typedef struct bfgx_model {
@@ -105,7 +110,8 @@ typedef struct bfgx_stats {
 
 /* kernel kinds reported by bfgx_plan_timing_read */
 enum { BFGX_K_PREP = 0, BFGX_K_OFFSETS = 1, BFGX_K_REGRID = 2, BFGX_K_PAINT = 3, BFGX_K_SUM = 4, BFGX_K_COUNT = 5,
-       BFGX_K_BIN = 6, BFGX_NUM_KERNELS = 7 };
+       BFGX_K_BIN = 6, BFGX_K_WIDE = 7, BFGX_NUM_KERNELS = 8 };
+/* OFFSETS / PAINT: the fast tile kernel (narrow discs); WIDE: the generic tile kernel over the wide discs (polar caps, very low z) */
 /* the grid plan reports its kernels under the same kinds: PREP, OFFSETS (halo loop), PAINT, REGRID, SUM */
 
 typedef struct bfgx_plan bfgx_plan;       /* opaque: device, stream, resident model + workspace */
