@@ -93,6 +93,7 @@ struct bfgx_plan {
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
             *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
     TileRef *tref = nullptr;
+    int32_t *wide_tiles = nullptr;   // [1 + ntiles]: number of tiles with wide entries, then those tiles (tile_scan_kernel)
     // fast tiled scatter (bfgx_scatter2.hpp): slim per-halo records + interleaved copies of the table
     bool fast_ok = false;            // 3-axis table with a uniform ln r axis, small enough to interleave
     RowRec *rowrec = nullptr;
@@ -287,7 +288,7 @@ static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback
     if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, (const int32_t *)p->tile_count,
-                       (const int32_t *)p->tile_count_b, (const int32_t *)p->tile_count_w, p->tile_start);
+                       (const int32_t *)p->tile_count_b, (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles);
     HIP_TRY(hipGetLastError());
     if (c->n > 0) if (int rc = launch_place(p, c)) return rc;
     return BFGX_OK;
@@ -313,11 +314,14 @@ static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out, bool wide_only)
     auto kern = tile_scatter_kernel<MODE, ACC, NC>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(p, wide_only ? BFGX_K_WIDE : (MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT)));
-    hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kWavesPerBlock), lds, p->stream,
+    // wide pass: a small fixed grid walks the list of tiles that have wide entries (usually empty or a few polar tiles)
+    const int grid = wide_only ? std::min(p->tiling.ntiles, 512) : p->tiling.ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kWavesPerBlock), lds, p->stream,
                        make_pair_table(p->model.tab), p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
                        (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total,
                        wide_only ? (const int32_t *)p->tile_count : (const int32_t *)nullptr,
-                       wide_only ? (const int32_t *)p->tile_count_b : (const int32_t *)nullptr, wide_only ? 1 : 0);
+                       wide_only ? (const int32_t *)p->tile_count_b : (const int32_t *)nullptr, wide_only ? 1 : 0,
+                       wide_only ? (const int32_t *)p->wide_tiles : (const int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -403,7 +407,7 @@ static void build_tiling(int64_t nside, bool paint, int &BR, int &W, std::vector
     W = std::max(16, std::min(64, pow2_floor(std::max<int64_t>(1, nside / 2))));
     // the painted map needs 8 B of LDS per pixel, pix_offsets 24 B: taller tiles for painting (fewer duplicated ring phases)
     BR = std::max(4, std::min(paint ? 64 : 32, pow2_floor(std::max<int64_t>(1, nside / 8))));
-    if (const char *e = std::getenv("BFGX_TILE_W")) W = std::max(4, std::min(64, std::atoi(e)));      // tuning knobs (W <= 64: kMaskWords)
+    if (const char *e = std::getenv("BFGX_TILE_W")) W = pow2_floor(std::max(4, std::min(64, std::atoi(e))));   // tuning knobs (W <= 64, a power of two)
     if (const char *e = std::getenv("BFGX_TILE_BR")) BR = std::max(1, std::min(64, std::atoi(e)));
     const int64_t nrings = 4 * nside - 1;
     const int nbands = (int)((nrings + BR - 1) / BR);
@@ -590,6 +594,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         p->tile_cursor = p->tile_count + 3 * (T.ntiles + 1); p->tile_cursor_w = p->tile_count + 4 * (T.ntiles + 1);
         p->tile_start = (int32_t *)d1; p->tref = (TileRef *)d6;
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
+        void *d9 = nullptr;
+        if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 1), &d9)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(wide tile list) failed"));
+        p->wide_tiles = (int32_t *)d9;
         void *d7 = nullptr;
         if (dalloc(sizeof(int32_t), &d7)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(flag) failed"));
         p->regrid_oob = (int32_t *)d7;

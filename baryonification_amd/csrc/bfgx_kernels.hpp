@@ -658,11 +658,11 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         }
     }
 
-    // class: the fast kernel takes discs without a pole inside whose pixels all lie within 0.45 rad of the halo's azimuth
+    // class: the fast kernel takes discs without a pole inside whose pixels all lie within 0.40 rad of the halo's azimuth
     // (fallback pixels: within one pixel of it, so rings of at least 64 pixels are narrow enough)
     int cls = kClsWide;
     if (bad) cls = kClsNone;
-    else if (o.fast && NC == 4 && !r.allphi && dmax <= 0.45) {
+    else if (o.fast && NC == 4 && !r.allphi && dmax <= 0.40) {
         cls = kClsNarrow;
         if (r.fb) for (int q = 0; q < 4; ++q) if (r.fb_ring[q] < 16 || r.fb_ring[q] > (int)nl4 - 16) cls = kClsWide;
     }
@@ -732,7 +732,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
 // [narrow, slots reserved by K0 | narrow, many-tile halos | wide]
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int ntiles, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, const int32_t *__restrict__ cnt_w,
-                 int32_t *__restrict__ start)
+                 int32_t *__restrict__ start, int32_t *__restrict__ wide_tiles)
 {
     __shared__ int32_t part[1024];
     const int tid = threadIdx.x;
@@ -751,6 +751,21 @@ tile_scan_kernel(int ntiles, const int32_t *__restrict__ cnt_a, const int32_t *_
     int32_t run = part[tid] - s;
     for (int i = lo; i < hi; ++i) { start[i] = run; run += cnt_a[i] + cnt_b[i] + cnt_w[i]; }
     if (tid == 1023) start[ntiles] = part[1023];
+    // the tiles that have wide entries: wide_tiles[0] = their number, wide_tiles[1..] = the tiles
+    __syncthreads();
+    int32_t nw = 0;
+    for (int i = lo; i < hi; ++i) nw += cnt_w[i] > 0 ? 1 : 0;
+    part[tid] = nw;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int32_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t pos = part[tid] - nw;
+    for (int i = lo; i < hi; ++i) if (cnt_w[i] > 0) wide_tiles[1 + pos++] = i;
+    if (tid == 1023) wide_tiles[0] = part[1023];
 }
 
 // tile binning, pass 2 (thread per halo): narrow halos with reserved slots are a plain scatter of halo indices; the others
@@ -1104,19 +1119,19 @@ __global__ void __launch_bounds__(kWave * kWavesPerBlock)
 tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ recs, const RowSetX *__restrict__ rowsx,
                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total,
-                    const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, int addmode)
+                    const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, int addmode,
+                    const int32_t *__restrict__ wide_tiles)
 {
-    // cnt_a / cnt_b != nullptr: only the wide-halo region of every tile's entry list is processed (the narrow halos went
-    // through the fast kernel, bfgx_scatter2.hpp); addmode: that kernel has already stored the tile, so add to it
+    // wide_tiles != nullptr ("wide pass"): only the wide-halo region of every tile's entry list is processed (the narrow
+    // halos went through the fast kernel, bfgx_scatter2.hpp, which has stored the tile: addmode) and only the tiles that
+    // have wide entries are visited: wide_tiles[0] = their number, wide_tiles[1..] = the tiles (tile_scan_kernel); the grid
+    // is small and fixed, so a catalog without wide halos costs a few microseconds
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    const int tile = T.tile_order[blockIdx.x];        // heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
-    {
-        const int64_t skip = cnt_a ? (int64_t)cnt_a[tile] + cnt_b[tile] : 0;
-        int64_t e1x = tile_start[tile + 1];
-        if (e1x > capacity) e1x = capacity;
-        if (addmode && tile_start[tile] + skip >= e1x) return;          // block-uniform: nothing to add to this tile
-    }
+    const int nvisit = wide_tiles ? wide_tiles[0] : T.ntiles;
+    for (int bi = blockIdx.x; bi < nvisit; bi += gridDim.x) {
+    // full pass: heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
+    const int tile = wide_tiles ? wide_tiles[1 + bi] : T.tile_order[bi];
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
@@ -1328,7 +1343,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
 
     if (MODE == MODE_COUNT) {
         if (lane == 0 && npairs) atomicAdd(pair_total, npairs);
-        return;
+        continue;
     }
     // ---- flush: every pixel of the tile is stored exactly once (plain, row-contiguous stores)
     for (int rr = wid; rr < i1 - i0; rr += kWavesPerBlock) {
@@ -1342,6 +1357,8 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
         const double *src = acc + NCOMP * rr * T.W;
         if (addmode) { for (int x = lane; x < n; x += kWave) dst[x] = (ACC)((double)dst[x] + src[x]); }
         else { for (int x = lane; x < n; x += kWave) dst[x] = (ACC)src[x]; }
+    }
+    __syncthreads();                                   // the LDS tile is reused by the next visit
     }
 }
 

@@ -23,12 +23,17 @@
 
 namespace bfgx {
 
+#ifndef BFGX_ABL2
+#define BFGX_ABL2 0               // >0: timing-only ablation builds (scripts/ablate2.sh); never shipped
+#endif
 constexpr int kW2 = 8;            // waves per workgroup
 constexpr int kChunk2 = 16;       // entries a wave takes at a time
 constexpr int kPlanePad = 11;     // doubles between accumulator planes: plane stride = 22 banks mod 64 (conflict-free flush)
 
 // ---------------------------------------------------------------------------------- pair-phase math per precision
 template <typename real> struct PMath;
+__device__ inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }      // __builtin_fma is the double form
+__device__ inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <> struct PMath<float> {
     static constexpr float kHuge = 1.0e37f;
@@ -76,17 +81,22 @@ template <> struct PMath<double> {
 // one clipped ring row (a contiguous pixel run inside the tile) as the pair phase sees it
 template <typename real>
 struct alignas(16) RowC2 {
-    uint32_t pk;                  // pair prefix (12 bits) | LDS offset of the first pixel (12) | entry slot (4)
-    real dz, ds, sth;             // z_ring - z0, sin(theta_ring) - sin(theta0), sin(theta_ring)
-    real zf, x0, dphi;            // cos(theta_ring), azimuth difference of the first pixel, 2 pi / nr
-    real _pad;
+    uint32_t pk;                  // pair prefix (12 bits) | rotated column of the first pixel (6) | ring in tile (6) | entry slot (4)
+    real dz, ds, x0;              // z_ring - z0, sin(theta_ring) - sin(theta0), azimuth difference of the first pixel
 };
+// what the pair phase needs of a ring of the tile
+template <typename real>
+struct alignas(16) RingC2 { real sth, zf, dphi, _pad; };      // sin / cos of the colatitude, 2 pi / nr
+
+struct EntC2 { int32_t hidx, prefix, ring_lo, fb; };      // one non-empty entry of the chunk (compacted)
 
 template <typename real>
 struct Wave2Lds {
     PairRecT<real> pair[kChunk2];
     RowC2<real> rows[kWave];
     unsigned long long mask[kWave + 2];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
+    EntC2 ent[kChunk2];
+    unsigned long long emask[kChunk2];       // bit R set <=> row R of the chunk is the first row of an entry (<= 16 x 64 rows)
 };
 
 template <typename real>
@@ -94,31 +104,63 @@ __host__ __device__ inline size_t tile2_lds_bytes(int BR, int W, int ncomp)
 {
     size_t a = (size_t)ncomp * ((size_t)BR * W + kPlanePad) * sizeof(double);
     a = (a + 15) & ~(size_t)15;
-    return a + sizeof(Wave2Lds<real>) * kW2 + 16 + sizeof(TileRow) * (size_t)BR;
+    return a + sizeof(Wave2Lds<real>) * kW2 + 16 + (sizeof(TileRow) + sizeof(RingC2<real>)) * (size_t)BR;
+}
+
+// atan(t) for 0 <= t <= 7/16: fdlibm's kernel polynomial (s_atan.c, no argument reduction needed below 7/16), < 1 ulp
+__device__ inline double atan_lt_7_16(double t)
+{
+    const double z = t * t, w = z * z;
+    double s1 = 1.62858201153657823623e-02;
+    s1 = __builtin_fma(s1, w, 4.97687799461593236017e-02);
+    s1 = __builtin_fma(s1, w, 6.66107313738753120669e-02);
+    s1 = __builtin_fma(s1, w, 9.09088713343650656196e-02);
+    s1 = __builtin_fma(s1, w, 1.42857142725034663711e-01);
+    s1 = __builtin_fma(s1, w, 3.33333333333329318027e-01);
+    double s2 = -3.65315727442169155270e-02;
+    s2 = __builtin_fma(s2, w, -5.83357013379057348645e-02);
+    s2 = __builtin_fma(s2, w, -7.69187620504482999495e-02);
+    s2 = __builtin_fma(s2, w, -1.11111104054623557880e-01);
+    s2 = __builtin_fma(s2, w, -1.99999999998764832476e-01);
+    return __builtin_fma(-t, __builtin_fma(z, s1, w * s2), t);
 }
 
 // the pixel span [lo, lo + cnt) (mod nr) of a disc in one ring: healpix_cxx query_disc_internal (fact = 0) for a ring
-// inside [irmin, irmax] (narrow discs have no polar-cap rows); same arithmetic as disc_row_span
+// inside [irmin, irmax] (narrow discs have no polar-cap rows).  x and ysq are formed exactly as disc_row_span forms them;
+// the half-width dphi = atan2(sqrt(ysq), x) of a narrow disc (0 < dphi <= 0.4, so x > 0 and sqrt(ysq) / x <= tan 0.4 < 7/16)
+// comes from an rsq seed + Newton and the fdlibm polynomial instead of libm's sqrt and atan2 (a few ulp either way: the
+// span changes only where fnr (phi0 +- dphi) lies within ~1e-13 of a pixel boundary).  Ring lengths are below 2^31.
 __device__ inline void disc_row_span_narrow(int nr, bool shifted, double z, double fnr, double z0, double xa, double cosr,
                                             double phi0, int &lo, int &cnt)
 {
     lo = 0; cnt = 0;
     const double x = (cosr - z * z0) * xa;
     const double ysq = 1.0 - z * z - x * x;
-    if (!(ysq > 0.0)) return;
-    const double dphi = atan2(sqrt(ysq), x);
+    if (!(ysq > 0.0) || !(x > 0.0)) return;
+    const double t = ysq * fast_rsq(ysq) * fast_rcp(x);              // sqrt(ysq) / x
+    const double dphi = atan_lt_7_16(t);
     if (!(dphi > 0.0)) return;
     const double sh = shifted ? 0.5 : 0.0;
-    const int64_t ip_lo = (int64_t)floor(fnr * (phi0 - dphi) - sh) + 1;
-    const int64_t ip_hi = (int64_t)floor(fnr * (phi0 + dphi) - sh);
-    int64_t c = ip_hi - ip_lo + 1;
-    c = c < 0 ? 0 : (c > nr ? nr : c);
-    cnt = (int)c;
-    int64_t l = ip_lo;
+    const int ip_lo = (int)floor(fnr * (phi0 - dphi) - sh) + 1;
+    const int ip_hi = (int)floor(fnr * (phi0 + dphi) - sh);
+    cnt = max(0, min(ip_hi - ip_lo + 1, nr));
+    int l = ip_lo;
     if (l < 0) l += nr;
     if (l >= nr) l -= nr;
     if (l < 0) l += nr;
-    lo = (int)l;
+    lo = l;
+}
+
+// the model-side cut r_sep / a < eps R of ONE pair, chord in fp64 (only where the fp32 chord is within 4e-6 of the cut)
+__device__ __noinline__ bool exact_cut_test(const TileRow &tr, const RowRec &rr, int kloc)
+{
+    const int kk = tr.ks + kloc;
+    const double xx = fold_dphi(__builtin_fma((double)kk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
+    double sh, ch;
+    sincos_small(0.5 * xx, sh, ch);
+    const double s2 = 2.0 * sh * ch, o2 = 2.0 * sh * sh;
+    const double wx = (tr.sth - rr.s0) - tr.sth * o2, wy = tr.sth * s2, wz = tr.z - rr.z0;
+    return (wx * wx + wy * wy + wz * wz) < rr.cut2;
 }
 
 __device__ inline unsigned long long wave_uniform64(unsigned long long v)
@@ -146,6 +188,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     const int i0 = 1 + band * T.BR;
     const int i1 = min(i0 + T.BR, (int)(4 * h.nside));            // exclusive
     const int PL = T.BR * T.W + kPlanePad;                        // accumulator plane stride (doubles)
+    const int wsh = __ffs(T.W) - 1, wmask = T.W - 1;              // W is a power of two (build_tiling)
     // LDS accumulators are always fp64: on gfx950 ds_add_f64 runs at ~7 lanes/clk/CU while ds_add_f32 manages only
     // ~0.3 (profiles/r01_ubench_lds_atomics.txt); ACC is only the type of the global output.
     double *acc = reinterpret_cast<double *>(smem);
@@ -156,6 +199,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     int *next_chunk = reinterpret_cast<int *>(smem + off);
     off += 16;
     TileRow *rowtab = reinterpret_cast<TileRow *>(smem + off);
+    off += sizeof(TileRow) * (size_t)T.BR;
+    RingC2<real> *ringc = reinterpret_cast<RingC2<real> *>(smem + off);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -174,6 +219,9 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         tr.fnr = (double)n64 * kInvTwoPi;
         tr.ks = tile_ks(tj, tr.nr, nphi); tr.ke = tile_ks(tj + 1, tr.nr, nphi);
         rowtab[tid] = tr;
+        RingC2<real> rg;
+        rg.sth = (real)tr.sth; rg.zf = (real)tr.z; rg.dphi = (real)tr.dphi; rg._pad = (real)0;
+        ringc[tid] = rg;
     }
     __syncthreads();
 
@@ -181,7 +229,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     int64_t ne64 = (int64_t)cnt_a[tile] + cnt_b[tile];            // the narrow-halo region of the tile's entry list
     if (e0 + ne64 > capacity) ne64 = capacity > e0 ? capacity - e0 : 0;
     const int ne = (int)ne64;
-    const int nchunks = (ne + kChunk2 - 1) / kChunk2;
+    const int nchunks = (BFGX_ABL2 == 1) ? 0 : (ne + kChunk2 - 1) / kChunk2;
     WaveLds &L = wl[wid];
     unsigned long long npairs = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -192,39 +240,50 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         c = __builtin_amdgcn_readfirstlane(c);
         if (c >= nchunks) break;
 
-        // ---- lanes = entries of this chunk
-        int hidx = 0, nrows = 0, ring_lo = 0, isfb = 0;
+        // ---- lanes = entries of this chunk; the non-empty ones are compacted into L.ent / L.pair
+        int nrows = 0;
+        EntC2 en;
+        en.hidx = 0; en.prefix = 0; en.ring_lo = 0; en.fb = 0;
         if (lane < kChunk2 && c * kChunk2 + lane < ne) {
-            hidx = entries[e0 + c * kChunk2 + lane];
-            const RowRec &rr = rowrecs[hidx];
-            isfb = rr.fb;
-            if (isfb) nrows = 4;
+            en.hidx = entries[e0 + c * kChunk2 + lane];
+            const RowRec &rr = rowrecs[en.hidx];
+            en.fb = rr.fb;
+            if (en.fb) nrows = 4;
             else {
                 const int lo = max(rr.rfirst, i0), hi = min(rr.rlast, i1 - 1);
                 nrows = max(0, hi - lo + 1);
-                ring_lo = lo;
+                en.ring_lo = lo;
             }
-            if (MODE != MODE_COUNT) L.pair[lane] = pairrecs[hidx];
         }
         const int incl_e = wave_scan_incl(nrows, lane);
         const int total_rows = __builtin_amdgcn_readlane(incl_e, kWave - 1);
-        const int prefix_e = incl_e - nrows;
-        int pe[kChunk2];                               // entry row prefixes as wave-uniform scalars
-#pragma unroll
-        for (int i = 0; i < kChunk2; ++i) pe[i] = __builtin_amdgcn_readlane(prefix_e, i);
+        en.prefix = incl_e - nrows;
+        if (lane < kChunk2) L.emask[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const unsigned long long nzE = __ballot(nrows > 0);
+            if (nrows > 0) {
+                const int slot = __popcll(nzE & lt);
+                L.ent[slot] = en;
+                if (MODE != MODE_COUNT) L.pair[slot] = pairrecs[en.hidx];
+                atomicOr(&L.emask[en.prefix >> 6], 1ull << (en.prefix & 63));
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 
-        for (int rb = 0; rb < total_rows; rb += kWave) {
+        int ebase = 0;                                 // entries started before the current 64 rows
+        for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += kWave) {
             // ---- lanes = ring rows (clipped to this tile): up to two pixel runs per row (a disc across phi = 0 in a
             // tile that spans the whole ring), handled as two passes over the pair phase
             const int R = rb + lane;
-            int es = 0;                                // largest entry with prefix <= R
-#pragma unroll
-            for (int i = 1; i < kChunk2; ++i) es += (R >= pe[i]) ? 1 : 0;
-            const int eh = __shfl(hidx, es, kWave), ep = __shfl(prefix_e, es, kWave);
-            const int erl = __shfl(ring_lo, es, kWave), efb = __shfl(isfb, es, kWave);
+            const unsigned long long em = wave_uniform64(L.emask[rb >> 6]);
+            const int es = ebase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u)) +
+                           (int)((em >> lane) & 1ull) - 1;        // the entry this row belongs to
+            ebase += __popcll(em);
+            const EntC2 ee = L.ent[es];
+            const int eh = ee.hidx, ep = ee.prefix, erl = ee.ring_lo, efb = ee.fb;
             int kA = 0, cA = 0, kB = 0, cB = 0, rloc = 0;
-            double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0, sthv = 0.0, zv = 0.0, dphv = 0.0;
+            double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0;
             if (R < total_rows) {
                 const int q = R - ep;
                 const RowRec &rr = rowrecs[eh];
@@ -233,7 +292,6 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                     if (ring >= i0 && ring < i1) {
                         const TileRow &tr = rowtab[ring - i0];
                         rloc = ring - i0;
-                        zv = tr.z; sthv = tr.sth; dphv = tr.dphi;
                         dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
                         if (fk >= tr.ks && fk < tr.ke) {
                             kA = fk - tr.ks; cA = 1;
@@ -246,7 +304,6 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                     int slo, scnt;
                     disc_row_span_narrow(tr.nr, tr.shifted != 0, tr.z, tr.fnr, rr.z0, rr.xa, rr.cosr, rr.phi0, slo, scnt);
                     rloc = ring - i0;
-                    zv = tr.z; sthv = tr.sth; dphv = tr.dphi;
                     dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
                     const int nr = tr.nr, ks = tr.ks, ke = tr.ke;
                     const double xoff = (tr.shifted ? 0.5 : 0.0) * tr.dphi - rr.phi0;
@@ -268,7 +325,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                 const int incl = wave_scan_incl(cnt, lane);
                 const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
                 npairs += (unsigned long long)total;
-                if (MODE == MODE_COUNT || total == 0) continue;
+                if (MODE == MODE_COUNT || total == 0 || BFGX_ABL2 == 3) continue;
                 // compact the non-empty rows and mark each row's first pair in a bit mask
                 const int pre = incl - cnt;
                 const int nwords = (total + kWave - 1) / kWave + 1;
@@ -278,9 +335,9 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                 if (cnt > 0) {
                     const int slot = __popcll(nz & lt);
                     RowC2<real> rc;
-                    rc.pk = (uint32_t)pre | ((uint32_t)(rloc * T.W + (part ? kB : kA)) << 12) | ((uint32_t)es << 24);
-                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.sth = (real)sthv;
-                    rc.zf = (real)zv; rc.x0 = (real)(part ? x0B : x0A); rc.dphi = (real)dphv; rc._pad = (real)0;
+                    const int krot = ((part ? kB : kA) + (((rloc & 7) << wsh) >> 3)) & wmask;      // ring r is rotated by (r & 7) W / 8 columns
+                    rc.pk = (uint32_t)pre | ((uint32_t)krot << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
+                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)(part ? x0B : x0A);
                     L.rows[slot] = rc;
                     atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
                 }
@@ -288,7 +345,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 
                 // ---- lanes = (halo, pixel) pairs
                 int base = 0;                                      // rows started before the current 64 pairs
-                for (int T0 = 0; T0 < total; T0 += kWave) {
+                for (int T0 = 0; T0 < (BFGX_ABL2 == 4 ? 0 : total); T0 += kWave) {
                     const unsigned long long m = wave_uniform64(L.mask[T0 >> 6]);
                     const int t = T0 + lane;
                     const bool act = t < total;
@@ -297,27 +354,21 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                     base += __popcll(m);
                     const RowC2<real> rc = L.rows[row];
                     const int jj = t - (int)(rc.pk & 0xFFFu);
-                    const int la = (int)((rc.pk >> 12) & 0xFFFu) + jj;            // LDS pixel offset in the plane
+                    const int rl = (int)((rc.pk >> 18) & 63u);
+                    const int la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);   // LDS pixel offset in the plane (rotated column)
                     const PairRecT<real> ph = L.pair[(rc.pk >> 24) & 15u];
-                    const real x = __builtin_fma((real)jj, rc.dphi, rc.x0);
+                    const RingC2<real> rg = ringc[rl];
+                    const real x = fma_((real)jj, rg.dphi, rc.x0);
                     real sn, omc;
                     PM::sin_omc(x, sn, omc);
-                    const real ux = __builtin_fma(-rc.sth, omc, rc.ds), uy = rc.sth * sn, uz = rc.dz;   // (v_pix - v_halo), HealpixRunner.py:314-316 / D
+                    const real ux = fma_(-rg.sth, omc, rc.ds), uy = rg.sth * sn, uz = rc.dz;   // (v_pix - v_halo), HealpixRunner.py:314-316 / D
                     const real u2 = ux * ux + uy * uy + uz * uz;
                     bool ok = act && (u2 > (real)0) && !ph.oob;    // r_sep = 0: diff / r_sep is NaN -> 0 (:322-323)
                     if (MODE == MODE_OFFSETS && ph.cut2 < PM::kHuge) {             // BaryonCorrection.py:381-382
                         bool in = u2 < ph.cut2;
                         if (sizeof(real) == 4 && act && fabs((double)(u2 - ph.cut2)) <= 4e-6 * (double)ph.cut2) {
                             // fp32 cannot decide: redo the chord of this one pair in fp64 (rare)
-                            const int rl = la / T.W;
-                            const TileRow &tr = rowtab[rl];
-                            const RowRec &rr = rowrecs[ph.hidx];
-                            const int kk = tr.ks + (la - rl * T.W);
-                            const double xx = fold_dphi(__builtin_fma((double)kk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
-                            double s2, o2;
-                            PMath<double>::sin_omc(xx, s2, o2);
-                            const double wx = (tr.sth - rr.s0) - tr.sth * o2, wy = tr.sth * s2, wz = tr.z - rr.z0;
-                            in = (wx * wx + wy * wy + wz * wz) < rr.cut2;
+                            in = exact_cut_test(rowtab[rl], rowrecs[ph.hidx], (la - (((rl & 7) << wsh) >> 3)) & wmask);
                         }
                         ok = ok && in;
                     }
@@ -330,7 +381,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                     const real tr_ = uu - (real)i;
                     const real *tp = tb.v + ph.cell + i * 8;
                     real q[8];
-                    if (sizeof(real) == 4) {
+                    if (BFGX_ABL2 == 6) { for (int k = 0; k < 8; ++k) q[k] = tr_ * (real)(k + 1); }
+                    else if (sizeof(real) == 4) {
                         const float4 a0 = reinterpret_cast<const float4 *>(tp)[0], a1 = reinterpret_cast<const float4 *>(tp)[1];
                         q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
                     } else {
@@ -342,7 +394,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                     }
                     real d = (real)0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d = __builtin_fma(ph.w[k], __builtin_fma(tr_, q[2 * k + 1], q[2 * k]), d);
+                    for (int k = 0; k < 4; ++k) d = fma_(ph.w[k], fma_(tr_, q[2 * k + 1], q[2 * k]), d);
                     if (MODE == MODE_PAINT) {
                         const real paint = PM::expv(d);                               // Tabulate.py:286
                         ok = ok && PM::finite(paint) && paint != (real)0;              // :442
@@ -353,15 +405,16 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                         // series in t = 2 v.e + e.e (|v| = 1): e + g (v + e), g = -t/2 + 3 t^2/8 - 5 t^3/16 + 35 t^4/128
                         const real sc = d * ph.aD * rinv;
                         const real ex0 = sc * ux, ey0 = sc * uy, ez0 = sc * uz;
-                        const real fx = __builtin_fma(-rc.sth, omc, rc.sth), fy = uy, fz = rc.zf;   // pixel unit vector, rotated frame
+                        const real fx = fma_(-rg.sth, omc, rg.sth), fy = uy, fz = rg.zf;   // pixel unit vector, rotated frame
                         const real tt = (real)2 * (fx * ex0 + fy * ey0 + fz * ez0) + (ex0 * ex0 + ey0 * ey0 + ez0 * ez0);
                         real g = (real)(35.0 / 128.0);
-                        g = __builtin_fma(g, tt, (real)-0.3125);
-                        g = __builtin_fma(g, tt, (real)0.375);
-                        g = __builtin_fma(g, tt, (real)-0.5);
+                        g = fma_(g, tt, (real)-0.3125);
+                        g = fma_(g, tt, (real)0.375);
+                        g = fma_(g, tt, (real)-0.5);
                         g = g * tt;
-                        const real ex = __builtin_fma(g, fx + ex0, ex0), ey = __builtin_fma(g, fy + ey0, ey0), ez = __builtin_fma(g, fz + ez0, ez0);
-                        if (ok) {
+                        const real ex = fma_(g, fx + ex0, ex0), ey = fma_(g, fy + ey0, ey0), ez = fma_(g, fz + ez0, ez0);
+                        if (BFGX_ABL2 == 5) { if (ok && ex == (real)1.2345e30) acc[la] = (double)(ey + ez); }
+                        else if (ok) {
                             atomicAdd(acc + la, (double)(ex * ph.cph0 - ey * ph.sph0));           // rotate back by +phi0
                             atomicAdd(acc + PL + la, (double)(ex * ph.sph0 + ey * ph.cph0));
                             atomicAdd(acc + 2 * PL + la, (double)ez);
@@ -386,11 +439,12 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         const TileRow &tr = rowtab[rr];
         const int n = (tr.ke - tr.ks) * NCOMP;
         ACC *dst = out + NCOMP * (st + tr.ks);
-        const double *src = acc + rr * T.W;
+        const double *src = acc + (rr << wsh);
+        const int rot = ((rr & 7) << wsh) >> 3;
         for (int x = lane; x < n; x += kWave) {
             const int px = (NCOMP == 3) ? (int)(((unsigned)x * 43691u) >> 17) : x;      // x / 3 for x < 2^15
             const int cc = x - px * NCOMP;
-            dst[x] = (ACC)src[cc * PL + px];
+            dst[x] = (ACC)src[cc * PL + ((px + rot) & wmask)];
         }
     }
 }
