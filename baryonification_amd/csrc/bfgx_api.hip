@@ -21,6 +21,9 @@
 #include "bfgx_cosmo.hpp"
 #include "bfgx_kernels.hpp"
 #include "bfgx_scatter2.hpp"
+#ifndef BFGX_NP
+#define BFGX_NP 1          // pairs per lane per trip of the fast kernel's pair loop
+#endif
 #include "bfgx_tables.hpp"
 #include "bfgx_grid.hpp"
 #include "bfgx_fft.hpp"
@@ -332,7 +335,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
 {
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
     const size_t lds = tile2_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
-    auto kern = tile_scatter2_kernel<MODE, ACC, real>;
+    auto kern = tile_scatter2_kernel<MODE, ACC, real, BFGX_NP>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     Tab8T<real> tb;
     tb.v = (sizeof(real) == 4) ? (const real *)p->tab8f : (const real *)p->tab8d;

@@ -94,7 +94,7 @@ template <typename real>
 struct Wave2Lds {
     PairRecT<real> pair[kChunk2];
     RowC2<real> rows[kWave];
-    unsigned long long mask[kWave + 2];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
+    unsigned long long mask[kWave + 4];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
     EntC2 ent[kChunk2];
     unsigned long long emask[kChunk2];       // bit R set <=> row R of the chunk is the first row of an entry (<= 16 x 64 rows)
 };
@@ -169,8 +169,87 @@ __device__ inline unsigned long long wave_uniform64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// ---------------------------------------------------------------------------------- one (halo, pixel) pair
+template <typename real>
+struct PairEval {
+    real v0, v1, v2;              // MODE_OFFSETS: nw_vec - vec (HealpixRunner.py:326-328); MODE_PAINT: v0 = Paint (:441)
+    int la;                       // LDS pixel offset in the plane (rotated column)
+    int hidx;
+    bool ok, ok_nocut, amb;       // contributes; the same without the model-side cut; fp32 cannot decide the cut
+};
+
+// Branch-free evaluation of pair t of the current row block.
+template <int MODE, typename real>
+__device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const RowC2<real> rc, const PairRecT<real> *pairs,
+                                 const RingC2<real> *ringc, int t, bool act, int wsh, int wmask)
+{
+    using PM = PMath<real>;
+    const int jj = t - (int)(rc.pk & 0xFFFu);
+    const int rl = (int)((rc.pk >> 18) & 63u);
+    o.la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);
+    const PairRecT<real> ph = pairs[(rc.pk >> 24) & 15u];
+    const RingC2<real> rg = ringc[rl];
+    o.hidx = ph.hidx;
+    const real x = fma_((real)jj, rg.dphi, rc.x0);
+    real sn, omc;
+    PM::sin_omc(x, sn, omc);
+    const real ux = fma_(-rg.sth, omc, rc.ds), uy = rg.sth * sn, uz = rc.dz;   // (v_pix - v_halo) / D, HealpixRunner.py:314-316
+    const real u2 = ux * ux + uy * uy + uz * uz;
+    bool ok = act && (u2 > (real)0) && !ph.oob;                    // r_sep = 0: diff / r_sep is NaN -> 0 (:322-323)
+    const real u2s = (u2 > (real)0) ? u2 : (real)1;
+    const real rinv = PM::rsq(u2s);                                // 1 / |u|
+    const real lx = PM::half_ln(u2s) + ph.lnoffD;                  // ln(r_sep / a) [- ln R when Rdelta]
+    ok = ok && (lx >= tb.r0) && (lx <= tb.r1);                     // RGI fill_value = nan
+    const real uu = (lx - tb.r0) * tb.inv_dr;
+    const int i = max(0, min((int)uu, tb.nr - 2));
+    const real tr_ = uu - (real)i;
+    const real *tp = tb.v + ph.cell + i * 8;
+    real q[8];
+    if (BFGX_ABL2 == 6) { for (int k = 0; k < 8; ++k) q[k] = tr_ * (real)(k + 1); }
+    else if (sizeof(real) == 4) {
+        const float4 a0 = reinterpret_cast<const float4 *>(tp)[0], a1 = reinterpret_cast<const float4 *>(tp)[1];
+        q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double2 a = reinterpret_cast<const double2 *>(tp)[k];
+            q[2 * k] = a.x; q[2 * k + 1] = a.y;
+        }
+    }
+    real d = (real)0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d = fma_(ph.w[k], fma_(tr_, q[2 * k + 1], q[2 * k]), d);
+    o.amb = false;
+    if (MODE == MODE_PAINT) {
+        const real paint = PM::expv(d);                            // Tabulate.py:286
+        o.ok = o.ok_nocut = ok && PM::finite(paint) && paint != (real)0;       // :442
+        o.v0 = paint; o.v1 = o.v2 = (real)0;
+        return;
+    }
+    ok = ok && PM::finite(d) && d != (real)0;                      // :323
+    o.ok_nocut = ok;
+    const bool cutting = ph.cut2 < PM::kHuge;                      // BaryonCorrection.py:381-382
+    o.ok = ok && (!cutting || u2 < ph.cut2);
+    if (sizeof(real) == 4) o.amb = ok && cutting && fabsf((float)(u2 - ph.cut2)) <= 4e-6f * (float)ph.cut2;
+    // offset / D = d a diff / (r_sep D) = (d a / D) u / |u|; renormalised (v + e)/|v + e| - v (:326-328) as a
+    // series in t = 2 v.e + e.e (|v| = 1): e + g (v + e), g = -t/2 + 3 t^2/8 - 5 t^3/16 + 35 t^4/128
+    const real sc = d * ph.aD * rinv;
+    const real ex0 = sc * ux, ey0 = sc * uy, ez0 = sc * uz;
+    const real fx = fma_(-rg.sth, omc, rg.sth), fy = uy, fz = rg.zf;   // pixel unit vector, rotated frame
+    const real tt = (real)2 * (fx * ex0 + fy * ey0 + fz * ez0) + (ex0 * ex0 + ey0 * ey0 + ez0 * ez0);
+    real g = (real)(35.0 / 128.0);
+    g = fma_(g, tt, (real)-0.3125);
+    g = fma_(g, tt, (real)0.375);
+    g = fma_(g, tt, (real)-0.5);
+    g = g * tt;
+    const real ex = fma_(g, fx + ex0, ex0), ey = fma_(g, fy + ey0, ey0), ez = fma_(g, fz + ez0, ez0);
+    o.v0 = ex * ph.cph0 - ey * ph.sph0;                            // rotate back by +phi0
+    o.v1 = ex * ph.sph0 + ey * ph.cph0;
+    o.v2 = ez;
+}
+
 // ---------------------------------------------------------------------------------- the kernel
-template <int MODE, typename ACC, typename real>
+template <int MODE, typename ACC, typename real, int NP>
 __global__ void __launch_bounds__(kWave * kW2, (sizeof(real) == 4 ? 4 : 2))
 tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
@@ -233,6 +312,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     WaveLds &L = wl[wid];
     unsigned long long npairs = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    (void)lt;
 
     while (true) {
         int c = 0;
@@ -271,20 +351,24 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         }
         __builtin_amdgcn_wave_barrier();
 
-        int ebase = 0;                                 // entries started before the current 64 rows
-        for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += kWave) {
-            // ---- lanes = ring rows (clipped to this tile): up to two pixel runs per row (a disc across phi = 0 in a
-            // tile that spans the whole ring), handled as two passes over the pair phase
+        // a row can hold two pixel runs only in a tile that spans whole rings (a disc across phi = 0): such tiles (the
+        // innermost polar bands) use 32 row lanes per pass so that the runs of one pass always fit the 64 row slots
+        const int rowlanes = (nphi == 1) ? 32 : kWave;
+        for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += rowlanes) {
+            // ---- lanes = ring rows (clipped to this tile)
             const int R = rb + lane;
-            const unsigned long long em = wave_uniform64(L.emask[rb >> 6]);
-            const int es = ebase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u)) +
-                           (int)((em >> lane) & 1ull) - 1;        // the entry this row belongs to
-            ebase += __popcll(em);
+            const bool rvalid = lane < rowlanes && R < total_rows;
+            int es = 0;                                            // the entry this row belongs to: set bits of emask at or below R, minus 1
+            {
+                const int wq = min(R, total_rows - 1) >> 6, bq = min(R, total_rows - 1) & 63;
+                for (int w = 0; w < wq; ++w) es += __popcll(L.emask[w]);          // at most 15 words; almost always 0 or 1
+                es += __popcll(L.emask[wq] & ((2ull << bq) - 1ull)) - 1;
+            }
             const EntC2 ee = L.ent[es];
             const int eh = ee.hidx, ep = ee.prefix, erl = ee.ring_lo, efb = ee.fb;
-            int kA = 0, cA = 0, kB = 0, cB = 0, rloc = 0;
+            int kA = 0, cA = 0, cB = 0, rloc = 0;
             double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0;
-            if (R < total_rows) {
+            if (rvalid) {
                 const int q = R - ep;
                 const RowRec &rr = rowrecs[eh];
                 if (efb) {
@@ -312,112 +396,102 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                     cA = max(0, min(endA, ke) - firstA);
                     kA = firstA - ks;
                     x0A = fold_dphi(__builtin_fma((double)firstA, tr.dphi, xoff));
-                    const int endB = slo + scnt - nr;              // > 0 when the row wraps past phi = 2 pi
+                    const int endB = slo + scnt - nr;              // > 0 when the row wraps past phi = 2 pi: second run [ks, endB)
                     cB = max(0, min(endB, ke) - ks);
-                    kB = 0;
                     x0B = fold_dphi(__builtin_fma((double)ks, tr.dphi, xoff));
                 }
             }
-#pragma unroll 1
-            for (int part = 0; part < 2; ++part) {
-                const int cnt = part ? cB : cA;
-                if (part && !__any(cnt > 0)) break;
-                const int incl = wave_scan_incl(cnt, lane);
-                const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
-                npairs += (unsigned long long)total;
-                if (MODE == MODE_COUNT || total == 0 || BFGX_ABL2 == 3) continue;
-                // compact the non-empty rows and mark each row's first pair in a bit mask
-                const int pre = incl - cnt;
-                const int nwords = (total + kWave - 1) / kWave + 1;
+            // pairs and row slots of this pass: one scan over (pairs | runs << 16)
+            const int nrun = (cA > 0 ? 1 : 0) + (cB > 0 ? 1 : 0);
+            const int incl = wave_scan_incl((cA + cB) | (nrun << 16), lane);
+            const int tot2 = __builtin_amdgcn_readlane(incl, kWave - 1);
+            const int total = tot2 & 0xFFFF;
+            npairs += (unsigned long long)total;
+            if (MODE == MODE_COUNT || total == 0 || BFGX_ABL2 == 3) continue;
+            {
+                // compact the runs into row slots and mark each run's first pair in a bit mask
+                const int excl = incl - ((cA + cB) | (nrun << 16));
+                const int pre = excl & 0xFFFF, slot = excl >> 16;
+                const int nwords = (total + kWave - 1) / kWave + 2;
                 for (int wI = lane; wI < nwords; wI += kWave) L.mask[wI] = 0ull;
                 __builtin_amdgcn_wave_barrier();
-                const unsigned long long nz = __ballot(cnt > 0);
-                if (cnt > 0) {
-                    const int slot = __popcll(nz & lt);
+                const int rot = ((rloc & 7) << wsh) >> 3;                  // ring r is rotated by (r & 7) W / 8 columns
+                if (cA > 0) {
                     RowC2<real> rc;
-                    const int krot = ((part ? kB : kA) + (((rloc & 7) << wsh) >> 3)) & wmask;      // ring r is rotated by (r & 7) W / 8 columns
-                    rc.pk = (uint32_t)pre | ((uint32_t)krot << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
-                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)(part ? x0B : x0A);
+                    rc.pk = (uint32_t)pre | ((uint32_t)((kA + rot) & wmask) << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
+                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)x0A;
                     L.rows[slot] = rc;
                     atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
                 }
+                if (cB > 0) {
+                    const int preB = pre + cA;
+                    RowC2<real> rc;
+                    rc.pk = (uint32_t)preB | ((uint32_t)(rot & wmask) << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
+                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)x0B;
+                    L.rows[slot + (cA > 0 ? 1 : 0)] = rc;
+                    atomicOr(&L.mask[preB >> 6], 1ull << (preB & 63));
+                }
                 __builtin_amdgcn_wave_barrier();
 
-                // ---- lanes = (halo, pixel) pairs
+                // ---- lanes = (halo, pixel) pairs, NP per lane per trip: the evaluations are straight-line code so that
+                // the LDS reads and table loads of the NP pairs are in flight together
                 int base = 0;                                      // rows started before the current 64 pairs
-                for (int T0 = 0; T0 < (BFGX_ABL2 == 4 ? 0 : total); T0 += kWave) {
-                    const unsigned long long m = wave_uniform64(L.mask[T0 >> 6]);
-                    const int t = T0 + lane;
-                    const bool act = t < total;
+                // the mask word and the row record of the NEXT trip are fetched while this trip computes
+                unsigned long long m_nx = wave_uniform64(L.mask[0]);
+                RowC2<real> rc_nx[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const unsigned long long m = (u == 0) ? m_nx : wave_uniform64(L.mask[u]);
                     const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     const int row = base + below + (int)((m >> lane) & 1ull) - 1;
                     base += __popcll(m);
-                    const RowC2<real> rc = L.rows[row];
-                    const int jj = t - (int)(rc.pk & 0xFFFu);
-                    const int rl = (int)((rc.pk >> 18) & 63u);
-                    const int la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);   // LDS pixel offset in the plane (rotated column)
-                    const PairRecT<real> ph = L.pair[(rc.pk >> 24) & 15u];
-                    const RingC2<real> rg = ringc[rl];
-                    const real x = fma_((real)jj, rg.dphi, rc.x0);
-                    real sn, omc;
-                    PM::sin_omc(x, sn, omc);
-                    const real ux = fma_(-rg.sth, omc, rc.ds), uy = rg.sth * sn, uz = rc.dz;   // (v_pix - v_halo), HealpixRunner.py:314-316 / D
-                    const real u2 = ux * ux + uy * uy + uz * uz;
-                    bool ok = act && (u2 > (real)0) && !ph.oob;    // r_sep = 0: diff / r_sep is NaN -> 0 (:322-323)
-                    if (MODE == MODE_OFFSETS && ph.cut2 < PM::kHuge) {             // BaryonCorrection.py:381-382
-                        bool in = u2 < ph.cut2;
-                        if (sizeof(real) == 4 && act && fabs((double)(u2 - ph.cut2)) <= 4e-6 * (double)ph.cut2) {
-                            // fp32 cannot decide: redo the chord of this one pair in fp64 (rare)
-                            in = exact_cut_test(rowtab[rl], rowrecs[ph.hidx], (la - (((rl & 7) << wsh) >> 3)) & wmask);
-                        }
-                        ok = ok && in;
-                    }
-                    const real u2s = (u2 > (real)0) ? u2 : (real)1;
-                    const real rinv = PM::rsq(u2s);                                   // 1 / |u|
-                    const real lx = PM::half_ln(u2s) + ph.lnoffD;                     // ln(r_sep / a) [- ln R when Rdelta]
-                    ok = ok && (lx >= tb.r0) && (lx <= tb.r1);                        // RGI fill_value = nan
-                    const real uu = (lx - tb.r0) * tb.inv_dr;
-                    const int i = max(0, min((int)uu, tb.nr - 2));
-                    const real tr_ = uu - (real)i;
-                    const real *tp = tb.v + ph.cell + i * 8;
-                    real q[8];
-                    if (BFGX_ABL2 == 6) { for (int k = 0; k < 8; ++k) q[k] = tr_ * (real)(k + 1); }
-                    else if (sizeof(real) == 4) {
-                        const float4 a0 = reinterpret_cast<const float4 *>(tp)[0], a1 = reinterpret_cast<const float4 *>(tp)[1];
-                        q[0] = a0.x; q[1] = a0.y; q[2] = a0.z; q[3] = a0.w; q[4] = a1.x; q[5] = a1.y; q[6] = a1.z; q[7] = a1.w;
-                    } else {
+                    rc_nx[u] = L.rows[(u * kWave + lane < total) ? row : 0];
+                }
+                for (int T0 = 0; T0 < (BFGX_ABL2 == 4 ? 0 : total); T0 += NP * kWave) {
+                    PairEval<real> pv[NP];
+                    RowC2<real> rc_cur[NP];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const double2 a = reinterpret_cast<const double2 *>(tp)[k];
-                            q[2 * k] = a.x; q[2 * k + 1] = a.y;
+                    for (int u = 0; u < NP; ++u) rc_cur[u] = rc_nx[u];
+                    const int T1 = T0 + NP * kWave;
+                    if (T1 < total) {
+#pragma unroll
+                        for (int u = 0; u < NP; ++u) {
+                            const unsigned long long m = wave_uniform64(L.mask[(T1 >> 6) + u]);
+                            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            const int row = base + below + (int)((m >> lane) & 1ull) - 1;
+                            base += __popcll(m);
+                            rc_nx[u] = L.rows[(T1 + u * kWave + lane < total) ? row : 0];
                         }
                     }
-                    real d = (real)0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d = fma_(ph.w[k], fma_(tr_, q[2 * k + 1], q[2 * k]), d);
-                    if (MODE == MODE_PAINT) {
-                        const real paint = PM::expv(d);                               // Tabulate.py:286
-                        ok = ok && PM::finite(paint) && paint != (real)0;              // :442
-                        if (ok) atomicAdd(acc + la, (double)paint);                   // ds_add_f64
-                    } else {
-                        ok = ok && PM::finite(d) && d != (real)0;                     // :323
-                        // offset / D = d a diff / (r_sep D) = (d a / D) u / |u|; renormalised (v + e)/|v + e| - v (:326-328) as a
-                        // series in t = 2 v.e + e.e (|v| = 1): e + g (v + e), g = -t/2 + 3 t^2/8 - 5 t^3/16 + 35 t^4/128
-                        const real sc = d * ph.aD * rinv;
-                        const real ex0 = sc * ux, ey0 = sc * uy, ez0 = sc * uz;
-                        const real fx = fma_(-rg.sth, omc, rg.sth), fy = uy, fz = rg.zf;   // pixel unit vector, rotated frame
-                        const real tt = (real)2 * (fx * ex0 + fy * ey0 + fz * ez0) + (ex0 * ex0 + ey0 * ey0 + ez0 * ez0);
-                        real g = (real)(35.0 / 128.0);
-                        g = fma_(g, tt, (real)-0.3125);
-                        g = fma_(g, tt, (real)0.375);
-                        g = fma_(g, tt, (real)-0.5);
-                        g = g * tt;
-                        const real ex = fma_(g, fx + ex0, ex0), ey = fma_(g, fy + ey0, ey0), ez = fma_(g, fz + ez0, ez0);
-                        if (BFGX_ABL2 == 5) { if (ok && ex == (real)1.2345e30) acc[la] = (double)(ey + ez); }
-                        else if (ok) {
-                            atomicAdd(acc + la, (double)(ex * ph.cph0 - ey * ph.sph0));           // rotate back by +phi0
-                            atomicAdd(acc + PL + la, (double)(ex * ph.sph0 + ey * ph.cph0));
-                            atomicAdd(acc + 2 * PL + la, (double)ez);
+                    for (int u = 0; u < NP; ++u) {
+                        const int t = T0 + u * kWave + lane;
+                        pair_eval<MODE, real>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
+                    }
+                    if (MODE == MODE_OFFSETS && sizeof(real) == 4) {
+                        // pairs whose fp32 chord is within 4e-6 of the model-side cut (BaryonCorrection.py:381-382): decide in fp64 (rare)
+                        bool anyamb = false;
+#pragma unroll
+                        for (int u = 0; u < NP; ++u) anyamb = anyamb || pv[u].amb;
+                        if (__builtin_expect(__any(anyamb), 0)) {
+#pragma unroll
+                            for (int u = 0; u < NP; ++u)
+                                if (pv[u].amb) {
+                                    const int rl = pv[u].la >> wsh;
+                                    const bool in = exact_cut_test(rowtab[rl], rowrecs[pv[u].hidx], (pv[u].la - (((rl & 7) << wsh) >> 3)) & wmask);
+                                    pv[u].ok = pv[u].ok_nocut && in;
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        if (BFGX_ABL2 == 5) { if (pv[u].ok && pv[u].v0 == (real)1.2345e30) acc[pv[u].la] = (double)(pv[u].v1 + pv[u].v2); }
+                        else if (pv[u].ok) {
+                            atomicAdd(acc + pv[u].la, (double)pv[u].v0);                         // ds_add_f64
+                            if (MODE == MODE_OFFSETS) {
+                                atomicAdd(acc + PL + pv[u].la, (double)pv[u].v1);
+                                atomicAdd(acc + 2 * PL + pv[u].la, (double)pv[u].v2);
+                            }
                         }
                     }
                 }
