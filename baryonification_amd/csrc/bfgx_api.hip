@@ -21,6 +21,7 @@
 #include "bfgx_cosmo.hpp"
 #include "bfgx_kernels.hpp"
 #include "bfgx_scatter2.hpp"
+#include "bfgx_regrid2.hpp"
 #ifndef BFGX_NP
 #define BFGX_NP 1          // pairs per lane per trip of the fast kernel's pair loop
 #endif
@@ -716,14 +717,14 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
                                           (long long)wlo, (long long)whi, (long long)p0, (long long)p1);
     const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
     KernelTimer kt(p, BFGX_K_REGRID);
-    const size_t lds = regrid_lds_bytes(p->tiling.BR, p->tiling.W);
+    const size_t lds = regrid2_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
     // virtual bases: the kernel indexes every array by global pixel number
     double *out_base = window_dev - wlo;
     if (acc_f64)
-        hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
+        hipLaunchKernelGGL((tile_regrid2_kernel<double, double>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
                            (const double *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob, (double *)nullptr);
     else
-        hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
+        hipLaunchKernelGGL((tile_regrid2_kernel<float, float>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
                            (const float *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob, (double *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
@@ -773,12 +774,12 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
     {
     KernelTimer kt(p, BFGX_K_REGRID);
     if (p->algo == 1) {
-        const size_t lds = regrid_lds_bytes(p->tiling.BR, p->tiling.W);
+        const size_t lds = regrid2_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
         if (acc_f64)
-            hipLaunchKernelGGL(tile_regrid_kernel<double>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
+            hipLaunchKernelGGL((tile_regrid2_kernel<double, double>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
                                p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob, sums_dev ? p->tile_sums : nullptr);
         else
-            hipLaunchKernelGGL(tile_regrid_kernel<float>, dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
+            hipLaunchKernelGGL((tile_regrid2_kernel<float, float>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
                                p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob, sums_dev ? p->tile_sums : nullptr);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
