@@ -97,6 +97,7 @@ struct bfgx_plan {
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
             *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
     TileRef *tref = nullptr;
+    FarList far;                     // deposits of the gathering regrid that need the generic route (bfgx_regrid2.hpp)
     int32_t *wide_tiles = nullptr;   // [1 + ntiles]: number of tiles with wide entries, then those tiles (tile_scan_kernel)
     // fast tiled scatter (bfgx_scatter2.hpp): slim per-halo records + interleaved copies of the table
     bool fast_ok = false;            // 3-axis table with a uniform ln r axis, small enough to interleave
@@ -598,6 +599,15 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         p->tile_cursor = p->tile_count + 3 * (T.ntiles + 1); p->tile_cursor_w = p->tile_count + 4 * (T.ntiles + 1);
         p->tile_start = (int32_t *)d1; p->tref = (TileRef *)d6;
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
+        {
+            void *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *f3 = nullptr;
+            p->far.cap = (int64_t)1 << 20;
+            if (dalloc(sizeof(unsigned long long), &f0) || dalloc(sizeof(int64_t) * (size_t)p->far.cap, &f1) ||
+                dalloc(sizeof(double) * (size_t)p->far.cap, &f2) || dalloc(sizeof(int32_t), &f3))
+                return bail(fail(BFGX_ERR_HIP, "hipMalloc(far list) failed"));
+            p->far.count = (unsigned long long *)f0; p->far.pix = (int64_t *)f1; p->far.val = (double *)f2; p->far.overflow = (int32_t *)f3;
+            if (hipMemsetAsync(p->far.overflow, 0, sizeof(int32_t), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
+        }
         void *d9 = nullptr;
         if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 1), &d9)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(wide tile list) failed"));
         p->wide_tiles = (int32_t *)d9;
@@ -671,6 +681,14 @@ int bfgx_plan_status(bfgx_plan *p)
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (ov) return fail(BFGX_ERR_INVALID, "halo->tile entry list overflowed its capacity (%lld); results are incomplete",
                         (long long)p->capacity);
+    int32_t fov = 0;
+    HIP_TRY(hipMemcpyAsync(&fov, p->far.overflow, sizeof(fov), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (fov) {
+        HIP_TRY(hipMemsetAsync(p->far.overflow, 0, sizeof(int32_t), p->stream));
+        return fail(BFGX_ERR_INVALID, "the regrid's list of far deposits overflowed (%lld entries): displacements of many pixels over a large "
+                                      "part of the map", (long long)p->far.cap);
+    }
     int32_t oob = 0;
     HIP_TRY(hipMemcpyAsync(&oob, p->regrid_oob, sizeof(oob), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -774,13 +792,17 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
     {
     KernelTimer kt(p, BFGX_K_REGRID);
     if (p->algo == 1) {
-        const size_t lds = regrid2_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
+        // gathering form: every output pixel is stored once by the tile that owns it (no atomics, no zero-fill needed);
+        // the few deposits that need the generic route are listed and added by a small fix-up kernel
+        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
+        HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
         if (acc_f64)
-            hipLaunchKernelGGL((tile_regrid2_kernel<double, double>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob, sums_dev ? p->tile_sums : nullptr);
+            hipLaunchKernelGGL((tile_regrid3_kernel<double, double>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
+                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr);
         else
-            hipLaunchKernelGGL((tile_regrid2_kernel<float, float>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, 0, (int64_t)0, (int64_t)p->hpx.npix, p->regrid_oob, sums_dev ? p->tile_sums : nullptr);
+            hipLaunchKernelGGL((tile_regrid3_kernel<float, float>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
+                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr);
+        hipLaunchKernelGGL(regrid_far_kernel, dim3(64), dim3(256), 0, p->stream, p->far, map_out_dev);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
         if (acc_f64)
@@ -796,9 +818,11 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
         KernelTimer kt(p, BFGX_K_SUM);
         if (p->algo == 1)       // the tiled regrid left per-tile {sum of source values, sum of deposits}: no second pass over the maps
             hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(256), 0, p->stream, p->tiling.ntiles, (const double *)p->tile_sums, sums_dev);
-        else
+        else {
+            HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
             hipLaunchKernelGGL(sum2_kernel, dim3(1024), dim3(256), 0, p->stream, p->hpx.npix, map_in_dev,
                                (const double *)map_out_dev, sums_dev);
+        }
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;

@@ -369,10 +369,12 @@ __device__ inline int axis_find(const double *g, int n, double x)
 // of the corners' radial rows in the device layout [z][M][p0][p1][r] (r innermost).  Returns true when a coordinate is
 // outside its axis (RegularGridInterpolator fill_value = nan).
 template <int NC>
-__device__ inline bool table_corners(const DevTable &tab, double x0, double x1, double xe0, double xe1, double *wv, int32_t *ro)
+__device__ inline bool table_corners(const DevTable &tab, const double *gz, const double *gm, double x0, double x1, double xe0, double xe1,
+                                     double *wv, int32_t *ro)
 {
-    const int iz = axis_find(tab.axis[0], tab.n[0], x0);
-    const int im = axis_find(tab.axis[1], tab.n[1], x1);
+    // gz / gm: the ln(1 + z) and ln M axes (K0 stages them in LDS: the binary searches are chains of dependent loads)
+    const int iz = axis_find(gz, tab.n[0], x0);
+    const int im = axis_find(gm, tab.n[1], x1);
     constexpr int K = (NC == 4) ? 0 : (NC == 8 ? 1 : 2);
     int ip[2] = {0, 0};
     double tp[2] = {0.0, 0.0};
@@ -388,7 +390,6 @@ __device__ inline bool table_corners(const DevTable &tab, double x0, double x1, 
         if (ip[1] >= 0) tp[1] = (xe1 - tab.axis[4][ip[1]]) / (tab.axis[4][ip[1] + 1] - tab.axis[4][ip[1]]);
     }
     if (!oob) {
-        const double *gz = tab.axis[0], *gm = tab.axis[1];
         const double tz = (x0 - gz[iz]) / (gz[iz + 1] - gz[iz]);
         const double tm = (x1 - gm[im]) / (gm[im + 1] - gm[im]);
         const int nr = tab.n[2];
@@ -550,6 +551,16 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ lnz1, const double *__restrict__ lnM,
                  int fallback4, Tiling T, PrepOut o)
 {
+    // the (z, M) axes of the table go to LDS when they are short (the usual 10 - 30 nodes)
+    constexpr int kAxisLds = 128;
+    __shared__ double ax_lds[2 * kAxisLds];
+    const bool ax_in_lds = m.tab.n[0] <= kAxisLds && m.tab.n[1] <= kAxisLds;
+    if (ax_in_lds) {
+        for (int i = threadIdx.x; i < m.tab.n[0]; i += blockDim.x) ax_lds[i] = m.tab.axis[0][i];
+        for (int i = threadIdx.x; i < m.tab.n[1]; i += blockDim.x) ax_lds[kAxisLds + i] = m.tab.axis[1][i];
+        __syncthreads();
+    }
+    const double *gz = ax_in_lds ? ax_lds : m.tab.axis[0], *gm = ax_in_lds ? ax_lds + kAxisLds : m.tab.axis[1];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
     HaloRec r;
@@ -618,7 +629,10 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     {
         const double sr = (radius >= kHalfPi) ? 1.0 : sr_;
         r.allphi = (pole || radius >= kHalfPi || !(sr < 0.999 * r.s0)) ? 1 : 0;
-        dmax = r.allphi ? kPi : asin(sr / r.s0);
+        // (needed to ~1e-6 only: tile binning adds margins, the class threshold has slack) series below 0.35, libm above
+        const double xs = sr / r.s0, xs2 = xs * xs;
+        const double as_small = xs * (1.0 + xs2 * (1.0 / 6.0 + xs2 * (3.0 / 40.0 + xs2 * (15.0 / 336.0 + xs2 * (105.0 / 3456.0)))));
+        dmax = r.allphi ? kPi : (xs < 0.35 ? as_small * (1.0 + 2e-6) : asin(xs));
         r.flo = (phq - dmax) * kInvTwoPi;
         r.fhi = (phq + dmax) * kInvTwoPi;
     }
@@ -631,7 +645,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
     double wv[NC];
     int32_t ro[NC];
-    const bool oob = table_corners<NC>(m.tab, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
+    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
     r.oob = oob ? 1 : 0;
     if (NC == 4) {
         for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
@@ -1653,7 +1667,7 @@ tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC
     }
 }
 
-// sums[0] += sum of tile_sums[2 t], sums[1] += sum of tile_sums[2 t + 1]   (one workgroup)
+// sums[0] = sum of tile_sums[2 t], sums[1] = sum of tile_sums[2 t + 1]   (one workgroup)
 __global__ void __launch_bounds__(256)
 sum_tiles_kernel(int ntiles, const double *__restrict__ tile_sums, double *__restrict__ sums)
 {
@@ -1668,7 +1682,7 @@ sum_tiles_kernel(int ntiles, const double *__restrict__ tile_sums, double *__res
     if (threadIdx.x == 0) {
         double ta = 0.0, tb = 0.0;
         for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; }
-        sums[0] += ta; sums[1] += tb;
+        sums[0] = ta; sums[1] = tb;
     }
 }
 

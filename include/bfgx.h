@@ -151,8 +151,9 @@ int  bfgx_plan_set_algo(bfgx_plan *p, int algo);
 int  bfgx_plan_status(bfgx_plan *p);
 /* K0 + K1: pix_offsets[npix][3] += per-halo unit-vector offsets; acc is f32 or f64 (acc_f64) */
 int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offsets_dev, int acc_f64);
-/* K2: map_out[npix] (f64, must be zeroed by the caller) += bilinear regrid of displaced pixels;
- * sums_dev (optional, double[2], zeroed by caller) receives {sum(map_in), sum(map_out)} */
+/* K2: map_out[npix] (f64) = bilinear regrid of the displaced pixels.  algo 1: every pixel of map_out is stored exactly
+ * once by the tile that owns it (no zero-fill needed); algo 0: map_out += (must be zeroed by the caller).
+ * sums_dev (optional, double[2]) receives {sum(map_in), sum(map_out)} */
 int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
                         double *map_out_dev, double *sums_dev);
 /* Multi-GPU form of K2: the sphere is cut into bands of consecutive rings (contiguous RING pixel ranges); a rank that

@@ -158,7 +158,9 @@ def test_banded_regrid_equals_full_regrid(gpu):
             acc[wlo:whi] += win
         plan.status()                                              # no deposit fell outside a window
         torch.cuda.synchronize()
-        assert (acc - full).abs().max().item() <= 1e-12 * full.abs().max().item()
+        # the full-map regrid gathers per output tile, the banded one scatters per source tile: the fp32 per-pixel geometry of a
+        # pixel seen from two tiles differs by an fp32 ulp of its ~1e-5 rad displacement
+        assert (acc - full).abs().max().item() <= 1e-9 * full.abs().max().item()
     # a window without margin must be reported, not silently corrupt memory
     p0, p1 = int(pb[1]), int(pb[2])
     win = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
