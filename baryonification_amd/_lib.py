@@ -238,6 +238,17 @@ def make_table(axes, values, rdelta_sampling=False, log_values=False, eps_model=
     return t, (axes, values)
 
 
+def table_coords(M, z):
+    """The halo's (z, M) table coordinates exactly as the reference forms them -- np.log(1/a) with a = 1/(1+z)
+    (HealpixRunner.py:295, BaryonCorrection.py:364, Tabulate.py:279) and np.log(M) (:369, :283) -- evaluated by the
+    caller's numpy.  README.md:78-80 builds tables whose edges ARE the catalog's min/max, so the last bit of these logs
+    decides whether an edge halo is inside the table; they travel through the ABI (bfgx_catalog.ln1pz / lnM)."""
+    M, z = f8(M), f8(z)
+    with np.errstate(all='ignore'):
+        a = 1.0 / (1.0 + z)
+        return f8(np.log(1.0 / a)), f8(np.log(M))
+
+
 def make_catalog_host(M, z, ra, dec, extra=()):
     cols = [f8(M), f8(z), f8(ra), f8(dec)] + [f8(e) for e in extra]
     c = bfgx_catalog()
@@ -245,15 +256,21 @@ def make_catalog_host(M, z, ra, dec, extra=()):
     c.M, c.z, c.ra, c.dec = (cols[i].ctypes.data for i in range(4))
     for k, e in enumerate(cols[4:]):
         c.extra[k] = e.ctypes.data
+    lnz, lnM = table_coords(cols[0], cols[1])
+    c.ln1pz, c.lnM = lnz.ctypes.data, lnM.ctypes.data
+    cols += [lnz, lnM]
     return c, cols
 
 
-def make_catalog_dev(n, M_ptr, z_ptr, ra_ptr, dec_ptr, extra_ptrs=()):
+def make_catalog_dev(n, M_ptr, z_ptr, ra_ptr, dec_ptr, extra_ptrs=(), ln1pz_ptr=0, lnM_ptr=0):
+    """ln1pz_ptr / lnM_ptr: device copies of table_coords(M, z) (optional; 0 = the device derives them, which may
+    classify a halo that sits exactly on a table edge differently from numpy)"""
     c = bfgx_catalog()
     c.n = int(n)
     c.M, c.z, c.ra, c.dec = int(M_ptr), int(z_ptr), int(ra_ptr), int(dec_ptr)
     for k, e in enumerate(extra_ptrs):
         c.extra[k] = int(e)
+    c.ln1pz, c.lnM = (int(ln1pz_ptr) or None), (int(lnM_ptr) or None)
     return c
 
 

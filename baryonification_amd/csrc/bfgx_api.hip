@@ -884,11 +884,29 @@ struct Timer {
     double stop(hipStream_t s) { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 };
 
-int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[4 + BFGX_MAX_EXTRA], bfgx_catalog *d)
+constexpr int kCatCols = 4 + BFGX_MAX_EXTRA + 2;       // M, z, ra, dec, extra[2], ln1pz, lnM
+
+int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[kCatCols], bfgx_catalog *d, std::vector<double> &hostlog)
 {
     const int nex = p->model.tab.ndim - 3;
-    const double *src[4 + BFGX_MAX_EXTRA] = {h->M, h->z, h->ra, h->dec, h->extra[0], h->extra[1]};
-    for (int i = 0; i < 4 + nex; ++i) {
+    // the (z, M) table coordinates travel as columns: the caller's numpy values when given, else libm on the host here
+    // (never the device's log: README.md:78-80 puts table edges exactly on the catalog's min/max)
+    const double *lnz = h->ln1pz, *lnm = h->lnM;
+    if (h->n > 0 && (!lnz || !lnm)) {
+        if (!h->M || !h->z) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
+        hostlog.resize(2 * (size_t)h->n);
+        for (int64_t i = 0; i < h->n; ++i) {
+            const double a = 1.0 / (1.0 + h->z[i]);                          // HealpixRunner.py:295
+            hostlog[i] = std::log(1.0 / a);                                  // BaryonCorrection.py:364
+            hostlog[(size_t)h->n + i] = std::log(h->M[i]);                   // :369
+        }
+        if (!lnz) lnz = hostlog.data();
+        if (!lnm) lnm = hostlog.data() + h->n;
+    }
+    const double *src[kCatCols] = {h->M, h->z, h->ra, h->dec, nex > 0 ? h->extra[0] : nullptr, nex > 1 ? h->extra[1] : nullptr, lnz, lnm};
+    for (int i = 0; i < kCatCols; ++i) {
+        const bool wanted = i < 4 + nex || i >= 4 + BFGX_MAX_EXTRA;
+        if (!wanted) continue;
         if (h->n > 0 && !src[i]) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
         if (cols[i].alloc(sizeof(double) * (size_t)h->n)) return fail(BFGX_ERR_HIP, "hipMalloc(catalog) failed");
         if (h->n > 0) HIP_TRY(hipMemcpyAsync(cols[i].p, src[i], sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, p->stream));
@@ -898,6 +916,7 @@ int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[4 + BFGX_MAX
     d->M = (const double *)cols[0].p; d->z = (const double *)cols[1].p;
     d->ra = (const double *)cols[2].p; d->dec = (const double *)cols[3].p;
     for (int k = 0; k < nex; ++k) d->extra[k] = (const double *)cols[4 + k].p;
+    d->ln1pz = (const double *)cols[4 + BFGX_MAX_EXTRA].p; d->lnM = (const double *)cols[5 + BFGX_MAX_EXTRA].p;
     return BFGX_OK;
 }
 
@@ -920,11 +939,12 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
 
     const size_t npix = (size_t)p->hpx.npix;
     const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
-    DevBuf cols[4 + BFGX_MAX_EXTRA], d_in, d_out, d_off, d_sums;
+    DevBuf cols[kCatCols], d_in, d_out, d_off, d_sums;
+    std::vector<double> hostlog;
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);
-    if (int rc = upload_catalog(p, cat, cols, &dcat)) return rc;
+    if (int rc = upload_catalog(p, cat, cols, &dcat, hostlog)) return rc;
     if (d_in.alloc(npix * sizeof(double)) || d_out.alloc(npix * sizeof(double)) || d_off.alloc(acc_bytes) || d_sums.alloc(2 * sizeof(double)))
         return fail(BFGX_ERR_HIP, "hipMalloc(map buffers) failed");
     HIP_TRY(hipMemcpyAsync(d_in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, p->stream));
@@ -974,11 +994,12 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     if (o.algo == 0 || o.algo == 1) p->algo = o.algo; else return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
 
     const size_t npix = (size_t)p->hpx.npix;
-    DevBuf cols[4 + BFGX_MAX_EXTRA], d_out;
+    DevBuf cols[kCatCols], d_out;
+    std::vector<double> hostlog;
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);
-    if (int rc = upload_catalog(p, cat, cols, &dcat)) return rc;
+    if (int rc = upload_catalog(p, cat, cols, &dcat, hostlog)) return rc;
     if (d_out.alloc(npix * sizeof(double))) return fail(BFGX_ERR_HIP, "hipMalloc(map) failed");
     const double ms_h2d = t.stop(p->stream);
     t.start(p->stream);

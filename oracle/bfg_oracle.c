@@ -428,6 +428,9 @@ double bfgo_rgi_eval(int ndim, const int *n, const double *const *axes, const do
  *   and BaryonCorrection.py:370):
  *     M[j], a[j] = 1/(1+z_j), R[j] = mass_def.get_radius(cosmo, M_j, a_j) [physical Mpc],
  *     D[j] = D_a(z_j) [physical Mpc], Rmod[j] = model.mass_def.get_radius(model.cosmo, M_j, a_j)/a_j,
+ *     lnz1[j] = np.log(1/a_j), lnM[j] = np.log(M_j): the table coordinates of BaryonCorrection.py:364, :369 evaluated by
+ *     the caller's numpy (README.md:78-80 puts table edges exactly on the catalog's min/max, so the last bit of these logs
+ *     decides whether an edge halo reads NaN); NULL -> libm log here,
  *     extra[k][j] = cat[p_keys[k]][j]
  *   table: displacement table (ndim = 3 + nextra), axes ln(1+z), ln M, ln r | ln(r/Rdelta), params
  *   out: pix_offsets [npix][3], ACCUMULATED INTO (caller zero-initialises), float64
@@ -436,6 +439,7 @@ double bfgo_rgi_eval(int ndim, const int *n, const double *const *axes, const do
 i64 bfgo_baryonify_offsets(i64 nside, i64 nhalo,
                            const double *ra, const double *dec, const double *M,
                            const double *a, const double *R, const double *D, const double *Rmod,
+                           const double *lnz1, const double *lnM,
                            int nextra, const double *const *extra,
                            int ndim, const int *tn, const double *const *taxes, const double *tvalues,
                            int rdelta_sampling, double eps_runner, double eps_model,
@@ -464,8 +468,8 @@ i64 bfgo_baryonify_offsets(i64 nside, i64 nhalo,
         total += npx;
 
         double x[BFGO_MAXDIM];
-        x[0] = log(1.0 / a_j);                                        /* BaryonCorrection.py:364 */
-        x[1] = log(M_j);                                              /* :369 */
+        x[0] = lnz1 ? lnz1[j] : log(1.0 / a_j);                       /* BaryonCorrection.py:364: np.log(1/a), as the caller's numpy gives it */
+        x[1] = lnM ? lnM[j] : log(M_j);                               /* :369 */
         for (int k = 3; k < ndim; ++k) x[k] = extra[k - 3][j];
         double Rc = Rmod[j];                                          /* :370 */
 
@@ -537,6 +541,7 @@ void bfgo_regrid_range(i64 nside, i64 p0, i64 p1, const double *orig_map, const 
 i64 bfgo_paint(i64 nside, i64 nhalo,
                const double *ra, const double *dec, const double *M,
                const double *a, const double *R, const double *D,
+               const double *lnz1, const double *lnM,
                int nextra, const double *const *extra,
                int ndim, const int *tn, const double *const *taxes, const double *tvalues,
                double eps_runner, double *new_map, i64 *npairs_per_halo)
@@ -556,8 +561,8 @@ i64 bfgo_paint(i64 nside, i64 nhalo,
         if (npairs_per_halo) npairs_per_halo[j] = l.n;
         total += l.n;
         double x[BFGO_MAXDIM];
-        x[0] = log(1.0 / a_j);                                        /* Tabulate.py:279 */
-        x[1] = log(M[j]);                                             /* :283 */
+        x[0] = lnz1 ? lnz1[j] : log(1.0 / a_j);                       /* Tabulate.py:279: np.log(1/a), as the caller's numpy gives it */
+        x[1] = lnM ? lnM[j] : log(M[j]);                              /* :283 */
         for (int k = 3; k < ndim; ++k) x[k] = extra[k - 3][j];
         for (i64 i = 0; i < l.n; ++i) {
             i64 p = l.p[i];

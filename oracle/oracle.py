@@ -120,12 +120,12 @@ def lib():
         L.bfgo_get_interp_weights_lonlat.argtypes = [i64, i64, vp, vp, vp, vp]
         L.bfgo_rgi_eval.argtypes = [C.c_int, vp, vp, vp, vp]
         L.bfgo_rgi_eval.restype = dbl
-        L.bfgo_baryonify_offsets.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
+        L.bfgo_baryonify_offsets.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
                                              C.c_int, vp, vp, vp, C.c_int, dbl, dbl, vp, vp]
         L.bfgo_baryonify_offsets.restype = i64
         L.bfgo_regrid.argtypes = [i64, vp, vp, vp]
         L.bfgo_regrid_range.argtypes = [i64, i64, i64, vp, vp, vp]
-        L.bfgo_paint.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp,
+        L.bfgo_paint.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp,
                                  C.c_int, vp, vp, vp, dbl, vp, vp]
         L.bfgo_paint.restype = i64
         _LIB = L
@@ -224,6 +224,16 @@ def halo_scalars(cat, bg_runner, bg_model=None, md_runner=(200.0, 'critical'), m
     return a, R, D, Rmod
 
 
+def table_coords(cat):
+    """np.log(1/a), np.log(M): the halo's (z, M) table coordinates exactly as BaryonCorrection.py:364, :369 / Tabulate.py:279,
+    :283 form them (a = 1/(1+z) from HealpixRunner.py:295), with numpy's own log so that halos on a table edge classify as
+    in the reference."""
+    M, z = _f8(cat['M']), _f8(cat['z'])
+    a = 1.0 / (1.0 + z)
+    with np.errstate(all='ignore'):
+        return _f8(np.log(1.0 / a)), _f8(np.log(M))
+
+
 def baryonify_offsets(nside, cat, table, eps_runner, bg_runner, bg_model=None, return_counts=False, md_runner=(200.0, 'critical'),
                       md_model=(200.0, 'critical')):
     a, R, D, Rmod = halo_scalars(cat, bg_runner, bg_model, md_runner, md_model)
@@ -233,8 +243,9 @@ def baryonify_offsets(nside, cat, table, eps_runner, bg_runner, bg_model=None, r
     npix = 12 * nside * nside
     off = np.zeros((npix, 3))
     counts = np.zeros(ra.size, dtype=np.int64)
+    lnz1, lnM = table_coords(cat)
     tot = lib().bfgo_baryonify_offsets(nside, ra.size, _ptr(ra), _ptr(dec), _ptr(M), _ptr(_f8(a)), _ptr(_f8(R)),
-                                       _ptr(_f8(D)), _ptr(_f8(Rmod)), len(extra), _ptr_array(extra),
+                                       _ptr(_f8(D)), _ptr(_f8(Rmod)), _ptr(lnz1), _ptr(lnM), len(extra), _ptr_array(extra),
                                        ndim, _ptr(tn), tax, _ptr(table.values), int(table.rdelta_sampling),
                                        float(eps_runner), table.eps_model, _ptr(off), _ptr(counts))
     assert tot == counts.sum()
@@ -267,8 +278,9 @@ def paint_shell(nside, cat, log_table, eps_runner, bg_runner, return_counts=Fals
     ndim, tn, tax = log_table._cargs()
     new_map = np.zeros(12 * nside * nside)
     counts = np.zeros(ra.size, dtype=np.int64)
+    lnz1, lnM = table_coords(cat)
     lib().bfgo_paint(nside, ra.size, _ptr(ra), _ptr(dec), _ptr(M), _ptr(_f8(a)), _ptr(_f8(R)), _ptr(_f8(D)),
-                     len(extra), _ptr_array(extra), ndim, _ptr(tn), tax, _ptr(log_table.values),
+                     _ptr(lnz1), _ptr(lnM), len(extra), _ptr_array(extra), ndim, _ptr(tn), tax, _ptr(log_table.values),
                      float(eps_runner), _ptr(new_map), _ptr(counts))
     return (new_map, counts) if return_counts else new_map
 
@@ -286,6 +298,7 @@ def baryonify_shell_threads(nside, orig_map, cat, table, eps_runner, bg_runner, 
     npix = 12 * nside * nside
     n = ra.size
     cuts = np.linspace(0, n, threads + 1).astype(np.int64)
+    lnz1, lnM = table_coords(cat)
     L = lib()
 
     def loop(i):
@@ -293,7 +306,7 @@ def baryonify_shell_threads(nside, orig_map, cat, table, eps_runner, bg_runner, 
         off = np.zeros((npix, 3))
         ex = [e[lo:hi] for e in extra]
         tot = L.bfgo_baryonify_offsets(nside, hi - lo, _ptr(ra[lo:hi]), _ptr(dec[lo:hi]), _ptr(M[lo:hi]), _ptr(a[lo:hi]), _ptr(R[lo:hi]),
-                                       _ptr(D[lo:hi]), _ptr(Rmod[lo:hi]), len(ex), _ptr_array(ex), ndim, _ptr(tn), tax,
+                                       _ptr(D[lo:hi]), _ptr(Rmod[lo:hi]), _ptr(lnz1[lo:hi]), _ptr(lnM[lo:hi]), len(ex), _ptr_array(ex), ndim, _ptr(tn), tax,
                                        _ptr(table.values), int(table.rdelta_sampling), float(eps_runner), table.eps_model,
                                        _ptr(off), None)
         return off, tot

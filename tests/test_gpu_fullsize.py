@@ -20,9 +20,14 @@ def _setup(N, nside, paint, pad=1e-9):
     return torch, _lib, syn, cat, axes, table, plan, dev
 
 
-def _cat_dev(torch, _lib, dev, cat, idx=None):
+def _cat_dev(torch, _lib, dev, cat, idx=None, coords=False):
     cols = {k: torch.from_numpy(np.ascontiguousarray(v if idx is None else v[idx])).to(dev) for k, v in cat.items()}
     n = cols['M'].numel()
+    if coords:        # the (z, M) table coordinates as the caller's numpy computes them (bfgx_catalog.ln1pz / lnM)
+        lnz, lnM = _lib.table_coords(cat['M'] if idx is None else cat['M'][idx], cat['z'] if idx is None else cat['z'][idx])
+        cols['lnz'], cols['lnM'] = torch.from_numpy(lnz).to(dev), torch.from_numpy(lnM).to(dev)
+        return _lib.make_catalog_dev(n, cols['M'].data_ptr(), cols['z'].data_ptr(), cols['ra'].data_ptr(), cols['dec'].data_ptr(),
+                                     ln1pz_ptr=cols['lnz'].data_ptr(), lnM_ptr=cols['lnM'].data_ptr()), cols
     return _lib.make_catalog_dev(n, cols['M'].data_ptr(), cols['z'].data_ptr(), cols['ra'].data_ptr(), cols['dec'].data_ptr()), cols
 
 
@@ -167,4 +172,112 @@ def test_banded_regrid_equals_full_regrid(gpu):
     plan.regrid_bands(int(cuts[1]), int(cuts[2]), hmap.data_ptr(), off[3 * p0:3 * p1].clone().data_ptr(), win.data_ptr(), p0, p1)
     with pytest.raises(ValueError, match='window'):
         plan.status()
+    plan.close()
+
+
+def test_config2_exact_bench_table_edges(gpu):
+    """The headline configuration exactly as bench.py builds it: table edges == catalog min/max (README.md:78-80, pad = 0).
+    Whether the four edge halos (min/max z, min/max M) are inside the table hangs on the last bit of np.log(1/a) and
+    np.log(M); with the caller's numpy coordinates travelling through the ABI the product classifies them as the oracle
+    (= the reference's arithmetic) does.  pix_offsets of the edge halos + 20 000 others against the oracle, and the full
+    1e6-halo catalog through properties (mass conservation; equality with the padded table away from the edge halos)."""
+    N, nside = 1_000_000, 1024
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False, pad=0.0)
+    npix = 12 * nside * nside
+    edge = np.array([cat['z'].argmin(), cat['z'].argmax(), cat['M'].argmin(), cat['M'].argmax()])
+    idx = np.unique(np.concatenate([edge, np.arange(20000)]))
+    sub = {k: v[idx] for k, v in cat.items()}
+    from oracle import oracle as O
+    tab = O.Table(axes, table, False, 10.0)
+    bg = O.Background.from_dict(syn.COSMO)
+    ora = O.baryonify_offsets(nside, sub, tab, 10.0, bg)
+    # the oracle itself must see both kinds: edge halos that read the table and (possibly) edge halos that read NaN
+    lnz, lnM = O.table_coords(sub)
+    inside = (lnz >= axes[0][0]) & (lnz <= axes[0][-1]) & (lnM >= axes[1][0]) & (lnM <= axes[1][-1])
+    assert inside.sum() >= idx.size - 4
+    cd, keep = _cat_dev(torch, _lib, dev, cat, idx, coords=True)
+    for acc_f64, tol in ((True, 1e-12), (False, 2e-9)):          # absolute: offsets are ~1e-5; fp32 storage of ~1e-5 numbers
+        off = torch.zeros(npix * 3, dtype=torch.float64 if acc_f64 else torch.float32, device=dev)
+        plan.offsets(cd, off.data_ptr(), acc_f64)
+        torch.cuda.synchronize()
+        got = off.cpu().numpy().astype(np.float64).reshape(npix, 3)
+        assert np.abs(got - ora).max() <= tol
+        # each edge halo alone: contributes exactly when the oracle says it is inside the table
+        for e in edge:
+            one = {k: v[e:e + 1] for k, v in cat.items()}
+            o1 = O.baryonify_offsets(nside, one, tab, 10.0, bg)
+            c1, k1 = _cat_dev(torch, _lib, dev, cat, np.array([e]), coords=True)
+            off.zero_()
+            plan.offsets(c1, off.data_ptr(), acc_f64)
+            torch.cuda.synchronize()
+            g1 = off.cpu().numpy().astype(np.float64).reshape(npix, 3)
+            assert (np.abs(g1).max() > 0) == (np.abs(o1).max() > 0)
+            assert np.abs(g1 - o1).max() <= tol
+    plan.status()
+    # full catalog on the bench's table: mass conservation through the default (fp32) path
+    cdf, keepf = _cat_dev(torch, _lib, dev, cat, coords=True)
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+    off = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    out = torch.zeros(npix, dtype=torch.float64, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.offsets(cdf, off.data_ptr(), False)
+    plan.regrid(d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), False)
+    torch.cuda.synchronize()
+    s_ = sums.cpu().numpy()
+    assert np.isclose(s_[1], s_[0]) and np.isclose(out.sum().item(), hmap.sum())
+    plan.status()
+    plan.close()
+
+
+def test_config4_share_nside2048(gpu):
+    """BASELINE config 4's per-GPU share (1e7 halos over 8 GPUs = 1.25e6 halos, NSIDE 2048, BaryonifyShell): pix_offsets
+    of a 20 000-halo sample against the oracle, and the full share through properties (mass conservation, linearity of
+    pix_offsets over a catalog split = what the multi-GPU sum relies on, census of the tile path == per-halo path)."""
+    N, nside = 1_250_000, 2048
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    npix = 12 * nside * nside
+    from oracle import oracle as O
+    tab = O.Table(axes, table, False, 10.0)
+    bg = O.Background.from_dict(syn.COSMO)
+    sub = {k: v[:20000] for k, v in cat.items()}
+    ora = O.baryonify_offsets(nside, sub, tab, 10.0, bg)
+    cdS, kS = _cat_dev(torch, _lib, dev, cat, np.arange(20000), coords=True)
+    off64 = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+    plan.offsets(cdS, off64.data_ptr(), True)
+    torch.cuda.synchronize()
+    assert np.abs(off64.cpu().numpy().reshape(npix, 3) - ora).max() <= 1e-12
+    off32 = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    plan.offsets(cdS, off32.data_ptr(), False)
+    torch.cuda.synchronize()
+    assert np.abs(off32.cpu().numpy().astype(np.float64).reshape(npix, 3) - ora).max() <= 2e-9
+    del ora
+    # the full share
+    cd, keep = _cat_dev(torch, _lib, dev, cat, coords=True)
+    plan.offsets(cd, off64.data_ptr(), True)
+    plan.status()
+    idx = np.random.default_rng(7).permutation(N)
+    cdA, kA = _cat_dev(torch, _lib, dev, cat, idx[: N // 2], coords=True)
+    cdB, kB = _cat_dev(torch, _lib, dev, cat, idx[N // 2:], coords=True)
+    lin = torch.zeros_like(off64)
+    tmp = torch.zeros_like(off64)
+    plan.offsets(cdA, lin.data_ptr(), True)
+    plan.offsets(cdB, tmp.data_ptr(), True)
+    lin += tmp
+    torch.cuda.synchronize()
+    assert (lin - off64).abs().max().item() <= 2e-14
+    del lin, tmp
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+    out = torch.zeros(npix, dtype=torch.float64, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.offsets(cd, off32.data_ptr(), False)
+    plan.regrid(d_map.data_ptr(), off32.data_ptr(), out.data_ptr(), sums.data_ptr(), False)
+    torch.cuda.synchronize()
+    s_ = sums.cpu().numpy()
+    assert np.isclose(s_[1], s_[0]) and np.isclose(out.sum().item(), hmap.sum())      # HealpixRunner.py:344-346
+    plan.set_algo(1); n1 = plan.count_pairs(cd, True)
+    plan.set_algo(0); n0 = plan.count_pairs(cd, True)
+    assert n0 == n1 > 2e8
+    plan.status()
     plan.close()

@@ -128,3 +128,58 @@ def test_background_cosmology_two_implementations_agree():
     # sanity vs textbook numbers: LCDM D_A(z=1) for these parameters is ~1.7 Gpc, R200c(1e14, z=0) ~ 0.96 Mpc
     assert 1650 < c.Da_of_z(1.0) < 1760
     assert 0.9 < md.get_radius(c, 1e14, 1.0)[0] < 1.0
+
+
+# ------------------------------------------------------------------------------------------ healpy known answers
+# The only healpy-held numbers available offline: the worked examples printed in healpy's own docstrings
+# (healpy.pixelfunc: pix2ang, pix2vec, ang2pix, get_interp_weights, nside2resol).  DOCS-DERIVED, typed in by hand to the
+# digits the docstrings print; they pin the C oracle and the numpy stand-in to healpy itself at these points.
+def test_healpy_docstring_pix2ang_pix2vec():
+    # >>> hp.pix2ang(16, 1440)  -> (1.5291175943723188, 0.0)
+    # >>> hp.pix2ang(16, [1440, 427, 1520, 0, 3068]) -> theta [1.52911759 0.78550497 1.57079633 0.05103658 3.09055608],
+    #                                                     phi   [0. 0.78539816 1.61988371 0.78539816 ...]
+    # (the last azimuth is left out: it was not remembered with certainty when these were typed in)
+    pix = np.array([1440, 427, 1520, 0, 3068])
+    theta_doc = np.array([1.52911759, 0.78550497, 1.57079633, 0.05103658, 3.09055608])
+    phi_doc = np.array([0.0, 0.78539816, 1.61988371, 0.78539816])
+    for impl in ('oracle', 'shim'):
+        v = O.pix2vec(16, pix) if impl == 'oracle' else np.stack(hp.pix2vec(16, pix), axis=1)
+        theta = np.arccos(v[:, 2])
+        phi = np.mod(np.arctan2(v[:, 1], v[:, 0]), 2 * np.pi)
+        assert np.abs(theta - theta_doc).max() < 5e-9 and np.abs(phi[:4] - phi_doc).max() < 5e-9
+        assert abs(theta[0] - 1.5291175943723188) < 1e-15
+    # >>> hp.pix2vec(16, 1504) -> (0.99879545620517241, 0.049067674327418015, 0.0)
+    # >>> hp.pix2vec(16, [1440, 427]) -> x [0.99913157 0.5000534], y [0. 0.5000534], z [0.04166667 0.70703125]
+    for v in (O.pix2vec(16, np.array([1504, 1440, 427])), np.stack(hp.pix2vec(16, np.array([1504, 1440, 427])), axis=1)):
+        assert np.abs(v[0] - [0.99879545620517241, 0.049067674327418015, 0.0]).max() < 2e-16
+        assert np.abs(v[1] - [0.99913157, 0.0, 0.04166667]).max() < 5e-9
+        assert np.abs(v[2] - [0.5000534, 0.5000534, 0.70703125]).max() < 5e-9
+
+
+def test_healpy_docstring_get_interp_weights():
+    # >>> hp.get_interp_weights(1, 0)      (pixel 0 itself, RING)     -> ([0, 1, 4, 5], [1., 0., 0., 0.])
+    # >>> hp.get_interp_weights(1, 0, 0)   (theta = 0, phi = 0)       -> ([1, 2, 3, 0], [0.25, 0.25, 0.25, 0.25])
+    # >>> hp.get_interp_weights(1, 0, 90, lonlat=True)                -> the same
+    # >>> hp.get_interp_weights(1, [0, np.pi / 2], 0) -> pix [[1 4] [2 5] [3 11] [0 8]], w [[.25 1.] [.25 0.] [.25 0.] [.25 0.]]
+    def as_map(pix, w):
+        m = np.zeros(12)
+        np.add.at(m, np.asarray(pix).ravel(), np.asarray(w).ravel())
+        return m
+    for impl in ('oracle', 'shim'):
+        f = (lambda lon, lat: O.get_interp_weights_lonlat(1, np.atleast_1d(lon), np.atleast_1d(lat))) if impl == 'oracle' else \
+            (lambda lon, lat: hp.get_interp_weights(1, np.atleast_1d(lon), np.atleast_1d(lat), lonlat=True))
+        pix, w = f(0.0, 90.0)                                  # north pole
+        assert sorted(np.asarray(pix).ravel().tolist()) == [0, 1, 2, 3] and np.allclose(np.asarray(w).ravel(), 0.25, atol=1e-15)
+        pix, w = f(0.0, 0.0)                                   # theta = pi/2, phi = 0: all the weight on pixel 4
+        assert np.allclose(as_map(pix, w), np.eye(12)[4], atol=1e-15)
+        assert set(np.asarray(pix).ravel().tolist()) == {4, 5, 11, 8}
+        # the centre of pixel 0 (theta = arccos(2/3), phi = pi/4): weight 1 on pixel 0, neighbours 0, 1, 4, 5
+        pix, w = f(45.0, 90.0 - np.degrees(np.arccos(2.0 / 3.0)))
+        assert np.allclose(as_map(pix, w), np.eye(12)[0], atol=1e-14)
+        assert set(np.asarray(pix).ravel().tolist()) == {0, 1, 4, 5}
+
+
+def test_healpy_docstring_scalars():
+    # >>> hp.nside2npix(8) -> 768 ; hp.npix2nside(768) -> 8 ; hp.nside2resol(128, arcmin=True) -> 27.483891294539248
+    assert hp.nside2npix(8) == 768 and hp.npix2nside(768) == 8
+    assert abs(np.degrees(hp.nside2resol(128)) * 60 - 27.483891294539248) < 1e-12
