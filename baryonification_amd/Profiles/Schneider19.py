@@ -88,6 +88,10 @@ class SchneiderProfiles(object):
         self.cutoff = kwargs.get('cutoff', 1e3)
         self.proj_cutoff = kwargs.get('proj_cutoff', self.cutoff)
         self._projected = self._projected_realspace
+        # ccl.halos.HaloProfile.precision_fftlog (pyccl 2.8.0 defaults): read by utils.Pixel.ConvolvedProfile (Pixel.py:72)
+        self.precision_fftlog = {'padding_lo_fftlog': 0.1, 'padding_lo_extra': 0.1, 'padding_hi_fftlog': 10.0, 'padding_hi_extra': 10.0,
+                                 'large_padding_2D': False, 'n_per_decade': 100, 'extrapol': 'linx_liny',
+                                 'plaw_fourier': -1.5, 'plaw_projected': -1.0}
 
     # -- protocol -------------------------------------------------------------------------------------
     @property
@@ -96,6 +100,13 @@ class SchneiderProfiles(object):
 
     def set_parameter(self, key, value):
         _set_parameter(self, key, value)
+
+    def update_precision_fftlog(self, **kwargs):
+        """ccl.halos.HaloProfile.update_precision_fftlog"""
+        for k, v in kwargs.items():
+            if k not in self.precision_fftlog:
+                raise KeyError("unknown FFTLog precision parameter %r" % (k,))
+            self.precision_fftlog[k] = v
 
     def real(self, cosmo, r, M, a):
         return self._real(cosmo, r, M, a)

@@ -104,6 +104,11 @@ SYMBOLS = {
     'bfgx_enclosed_mass_3d': (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'bfgx_displacement_rows': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_pressure_profile': (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
+    'bfgx_fftlog_kgrid': (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
+    'bfgx_fftlog_transform': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                        C.c_void_p, C.c_void_p]),
+    'bfgx_fftlog_convolve': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p]),
     'bfgx_count_pairs_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int, C.c_void_p, _P(C.c_int64)]),
     # regular-grid path
     'bfgx_baryonify_grid': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_grid), C.c_void_p, C.c_void_p,

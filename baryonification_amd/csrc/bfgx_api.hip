@@ -29,6 +29,7 @@
 #include "bfgx_grid.hpp"
 #include "bfgx_fft.hpp"
 #include "bfgx_snapshot.hpp"
+#include "bfgx_fftlog.hpp"
 
 using namespace bfgx;
 
@@ -1164,6 +1165,9 @@ int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const d
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------ pixel-window convolution (8f-3)
+#include "bfgx_fftlog_api.inc"
 
 // ------------------------------------------------------------------------------ regular-grid path (8f-1)
 #include "bfgx_grid_api.inc"

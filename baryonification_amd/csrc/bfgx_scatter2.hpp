@@ -183,7 +183,6 @@ template <int MODE, typename real>
 __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const RowC2<real> rc, const PairRecT<real> *pairs,
                                  const RingC2<real> *ringc, int t, bool act, int wsh, int wmask)
 {
-    using PM = PMath<real>;
     const int jj = t - (int)(rc.pk & 0xFFFu);
     const int rl = (int)((rc.pk >> 18) & 63u);
     o.la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);
@@ -259,7 +258,6 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    using PM = PMath<real>;
     const int tile = T.tile_order[blockIdx.x];        // heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];

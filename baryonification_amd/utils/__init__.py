@@ -2,3 +2,4 @@ from .io import *
 from .cosmology import *
 from .Tabulate import *
 from .Parallelize import *
+from .Pixel import *

@@ -207,6 +207,26 @@ int bfgx_displacement_rows(int device, int64_t nrows, int32_t nr, const double *
 int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const double *rho_tot, const double *rho_gas,
                           int32_t nr_out, const double *r_out, double cutoff, double *P_out);
 
+/* ---- pixel-window convolution ---------------------------------------------------
+ * BaryonForge/utils/Pixel.py: ConvolvedProfile.real (:106-157) / .projected (:160-224) = FFTLog forward, x pixel window,
+ * FFTLog back, PCHIP in ln r.  The transform is pyccl.pyutils._fftlog_transform(rs, frs, dim, mu, power_law_index)
+ * (pyccl 2.8.0, a C port of Hamilton's FFTLog); pyccl is absent here, so what is implemented is the published algorithm
+ * (Hamilton 2000, App. B) with the bias exponent q = dim/2 + power_law_index and the low-ringing k r nearest to 1:
+ *   dim 3: F(k) = (2 pi)^-3 int d^3r f(r) j_mu(k r)-kernel;   dim 2: F(k) = (2 pi)^-2 int d^2r f(r) J_mu(k r).
+ * Host arrays in / out; f and prof are [nrows][n] on the log grid r (positive, ascending, log-uniform). */
+/* the output grid of one transform (pure CPU): k_j = (k r)_lowring / r[n-1-j] */
+int bfgx_fftlog_kgrid(int32_t n, const double *r, int32_t dim, double mu, double plaw, double *k_out);
+/* ks, fks = _fftlog_transform(rs, frs, dim, mu, plaw) */
+int bfgx_fftlog_transform(int device, int64_t nrows, int32_t n, const double *r, const double *f, int32_t dim, double mu,
+                          double plaw, double *k_out, double *F_out);
+/* Pixel.py:146-155 / :208-222 in one call: transform(prof; plaw_fwd) * window -> transform(.; plaw_back) ->
+ * PchipInterpolator(ln(r_out * r_scale), ., extrapolate=False)(ln r_eval), NaN -> 0, x (2 pi)^dim.
+ * window[n] = Pixel.real / Pixel.projected evaluated by the caller at bfgx_fftlog_kgrid(r_fft, plaw_fwd); r_eval[nq] is
+ * already clipped at pixel_size / 5 (:153, :217-219); r_scale = D_A for harmonic pixels (r_fft given in radians), else 1 */
+int bfgx_fftlog_convolve(int device, int64_t nrows, int32_t n, const double *r_fft, const double *prof, int32_t dim, double mu,
+                         double plaw_fwd, double plaw_back, const double *window, int32_t nq, const double *r_eval, double r_scale,
+                         double *out);
+
 /* ---- regular-grid path: periodic square / cubic maps ---------------------------------
  * Replaces BaryonForge/Runners/Map2DRunner.py: BaryonifyGrid.process :431-607, PaintProfilesGrid.process :676-817,
  * regrid_pixels_2D :14-83, regrid_pixels_3D :86-163; utils/io.py ParticleSnapshot.make_map :622-670; and the FFT
