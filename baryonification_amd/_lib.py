@@ -91,7 +91,11 @@ SYMBOLS = {
     'bfgx_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'bfgx_plan_bands': (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_void_p]),
-    'bfgx_regrid_bands_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
+    'bfgx_plan_band_apron': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_int64), _P(C.c_int64)]),
+    'bfgx_regrid_bands_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
+    'bfgx_plan_far_fetch': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
+    'bfgx_plan_far_apply_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_plan_set_algo': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_status': (C.c_int, [C.c_void_p]),
@@ -176,8 +180,8 @@ def load():
             fn = getattr(L, name)        # AttributeError here = ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if L.bfgx_abi_version() != 1:
-            raise ImportError("libbfgx.so ABI version %d != 1" % L.bfgx_abi_version())
+        if L.bfgx_abi_version() != 2:
+            raise ImportError("libbfgx.so ABI version %d != 2" % L.bfgx_abi_version())
         _lib = L
     return _lib
 

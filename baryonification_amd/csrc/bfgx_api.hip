@@ -109,7 +109,6 @@ struct bfgx_plan {
     const double *tab8d = nullptr;
     unsigned long long *pair_total = nullptr;
     double *tile_sums = nullptr;     // [ntiles][2] per-tile {sum of source values, sum of deposits} of the tiled regrid
-    int32_t *regrid_oob = nullptr;   // set when a banded regrid dropped a deposit outside its output window
     std::vector<int32_t> band_tile0_host;   // first tile of every band (+ total)
     int64_t capacity = 0;
     // optional per-kernel HIP-event timing (bfgx_plan_timing_*)
@@ -612,13 +611,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         void *d9 = nullptr;
         if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 1), &d9)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(wide tile list) failed"));
         p->wide_tiles = (int32_t *)d9;
-        void *d7 = nullptr;
-        if (dalloc(sizeof(int32_t), &d7)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(flag) failed"));
-        p->regrid_oob = (int32_t *)d7;
         void *d8 = nullptr;
         if (dalloc(sizeof(double) * 2 * (size_t)(T.ntiles + 1), &d8)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(tile sums) failed"));
         p->tile_sums = (double *)d8;
-        if (hipMemsetAsync(p->regrid_oob, 0, sizeof(int32_t), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
         if (hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream) != hipSuccess)
             return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
     }
@@ -690,14 +685,6 @@ int bfgx_plan_status(bfgx_plan *p)
         return fail(BFGX_ERR_INVALID, "the regrid's list of far deposits overflowed (%lld entries): displacements of many pixels over a large "
                                       "part of the map", (long long)p->far.cap);
     }
-    int32_t oob = 0;
-    HIP_TRY(hipMemcpyAsync(&oob, p->regrid_oob, sizeof(oob), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (oob) {
-        HIP_TRY(hipMemsetAsync(p->regrid_oob, 0, sizeof(int32_t), p->stream));
-        return fail(BFGX_ERR_INVALID, "a banded regrid dropped deposits outside its output window (displacements larger than the window margin): "
-                                      "use a wider margin or the full-map regrid");
-    }
     return BFGX_OK;
 }
 
@@ -719,33 +706,85 @@ int bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel)
     return BFGX_OK;
 }
 
-int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_slice_dev,
-                             int acc_f64, double *window_dev, int64_t wlo, int64_t whi)
+// first pixel of ring `ring` (1 .. 4 nside - 1), npix beyond
+static int64_t ring_first_pixel(const Hpx &h, int64_t ring)
 {
-    if (!p || !map_in_dev || !offsets_slice_dev || !window_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
-    if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "banded regrid needs the tiled algorithm (algo 1)");
+    const int64_t ns = h.nside, nl4 = 4 * ns;
+    if (ring < 1) return 0;
+    if (ring >= nl4) return h.npix;
+    const int64_t q = nl4 - ring;
+    return (ring < ns) ? 2 * ring * (ring - 1) : (ring < 3 * ns) ? h.ncap + (ring - ns) * 4 * ns : h.npix - 2 * q * (q + 1);
+}
+
+int bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *olo, int64_t *ohi)
+{
+    if (!p || !olo || !ohi) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
-    if (wlo < 0 || whi > p->hpx.npix || wlo > whi) return fail(BFGX_ERR_INVALID, "window out of bounds");
-    if (band0 == band1) return BFGX_OK;
+    const int64_t i0 = 1 + (int64_t)p->tiling.BR * band0, i1 = 1 + (int64_t)p->tiling.BR * band1;      // rings [i0, i1)
+    *olo = ring_first_pixel(p->hpx, i0 - kGatherR);
+    *ohi = ring_first_pixel(p->hpx, i1 + kGatherR);
+    return BFGX_OK;
+}
+
+int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
+                             int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev)
+{
+    if (!p || !map_in_dev || !offsets_dev || !out_slice_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "banded regrid needs the tiled algorithm (algo 1)");
+    int64_t need_lo = 0, need_hi = 0;
+    if (int rc = bfgx_plan_band_apron(p, band0, band1, &need_lo, &need_hi)) return rc;
+    if (olo > need_lo || ohi < need_hi || olo < 0 || ohi > p->hpx.npix)
+        return fail(BFGX_ERR_INVALID, "pix_offsets range [%lld, %lld) does not cover the bands and one ring either side [%lld, %lld)",
+                    (long long)olo, (long long)ohi, (long long)need_lo, (long long)need_hi);
     HIP_TRY(hipSetDevice(p->device));
-    std::vector<int64_t> first(p->tiling.nbands + 1);
-    int32_t nb = 0;
-    if (int rc = bfgx_plan_bands(p, &nb, first.data())) return rc;
-    const int64_t p0 = first[band0], p1 = first[band1];
-    if (wlo > p0 || whi < p1) return fail(BFGX_ERR_INVALID, "window [%lld, %lld) does not cover the bands' own pixels [%lld, %lld)",
-                                          (long long)wlo, (long long)whi, (long long)p0, (long long)p1);
+    HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
+    if (band0 == band1) return BFGX_OK;
+    const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * band0);
     const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
-    KernelTimer kt(p, BFGX_K_REGRID);
-    const size_t lds = regrid2_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
-    // virtual bases: the kernel indexes every array by global pixel number
-    double *out_base = window_dev - wlo;
-    if (acc_f64)
-        hipLaunchKernelGGL((tile_regrid2_kernel<double, double>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
-                           (const double *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob, (double *)nullptr);
-    else
-        hipLaunchKernelGGL((tile_regrid2_kernel<float, float>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
-                           (const float *)offsets_slice_dev - 3 * p0, out_base, t0, wlo, whi, p->regrid_oob, (double *)nullptr);
+    {
+        KernelTimer kt(p, BFGX_K_REGRID);
+        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
+        // virtual bases: the kernel indexes every array by global pixel number
+        double *out_base = out_slice_dev - p0;
+        if (acc_f64)
+            hipLaunchKernelGGL((tile_regrid3_kernel<double, double>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
+                               (const double *)offsets_dev - 3 * olo, out_base, p->far, sums_dev ? p->tile_sums : nullptr, t0);
+        else
+            hipLaunchKernelGGL((tile_regrid3_kernel<float, float>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
+                               (const float *)offsets_dev - 3 * olo, out_base, p->far, sums_dev ? p->tile_sums : nullptr, t0);
+        HIP_TRY(hipGetLastError());
+    }
+    if (sums_dev) {
+        KernelTimer kt(p, BFGX_K_SUM);
+        hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(256), 0, p->stream, t1 - t0, (const double *)(p->tile_sums + 2 * (size_t)t0), sums_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
+}
+
+int bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0, int64_t p1, unsigned long long *foreign_dev)
+{
+    if (!p || !out_slice_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    hipLaunchKernelGGL(regrid_far_local_kernel, dim3(64), dim3(256), 0, p->stream, p->far, out_slice_dev, p0, p1, foreign_dev);
     HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
+int bfgx_plan_far_fetch(bfgx_plan *p, int64_t cap, int64_t *pix_host, double *val_host, int64_t *n_host)
+{
+    if (!p || !n_host) return fail(BFGX_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, p->far.count, sizeof(n), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if ((int64_t)n > p->far.cap) return fail(BFGX_ERR_INVALID, "the regrid's list of far deposits overflowed (%lld entries)", (long long)p->far.cap);
+    *n_host = (int64_t)n;
+    if (n == 0 || (!pix_host && !val_host)) return BFGX_OK;          // count only
+    if ((int64_t)n > cap || !pix_host || !val_host) return fail(BFGX_ERR_INVALID, "far-deposit buffers hold %lld entries, %lld are listed", (long long)cap, (long long)n);
+    HIP_TRY(hipMemcpyAsync(pix_host, p->far.pix, sizeof(int64_t) * n, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(val_host, p->far.val, sizeof(double) * n, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
     return BFGX_OK;
 }
 
@@ -799,10 +838,10 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
         HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
         if (acc_f64)
             hipLaunchKernelGGL((tile_regrid3_kernel<double, double>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr);
+                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr, -1);
         else
             hipLaunchKernelGGL((tile_regrid3_kernel<float, float>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr);
+                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr, -1);
         hipLaunchKernelGGL(regrid_far_kernel, dim3(64), dim3(256), 0, p->stream, p->far, map_out_dev);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);

@@ -1414,15 +1414,8 @@ __device__ inline double ring_theta(const Hpx &h, int ring)
     return th;
 }
 
-// ---------------------------------------------------------------------------------- K2, tiled
-// One workgroup per tile of SOURCE pixels.  Displacements are a small fraction of a pixel, so almost every
-// target pixel lies in the tile or within a thin apron around it: contributions are summed in LDS (fp64
-// ds_add) and flushed as row-contiguous fp64 atomics (full-rate shape); the rare far target goes straight
-// to a global atomic.  map_out must be zeroed by the caller.
-constexpr int kApronR = 2;     // apron rings above / below the band
-constexpr int kApronK = 4;     // apron pixels left / right of the tile's azimuth range
-
-// one ring of the tiled regrid's LDS window (rings i0 - kApronR - 1 .. i1 + kApronR): everything the per-pixel code
+// ---------------------------------------------------------------------------------- K2, tiled (bfgx_regrid2.hpp)
+// one ring of the tiled regrid's ring table: everything the per-pixel code
 // needs of a ring, so that no pixel re-derives ring geometry (integer divisions, square roots, 2 pi / n)
 struct RegRow {
     double theta, z, sth;                 // colatitude (-inf / +inf beyond the poles), cos, sin
@@ -1432,239 +1425,12 @@ struct RegRow {
     int32_t nr, ks, ke, shf;              // nr == 0: no such ring
 };
 
-__host__ __device__ inline size_t regrid_lds_bytes(int BR, int W)
-{
-    return (size_t)(BR + 2 * kApronR) * (W + 2 * kApronK) * sizeof(double) + (size_t)(BR + 2 * kApronR + 2) * sizeof(RegRow);
-}
-
 // colatitude of a ring centre without libm (atan2 of the ring's sin/cos), for the tiled regrid
 __device__ inline double ring_theta_nolibm(const Hpx &h, int ring)
 {
     double z, sth;
     ring_z_sth(h, ring, z, sth);
     return atan2_generic(sth, z);
-}
-
-template <typename ACC>
-__global__ void __launch_bounds__(256)
-tile_regrid_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
-                   double *__restrict__ map_out, int tile_off, int64_t wlo, int64_t whi, int32_t *__restrict__ oob_flag,
-                   double *__restrict__ tile_sums)
-{
-    // map_out, offsets and map_in are indexed by GLOBAL pixel number; a rank that owns only a range of bands passes
-    // pointers shifted accordingly and the window [wlo, whi) of map_out that really exists.  A deposit outside the
-    // window (a displacement of more than the window margin) is dropped and flagged, never written.
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int LR = T.BR + 2 * kApronR, LW = T.W + 2 * kApronK;
-    double *acc = reinterpret_cast<double *>(smem);            // [LR][LW]
-    RegRow *rows = reinterpret_cast<RegRow *>(acc + LR * LW);  // rings rth0 .. rth0 + LR + 1
-    const int tile = blockIdx.x + tile_off;
-    // optional mass-conservation sums (HealpixRunner.py:344-345) without another pass over the maps: every thread adds up
-    // the source values it read and the values it deposited; per-tile totals go to tile_sums[2 tile + {0, 1}]
-    double sum_in = 0.0, sum_out = 0.0;
-    auto out_add = [&](int64_t p, double v) {
-        if (p >= wlo && p < whi) { atomicAdd(map_out + p, v); sum_out += v; }
-        else atomicOr(oob_flag, 1);
-    };
-    const int band = T.tile_band[tile];
-    const int nphi = T.band_nphi[band];
-    const int tj = tile - T.band_tile0[band];
-    const int nl4 = (int)(4 * h.nside);
-    const int i0 = 1 + band * T.BR;
-    const int i1 = min(i0 + T.BR, nl4);                        // exclusive
-    const int tid = threadIdx.x;
-    const int rth0 = i0 - kApronR - 1;
-    for (int i = tid; i < LR * LW; i += 256) acc[i] = 0.0;
-    if (tid < LR + 2) {
-        const int ring = rth0 + tid;
-        RegRow rw;
-        rw.theta = (ring < 1) ? -1.0e300 : 1.0e300;
-        rw.z = rw.sth = rw.dphi = rw.inv_dphi = rw.c0 = rw.s0 = 0.0;
-        rw.start = 0; rw.nr = 0; rw.ks = 0; rw.ke = 0; rw.shf = 0;
-        if (ring >= 1 && ring <= nl4 - 1) {
-            int64_t st, nr64; bool shf;
-            ring_info_small(h, ring, st, nr64, shf);
-            ring_z_sth(h, ring, rw.z, rw.sth);
-            rw.theta = atan2_generic(rw.sth, rw.z);
-            rw.start = st; rw.nr = (int)nr64; rw.shf = shf ? 1 : 0;
-            rw.dphi = kTwoPi / (double)rw.nr;
-            rw.inv_dphi = (double)rw.nr * kInvTwoPi;
-            rw.ks = tile_ks(tj, rw.nr, nphi);
-            rw.ke = tile_ks(tj + 1, rw.nr, nphi);
-            sincos_bounded(((double)rw.ks + (shf ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
-        }
-        rows[tid] = rw;
-    }
-    __syncthreads();
-
-    auto add_target = [&](int ring_t, int k_t, double v) {
-        const int ti = ring_t - rth0;
-        if (ti >= 1 && ti <= LR) {                             // rings i0 - kApronR .. i1 + kApronR - 1 own an LDS row
-            const RegRow &rt = rows[ti];
-            int dk = k_t - rt.ks;
-            if (dk >= LW - kApronK) dk -= rt.nr;
-            if (dk < -kApronK) dk += rt.nr;
-            if (dk >= -kApronK && dk < LW - kApronK) { atomicAdd(acc + (ti - 1) * LW + dk + kApronK, v); return; }
-            out_add(rt.start + k_t, v);                        // far target in a window ring (rare)
-            return;
-        }
-        int64_t st_t, nr64; bool sh_t;
-        ring_info_small(h, ring_t, st_t, nr64, sh_t);
-        out_add(st_t + k_t, v);                                // far target (rare)
-    };
-
-    // source pixels of the tile, 8 per thread; the loads of pixel i+1 are issued before pixel i is processed
-    struct Src { int ti, x; bool ok; double val; ACC o0, o1, o2; };
-    const int wshift = ((T.W & (T.W - 1)) == 0) ? __ffs(T.W) - 1 : -1;      // W a power of two: shift instead of divide
-    auto fetch = [&](int idx) {
-        Src sx;
-        sx.ok = false; sx.ti = 0; sx.x = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (ACC)0;
-        if (idx < T.BR * T.W) {
-            const int r = (wshift >= 0) ? (idx >> wshift) : idx / T.W, x = idx - r * T.W;
-            if (i0 + r < i1) {
-                const RegRow &rw = rows[r + kApronR + 1];
-                if (x < rw.ke - rw.ks) {
-                    const int64_t p = rw.start + rw.ks + x;
-                    sx.ok = true; sx.ti = r + kApronR + 1; sx.x = x;
-                    sx.val = map_in[p];
-                    sx.o0 = offsets[3 * p + 0]; sx.o1 = offsets[3 * p + 1]; sx.o2 = offsets[3 * p + 2];
-                }
-            }
-        }
-        return sx;
-    };
-    int last_nr = -1, last_x = -1;                     // sincos(x * dphi) is reused while the ring length stays the same
-    double sa = 0.0, ca = 1.0;
-    Src nxt = fetch(tid);
-    for (int idx = tid; idx < T.BR * T.W; idx += 256) {
-        const Src cur = nxt;
-        nxt = fetch(idx + 256);
-        if (cur.ok) sum_in += cur.val;
-        if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
-        const RegRow &rw = rows[cur.ti];
-        const double val = cur.val;
-        const double z = rw.z, sth = rw.sth;
-        const double phi = ((double)(rw.ks + cur.x) + (rw.shf ? 0.5 : 0.0)) * rw.dphi;
-        double s, c;
-        const double ang = (double)cur.x * rw.dphi;                          // azimuth relative to the tile's first pixel
-        if (ang <= 0.45) {
-            if (rw.nr != last_nr || cur.x != last_x) { sincos_small(ang, sa, ca); last_nr = rw.nr; last_x = cur.x; }
-            c = rw.c0 * ca - rw.s0 * sa;
-            s = rw.s0 * ca + rw.c0 * sa;
-        } else {
-            sincos_bounded(phi, s, c);
-        }
-        const double nx = sth * c + (double)cur.o0;                          // :333
-        const double ny = sth * s + (double)cur.o1;
-        const double nz = z + (double)cur.o2;
-        // (theta, phi) of the displaced pixel (:334) as small corrections to the pixel's own angles:
-        //   in the frame rotated by -phi:  x' = n.e_r, y' = n.e_phi;  dphi = atan2(y', x');
-        //   sin(dtheta) = sin(theta_n) z - cos(theta_n) sin(theta)
-        const double xr = nx * c + ny * s, yr = ny * c - nx * s;
-        const double inv = fast_rsq(nx * nx + ny * ny + nz * nz);
-        const double zc = nz * inv;                                          // cos(theta_new)
-        const double tq = yr * fast_rcp(xr);
-        const double sn = fast_sqrt(xr * xr + yr * yr) * inv;                // sin(theta_new)
-        const double q = sn * z - zc * sth;
-        double theta, ph;
-        if (xr > 0.0 && fabs(tq) <= 0.1 && fabs(q) <= 0.05) {
-            ph = phi + atan_small(tq);
-            theta = rw.theta + asin_small(q);
-        } else {                                                             // large displacement: libm
-            theta = atan2_generic(sn, zc);
-            ph = atan2_generic(ny, nx);
-        }
-        if (ph < 0) ph += kTwoPi;
-        if (ph >= kTwoPi) ph -= kTwoPi;
-        // get_interp_weights (:337): healpix_cxx get_interpol.  ring_above(z) is the ring with theta_ring <= theta <
-        // theta_next; found by walking the window's colatitude table from the pixel's own ring (on a ring boundary both
-        // answers interpolate to the same value), with the closed form as fallback outside the window.
-        int t1 = cur.ti;
-        while (t1 > 0 && theta < rows[t1].theta) --t1;
-        while (t1 < LR + 1 && theta >= rows[t1 + 1].theta) ++t1;
-        const bool in_window = (theta >= rows[t1].theta) && (t1 < LR + 1) && (theta < rows[t1 + 1].theta);
-        const int ir1 = in_window ? rth0 + t1 : (int)ring_above(h, zc);
-        const int ir2 = ir1 + 1;
-        int tr[4] = {0, 0, 0, 0}, tk[4] = {0, 0, 0, 0};
-        double w[4] = {0.0, 0.0, 0.0, 0.0};
-        double theta1 = 0.0, theta2 = 0.0;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int ir = half ? ir2 : ir1;
-            if (half ? (ir < nl4) : (ir > 0)) {
-                const int ti = ir - rth0;
-                int n2; double shd, invd, th;
-                if (ti >= 0 && ti < LR + 2) {
-                    const RegRow &r2 = rows[ti];
-                    n2 = r2.nr; shd = r2.shf ? 0.5 : 0.0; invd = r2.inv_dphi; th = r2.theta;
-                } else {
-                    n2 = ring_len(h, ir);
-                    const bool sh2 = (ir < h.nside) || (ir >= 3 * h.nside) || (((ir - (int)h.nside) & 1) == 0);
-                    shd = sh2 ? 0.5 : 0.0; invd = (double)n2 * kInvTwoPi; th = ring_theta_nolibm(h, ir);
-                }
-                const double tmp = ph * invd - shd;
-                int j1 = (int)floor(tmp);
-                const double w1 = tmp - (double)j1;
-                int j2 = j1 + 1;
-                if (j1 < 0) j1 += n2;
-                if (j2 >= n2) j2 -= n2;
-                tr[2 * half] = ir; tr[2 * half + 1] = ir;
-                tk[2 * half] = j1; tk[2 * half + 1] = j2;
-                w[2 * half] = 1.0 - w1; w[2 * half + 1] = w1;
-                if (half) theta2 = th; else theta1 = th;
-            }
-        }
-        if (ir1 == 0) {                                    // north pole: missing ring -> the 4 polar pixels
-            const double wtheta = theta / theta2;
-            w[2] *= wtheta; w[3] *= wtheta;
-            const double fac = (1.0 - wtheta) * 0.25;
-            w[0] = fac; w[1] = fac; w[2] += fac; w[3] += fac;
-            tr[0] = 1; tr[1] = 1; tk[0] = (tk[2] + 2) & 3; tk[1] = (tk[3] + 2) & 3;
-        } else if (ir2 == nl4) {                           // south pole
-            const double wtheta = (theta - theta1) / (kPi - theta1);
-            w[0] *= (1.0 - wtheta); w[1] *= (1.0 - wtheta);
-            const double fac = wtheta * 0.25;
-            w[0] += fac; w[1] += fac; w[2] = fac; w[3] = fac;
-            tr[2] = nl4 - 1; tr[3] = nl4 - 1; tk[2] = (tk[0] + 2) & 3; tk[3] = (tk[1] + 2) & 3;
-        } else {
-            const double wtheta = (theta - theta1) * fast_rcp(theta2 - theta1);
-            w[0] *= (1.0 - wtheta); w[1] *= (1.0 - wtheta);
-            w[2] *= wtheta; w[3] *= wtheta;
-        }
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) add_target(tr[q4], tk[q4], w[q4] * val);    // regrid_pixels_hpix :64
-    }
-    __syncthreads();
-
-    // flush: row-contiguous fp64 atomics
-    const int lane = tid & (kWave - 1), wid = tid / kWave;
-    for (int rr = wid; rr < LR; rr += 256 / kWave) {
-        const RegRow &rt = rows[rr + 1];
-        if (rt.nr == 0) continue;
-        const int k0 = rt.ks - kApronK;
-        for (int xx = lane; xx < LW; xx += kWave) {
-            const double v = acc[rr * LW + xx];
-            if (v != 0.0) {
-                int k = k0 + xx;
-                if (k < 0) k += rt.nr;
-                if (k >= rt.nr) k -= rt.nr;
-                if (k < 0 || k >= rt.nr) { k %= rt.nr; if (k < 0) k += rt.nr; }
-                out_add(rt.start + k, v);
-            }
-        }
-    }
-    if (tile_sums) {
-        __syncthreads();                                   // acc is free again: reuse its first words for the block reduction
-#pragma unroll
-        for (int sft = kWave >> 1; sft > 0; sft >>= 1) { sum_in += __shfl_down(sum_in, sft, kWave); sum_out += __shfl_down(sum_out, sft, kWave); }
-        if (lane == 0) { acc[2 * wid] = sum_in; acc[2 * wid + 1] = sum_out; }
-        __syncthreads();
-        if (tid == 0) {
-            double a = 0.0, b = 0.0;
-            for (int w = 0; w < 256 / kWave; ++w) { a += acc[2 * w]; b += acc[2 * w + 1]; }
-            tile_sums[2 * (int64_t)tile] = a; tile_sums[2 * (int64_t)tile + 1] = b;
-        }
-    }
 }
 
 // sums[0] = sum of tile_sums[2 t], sums[1] = sum of tile_sums[2 t + 1]   (one workgroup)

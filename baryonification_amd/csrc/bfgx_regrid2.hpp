@@ -1,18 +1,18 @@
 // K2 for gfx950 (MI355X): the post-loop regrid of BaryonifyShell (HealpixRunner.py:333-341 + regrid_pixels_hpix :60-64).
 //
-// One 256-thread workgroup per tile of SOURCE pixels, targets summed in an LDS window (tile + apron) and flushed as
-// row-contiguous fp64 atomics -- the structure of tile_regrid_kernel (bfgx_kernels.hpp).  What is new is the per-pixel
-// arithmetic.  The reference turns pix2vec + offset into (theta, phi) with vec2ang and then asks get_interp_weights; both
-// steps move O(1) numbers although the displacement is ~1e-5 rad.  Here the displaced position is carried as the pixel's
-// OWN (ring, k) plus two small angles, formed from the offset's components in the pixel's local frame
+// Per-pixel arithmetic.  The reference turns pix2vec + offset into (theta, phi) with vec2ang and then asks
+// get_interp_weights; both steps move O(1) numbers although the displacement is ~1e-5 rad.  Here the displaced position is
+// carried as the pixel's OWN (ring, k) plus two small angles, formed from the offset's components in the pixel's local frame
 //     a = o.e_rho,  b = o.e_phi,  o_z      (e_rho, e_phi: in-plane radial / azimuthal unit vectors at the pixel)
 //     dphi   = atan(b / (sth + a))
 //     dtheta = asin( [ (a z - o_z sth) + (sth + a) z (sqrt(1 + t^2) - 1) ] / |v + o| ),   t = b / (sth + a)
 // in which nothing cancels, so the pair runs in the precision of pix_offsets (fp32 by default; fp64 keeps 1e-10 parity):
 // the ring above / below and the colatitude weight follow from dtheta and the ring spacing, the azimuth weights on the
 // pixel's own ring from dphi / (2 pi / nr), and on the neighbouring ring from the exact rational (k + shift) nr' / nr (the
-// only fp64 arithmetic left per pixel).  Pixels next to a pole, displacements beyond one ring / 0.02 rad and tiles that span
-// whole rings fall back to the generic fp64 evaluation (healpix_cxx get_interpol on the displaced vector).
+// only fp64 arithmetic left per pixel).  Pixels next to a pole and displacements beyond one ring / 3 columns / 0.02 rad take
+// the generic fp64 evaluation (healpix_cxx get_interpol on the displaced vector).
+//
+// Ownership.  Every OUTPUT pixel belongs to one workgroup (tile_regrid3_kernel below): no global atomics, no zero-fill.
 #pragma once
 #include "bfgx_kernels.hpp"
 #include "bfgx_scatter2.hpp"
@@ -26,11 +26,6 @@ struct alignas(16) RegRowC {
     real c0, s0;                          // cos / sin of the azimuth of the tile's first pixel (ks) in this ring
     real inv_dth_up, inv_dth_dn;          // 1 / (theta_r - theta_{r-1}), 1 / (theta_{r+1} - theta_r); 0 where there is no such ring
 };
-
-__host__ __device__ inline size_t regrid2_lds_bytes(int BR, int W, size_t real_size)
-{
-    return (size_t)(BR + 2 * kApronR) * (W + 2 * kApronK) * sizeof(double) + (size_t)(BR + 2 * kApronR + 2) * (sizeof(RegRow) + 8 * real_size);
-}
 
 // the 4 targets of one displaced pixel by the generic route: get_interpol (healpix_cxx) on (theta, phi) of v + o, fp64
 __device__ inline void regrid_targets_generic(const Hpx &h, const RegRow *rows, int LR, int rth0, int ti, int x,
@@ -203,154 +198,6 @@ __device__ inline bool regrid_near_targets(const RegRow *rows, const RegRowC<rea
     return true;
 }
 
-template <typename ACC, typename real>
-__global__ void __launch_bounds__(256)
-tile_regrid2_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
-                    double *__restrict__ map_out, int tile_off, int64_t wlo, int64_t whi, int32_t *__restrict__ oob_flag,
-                    double *__restrict__ tile_sums)
-{
-    // map_out, offsets and map_in are indexed by GLOBAL pixel number; a rank that owns only a range of bands passes
-    // pointers shifted accordingly and the window [wlo, whi) of map_out that really exists.  A deposit outside the
-    // window (a displacement of more than the window margin) is dropped and flagged, never written.
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int LR = T.BR + 2 * kApronR, LW = T.W + 2 * kApronK;
-    double *acc = reinterpret_cast<double *>(smem);            // [LR][LW]
-    RegRow *rows = reinterpret_cast<RegRow *>(acc + LR * LW);  // rings rth0 .. rth0 + LR + 1
-    RegRowC<real> *rowc = reinterpret_cast<RegRowC<real> *>(rows + LR + 2);
-    const int tile = blockIdx.x + tile_off;
-    double sum_in = 0.0, sum_out = 0.0;                        // mass-conservation sums (HealpixRunner.py:344-345)
-    auto out_add = [&](int64_t p, double v) {
-        if (p >= wlo && p < whi) { atomicAdd(map_out + p, v); sum_out += v; }
-        else atomicOr(oob_flag, 1);
-    };
-    const int band = T.tile_band[tile];
-    const int nphi = T.band_nphi[band];
-    const int tj = tile - T.band_tile0[band];
-    const int nl4 = (int)(4 * h.nside);
-    const int i0 = 1 + band * T.BR;
-    const int i1 = min(i0 + T.BR, nl4);                        // exclusive
-    const int tid = threadIdx.x;
-    const int rth0 = i0 - kApronR - 1;
-    for (int i = tid; i < LR * LW; i += 256) acc[i] = 0.0;
-    if (tid < LR + 2) {
-        const int ring = rth0 + tid;
-        RegRow rw;
-        rw.theta = (ring < 1) ? -1.0e300 : 1.0e300;
-        rw.z = rw.sth = rw.dphi = rw.inv_dphi = rw.c0 = rw.s0 = 0.0;
-        rw.start = 0; rw.nr = 0; rw.ks = 0; rw.ke = 0; rw.shf = 0;
-        if (ring >= 1 && ring <= nl4 - 1) {
-            int64_t st, nr64; bool shf;
-            ring_info_small(h, ring, st, nr64, shf);
-            ring_z_sth(h, ring, rw.z, rw.sth);
-            rw.theta = atan2_generic(rw.sth, rw.z);
-            rw.start = st; rw.nr = (int)nr64; rw.shf = shf ? 1 : 0;
-            rw.dphi = kTwoPi / (double)rw.nr;
-            rw.inv_dphi = (double)rw.nr * kInvTwoPi;
-            rw.ks = tile_ks(tj, rw.nr, nphi);
-            rw.ke = tile_ks(tj + 1, rw.nr, nphi);
-            sincos_bounded(((double)rw.ks + (shf ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
-        }
-        rows[tid] = rw;
-    }
-    __syncthreads();
-    if (tid < LR + 2) {
-        const RegRow &rw = rows[tid];
-        RegRowC<real> rc;
-        rc.z = (real)rw.z; rc.sth = (real)rw.sth; rc.dphi = (real)rw.dphi; rc.inv_dphi = (real)rw.inv_dphi;
-        rc.c0 = (real)rw.c0; rc.s0 = (real)rw.s0;
-        rc.inv_dth_up = (real)0; rc.inv_dth_dn = (real)0;
-        if (rw.nr > 0) {
-            if (tid > 0 && rows[tid - 1].nr > 0) rc.inv_dth_up = (real)(1.0 / (rw.theta - rows[tid - 1].theta));
-            if (tid < LR + 1 && rows[tid + 1].nr > 0) rc.inv_dth_dn = (real)(1.0 / (rows[tid + 1].theta - rw.theta));
-        }
-        rowc[tid] = rc;
-    }
-    __syncthreads();
-
-    auto add_target = [&](int ring_t, int k_t, double v) {
-        const int ti = ring_t - rth0;
-        if (ti >= 1 && ti <= LR) {                             // rings i0 - kApronR .. i1 + kApronR - 1 own an LDS row
-            const RegRow &rt = rows[ti];
-            int dk = k_t - rt.ks;
-            if (dk >= LW - kApronK) dk -= rt.nr;
-            if (dk < -kApronK) dk += rt.nr;
-            if (dk >= -kApronK && dk < LW - kApronK) { atomicAdd(acc + (ti - 1) * LW + dk + kApronK, v); return; }
-            out_add(rt.start + k_t, v);                        // far target in a window ring (rare)
-            return;
-        }
-        int64_t st_t, nr64; bool sh_t;
-        ring_info_small(h, ring_t, st_t, nr64, sh_t);
-        out_add(st_t + k_t, v);                                // far target (rare)
-    };
-
-    // source pixels of the tile; the loads of pixel i+1 are issued before pixel i is processed
-    struct Src { int ti, x; bool ok; double val; ACC o0, o1, o2; };
-    const int wshift = ((T.W & (T.W - 1)) == 0) ? __ffs(T.W) - 1 : -1;      // W a power of two: shift instead of divide
-    auto fetch = [&](int idx) {
-        Src sx;
-        sx.ok = false; sx.ti = 0; sx.x = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (ACC)0;
-        if (idx < T.BR * T.W) {
-            const int r = (wshift >= 0) ? (idx >> wshift) : idx / T.W, x = idx - r * T.W;
-            if (i0 + r < i1) {
-                const RegRow &rw = rows[r + kApronR + 1];
-                if (x < rw.ke - rw.ks) {
-                    const int64_t p = rw.start + rw.ks + x;
-                    sx.ok = true; sx.ti = r + kApronR + 1; sx.x = x;
-                    sx.val = map_in[p];
-                    sx.o0 = offsets[3 * p + 0]; sx.o1 = offsets[3 * p + 1]; sx.o2 = offsets[3 * p + 2];
-                }
-            }
-        }
-        return sx;
-    };
-    Src nxt = fetch(tid);
-    for (int idx = tid; idx < T.BR * T.W; idx += 256) {
-        const Src cur = nxt;
-        nxt = fetch(idx + 256);
-        if (cur.ok) sum_in += cur.val;
-        if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
-        const double val = cur.val;
-        int tr[4], tk[4];
-        double w[4];
-        if (!regrid_near_targets<real>(rows, rowc, rth0, cur.ti, cur.x, (real)cur.o0, (real)cur.o1, (real)cur.o2, (real)4, tr, tk, w))
-            regrid_targets_generic(h, rows, LR, rth0, cur.ti, cur.x, (double)cur.o0, (double)cur.o1, (double)cur.o2, tr, tk, w);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) add_target(tr[q4], tk[q4], w[q4] * val);    // regrid_pixels_hpix :64
-    }
-    __syncthreads();
-
-    // flush: row-contiguous fp64 atomics
-    const int lane = tid & (kWave - 1), wid = tid / kWave;
-    for (int rr = wid; rr < LR; rr += 256 / kWave) {
-        const RegRow &rt = rows[rr + 1];
-        if (rt.nr == 0) continue;
-        const int k0 = rt.ks - kApronK;
-        for (int xx = lane; xx < LW; xx += kWave) {
-            const double v = acc[rr * LW + xx];
-            if (v != 0.0) {
-                int k = k0 + xx;
-                if (k < 0) k += rt.nr;
-                if (k >= rt.nr) k -= rt.nr;
-                if (k < 0 || k >= rt.nr) { k %= rt.nr; if (k < 0) k += rt.nr; }
-                out_add(rt.start + k, v);
-            }
-        }
-    }
-    if (tile_sums) {
-        __syncthreads();                                   // acc is free again: reuse its first words for the block reduction
-#pragma unroll
-        for (int sft = kWave >> 1; sft > 0; sft >>= 1) { sum_in += __shfl_down(sum_in, sft, kWave); sum_out += __shfl_down(sum_out, sft, kWave); }
-        if (lane == 0) { acc[2 * wid] = sum_in; acc[2 * wid + 1] = sum_out; }
-        __syncthreads();
-        if (tid == 0) {
-            double sa_ = 0.0, sb_ = 0.0;
-            for (int wv = 0; wv < 256 / kWave; ++wv) { sa_ += acc[2 * wv]; sb_ += acc[2 * wv + 1]; }
-            tile_sums[2 * (int64_t)tile] = sa_; tile_sums[2 * (int64_t)tile + 1] = sb_;
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------- K2, gathering form (full-map regrid)
 // The scatter form above ends in ~1.3 global fp64 atomics per map pixel (tile + apron), which is what bounds it (the
 // memory-side atomic rate), and it needs a zeroed output.  The gathering form makes every OUTPUT pixel the property of one
@@ -379,14 +226,17 @@ __host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_s
 template <typename ACC, typename real>
 __global__ void __launch_bounds__(256)
 tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
-                    double *__restrict__ map_out, FarList far, double *__restrict__ tile_sums)
+                    double *__restrict__ map_out, FarList far, double *__restrict__ tile_sums, int tile_off)
 {
+    // map_in, offsets and map_out are indexed by GLOBAL pixel number.  tile_off < 0: all tiles, heavy ones first; tile_off >= 0
+    // (a rank that owns a range of bands): tiles tile_off + blockIdx.x, and the caller passes offsets / map_out pointers
+    // shifted so that only the pixels this rank holds (its bands + one ring either side / its bands) are touched.
     extern __shared__ __align__(16) unsigned char smem[];
     const int NT = T.BR + 2 * kGatherR + 2;                    // rings rth0 .. rth0 + NT - 1 in the ring tables
     double *acc = reinterpret_cast<double *>(smem);            // [BR][W]: the tile's own pixels
     RegRow *rows = reinterpret_cast<RegRow *>(acc + T.BR * T.W);
     RegRowC<real> *rowc = reinterpret_cast<RegRowC<real> *>(rows + NT);
-    const int tile = T.tile_order[blockIdx.x];
+    const int tile = (tile_off < 0) ? T.tile_order[blockIdx.x] : tile_off + (int)blockIdx.x;
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
@@ -531,6 +381,19 @@ regrid_far_kernel(FarList far, double *__restrict__ map_out)
     if ((int64_t)n > far.cap) n = (unsigned long long)far.cap;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
         atomicAdd(map_out + far.pix[i], far.val[i]);
+}
+
+// banded regrid: adds the listed deposits whose pixel lies in [p0, p1) to the slice that starts at pixel p0, counts the others
+__global__ void __launch_bounds__(256)
+regrid_far_local_kernel(FarList far, double *__restrict__ out_slice, int64_t p0, int64_t p1, unsigned long long *__restrict__ foreign)
+{
+    unsigned long long n = *far.count;
+    if ((int64_t)n > far.cap) n = (unsigned long long)far.cap;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const int64_t p = far.pix[i];
+        if (p >= p0 && p < p1) atomicAdd(out_slice + (p - p0), far.val[i]);
+        else if (foreign) atomicAdd(foreign, 1ull);
+    }
 }
 
 }  // namespace bfgx

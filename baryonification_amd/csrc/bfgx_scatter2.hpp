@@ -183,6 +183,7 @@ template <int MODE, typename real>
 __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const RowC2<real> rc, const PairRecT<real> *pairs,
                                  const RingC2<real> *ringc, int t, bool act, int wsh, int wmask)
 {
+    using PM = PMath<real>;
     const int jj = t - (int)(rc.pk & 0xFFFu);
     const int rl = (int)((rc.pk >> 18) & 63u);
     o.la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);

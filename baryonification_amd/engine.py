@@ -53,11 +53,33 @@ class ShellPlan(object):
         _lib.check(_lib.load().bfgx_plan_bands(self._h, C.byref(nb), first.ctypes.data))
         return first
 
-    def regrid_bands(self, band0, band1, map_in_ptr, offsets_slice_ptr, window_ptr, wlo, whi, acc_f64=False):
-        """K2 for the source pixels of bands [band0, band1) only; window = output pixels [wlo, whi), zeroed by the caller"""
+    def band_apron(self, band0, band1):
+        """pixel range [olo, ohi) of summed pix_offsets the owner of bands [band0, band1) needs: its pixels + one ring either side"""
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().bfgx_plan_band_apron(self._h, int(band0), int(band1), C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def regrid_bands(self, band0, band1, map_in_ptr, offsets_ptr, olo, ohi, out_slice_ptr, sums_ptr=0, acc_f64=False):
+        """K2 for the OUTPUT pixels of bands [band0, band1): offsets_ptr -> summed pix_offsets of pixels [olo, ohi) (band_apron),
+        out_slice_ptr -> the bands' own pixels (stored once, no zero-fill).  Far deposits: far_fetch()."""
         _lib.check(_lib.load().bfgx_regrid_bands_device(self._h, int(band0), int(band1), C.c_void_p(int(map_in_ptr)),
-                                                       C.c_void_p(int(offsets_slice_ptr)), int(acc_f64), C.c_void_p(int(window_ptr)),
-                                                       int(wlo), int(whi)))
+                                                       C.c_void_p(int(offsets_ptr)), int(olo), int(ohi), int(acc_f64),
+                                                       C.c_void_p(int(out_slice_ptr)), C.c_void_p(int(sums_ptr) or None)))
+
+    def far_apply(self, out_slice_ptr, p0, p1, foreign_ptr=0):
+        """enqueue-only: add the listed deposits that fall into pixels [p0, p1) to the slice; count the others into *foreign_ptr"""
+        _lib.check(_lib.load().bfgx_plan_far_apply_device(self._h, C.c_void_p(int(out_slice_ptr)), int(p0), int(p1),
+                                                         C.c_void_p(int(foreign_ptr) or None)))
+
+    def far_fetch(self):
+        """(pixels, values) of the deposits the last regrid listed instead of applying (banded regrid only); blocking"""
+        n = C.c_int64(0)
+        _lib.check(_lib.load().bfgx_plan_far_fetch(self._h, 0, None, None, C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros(0)
+        pix, val = np.zeros(n.value, dtype=np.int64), np.zeros(n.value)
+        _lib.check(_lib.load().bfgx_plan_far_fetch(self._h, n.value, pix.ctypes.data, val.ctypes.data, C.byref(n)))
+        return pix, val
 
     def paint(self, cat_dev, map_out_ptr, acc_f64=True):
         """K0 + K3 (HealpixRunner.py:418-445)"""

@@ -12,10 +12,16 @@ xGMI is a point-to-point mesh (one link per peer), so a ring reduce of the whole
 (`exchange='slices'`): the sphere's ring bands are dealt out to the ranks in contiguous pixel ranges,
   1. all_to_all: every rank sends slice j of its accumulator straight to rank j (all 7 links busy, 1/N of the
      data per link) and sums the N slices it receives -- a reduce-scatter;
-  2. BaryonifyShell only: every rank regrids the source pixels of ITS bands (K2 on 1/N of the map) into a window
-     that is a few rings wider than its slice (deposits cross the band boundary by at most a pixel or two);
-  3. all_to_all with empty splits except towards rank 0: the windows (slices for PaintProfilesShell) travel to
-     rank 0 over separate links and are added into the final map.
+  2. BaryonifyShell only: a halo exchange of ONE ring with the two neighbouring ranks (the gathering regrid evaluates
+     the displaced pixels of the ring either side of its bands), then every rank regrids ITS bands: K2 on 1/N of the
+     map, every output pixel of the slice stored exactly once (no window margins, no overlap to sum); the rare deposits
+     that need the generic route (pole caps, moves of several pixels) are listed with global pixel numbers and added by
+     whichever rank holds the pixel;
+  3. the disjoint slices travel to rank 0 in one all_to_all with empty splits except towards rank 0 (`result='root'`),
+     or to every rank with one all_gather (`result='all'`).
+Bytes per link at N = 8, NSIDE 1024 (1e6-halo shards): step 1 moves 151 MB / 8 = 18.9 MB of f32 pix_offsets to each of
+7 peers, i.e. per direction of one ~153 GB/s xGMI link ~0.12 ms; step 2 a 49 KB ring to 2 peers; step 3 12.6 MB of f64
+map to rank 0 over 7 separate links (~0.08 ms) or 7 x 12.6 MB into every rank for `result='all'`.
 `exchange='reduce'` keeps the single `reduce(sum)` to rank 0 (== Parallelize.py:318; for BaryonifyShell on
 pix_offsets BEFORE the regrid, which rank 0 then runs once).  Summing offsets is exact because every halo's
 contribution is computed against the undisplaced grid (HealpixRunner.py:312-331); the reference refuses Baryonify
@@ -24,9 +30,10 @@ runners in SplitJoinParallel (Parallelize.py:206-209) only because it can sum no
 Entry points
   shard_slices(n, world)                        -- the reference's ceil(N/njobs) contiguous split
   band_partition(first_pixel, world)            -- ring bands -> ranks, balanced by pixel count
-  sliced_reduce / gather_windows                -- the two all_to_all steps above (any backend)
+  sliced_reduce / halo_exchange / gather_slices -- the collective steps above (any backend)
   distributed_process(runner, kind, ...)        -- call from every rank of an initialised process group
-  SplitJoinParallel(runner, njobs, seed).process()  -- drop-in: spawns one process per GPU and returns the map
+  SplitJoinParallel(runner, njobs, seed).process()  -- drop-in: all GPUs of the node from ONE process through the C ABI
+                                                   (bfgx_*_shell_multi), or one process per GPU with backend='nccl'
 
 `compute`, `bounds` and `regrid_slice` are injectable so the sharding / collective logic can be exercised on CPU
 ranks (gloo) in the test-suite; the product default is the HIP engine and there is no CPU fallback.
@@ -36,7 +43,7 @@ import os
 import numpy as np
 
 __all__ = ['SplitJoinParallel', 'SimpleParallel', 'shard_slices', 'distributed_process', 'band_partition', 'sliced_reduce',
-           'gather_windows']
+           'halo_exchange', 'gather_slices']
 
 
 def shard_slices(n, world):
@@ -70,7 +77,7 @@ def _hip_compute(runner, kind, cat_cols, device):
     else:
         acc = torch.zeros(npix, dtype=torch.float64, device=dev)
         plan.paint(cd, acc.data_ptr(), acc_f64=True)
-    torch.cuda.synchronize(dev)
+    plan.status()            # blocking: the halo -> tile entry list did not overflow (a resident plan does not regrow it)
     return acc, plan
 
 
@@ -118,64 +125,118 @@ def sliced_reduce(acc, bounds, width, recv=None):
     return recv.view(world, mylen).sum(0)
 
 
-def gather_windows(win, windows, npix, recv=None, out=None):
-    """Every rank's window (pixels [wlo_j, whi_j) of the output map, possibly overlapping its neighbours') travels to
-    rank 0 in ONE all_to_all whose splits are empty except towards rank 0, which adds them into the full map."""
+def _a2a(recv, send, outs, ins):
     import torch.distributed as dist
-    rank, world = dist.get_rank(), dist.get_world_size()
-    lens = [int(hi - lo) for lo, hi in windows]
-    ins = [lens[rank]] + [0] * (world - 1)
-    outs = lens if rank == 0 else [0] * world
-    if recv is None:
-        recv = win.new_empty(sum(outs))
-    if win.is_cuda and dist.get_backend() == 'gloo':
-        r = win.new_empty(sum(outs), device='cpu')
-        dist.all_to_all_single(r, win.cpu(), output_split_sizes=outs, input_split_sizes=ins)
+    if send.is_cuda and dist.get_backend() == 'gloo':       # rehearsal on a box without RCCL peers: stage through the host
+        r = send.new_empty(sum(outs), device='cpu')
+        dist.all_to_all_single(r, send.cpu(), output_split_sizes=outs, input_split_sizes=ins)
         recv.copy_(r)
     else:
-        dist.all_to_all_single(recv, win, output_split_sizes=outs, input_split_sizes=ins)
+        dist.all_to_all_single(recv, send, output_split_sizes=outs, input_split_sizes=ins)
+    return recv
+
+
+def halo_exchange(mine, pb, needs, width):
+    """After the reduce-scatter rank j holds the summed values of pixels [pb[j], pb[j+1]) (`mine`, `width` numbers per
+    pixel); it needs the pixels needs[j] = (lo_j, hi_j), a superset that reaches into its neighbours' slices.  One
+    all_to_all whose splits are empty except towards the ranks that need a piece of this rank's slice.  Returns the
+    tensor of pixels [lo_rank, hi_rank)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def piece(owner, taker):
+        """pixel range of `owner`'s slice that `taker` needs (taker != owner): below or above the taker's own slice"""
+        lo, hi = needs[taker]
+        if owner < taker:
+            a, b = max(int(pb[owner]), int(lo)), min(int(pb[owner + 1]), int(pb[taker]))
+        else:
+            a, b = max(int(pb[owner]), int(pb[taker + 1])), min(int(pb[owner + 1]), int(hi))
+        return (a, b) if b > a else (0, 0)
+
+    p0 = int(pb[rank])
+    send_ranges = [piece(rank, i) if i != rank else (0, 0) for i in range(world)]
+    recv_ranges = [piece(j, rank) if j != rank else (0, 0) for j in range(world)]
+    ins = [(b - a) * width for a, b in send_ranges]
+    outs = [(b - a) * width for a, b in recv_ranges]
+    send = torch.cat([mine[(a - p0) * width:(b - p0) * width] for a, b in send_ranges]) if sum(ins) else mine.new_empty(0)
+    recv = _a2a(mine.new_empty(sum(outs)), send, outs, ins)
+    lo, hi = int(needs[rank][0]), int(needs[rank][1])
+    full = mine.new_empty((hi - lo) * width)
+    full[(p0 - lo) * width:(int(pb[rank + 1]) - lo) * width] = mine
+    o = 0
+    for (a, b), n in zip(recv_ranges, outs):
+        if n:
+            full[(a - lo) * width:(b - lo) * width] = recv[o:o + n]
+            o += n
+    return full
+
+
+def gather_slices(mine, pb, npix, result='root', recv=None, out=None):
+    """The ranks' disjoint slices (pixels [pb[j], pb[j+1])) -> the full map on rank 0 (`result='root'`: one all_to_all with
+    empty splits except towards rank 0, 7 separate links) or on every rank (`result='all'`: one all_gather of slices
+    padded to the longest).  Returns the map or None."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lens = [int(pb[j + 1] - pb[j]) for j in range(world)]
+    if result == 'all':
+        L = max(lens)
+        pad = mine if lens[rank] == L else torch.cat([mine, mine.new_zeros(L - lens[rank])])
+        buf = mine.new_empty(world * L)
+        if mine.is_cuda and dist.get_backend() == 'gloo':
+            b = buf.cpu()
+            dist.all_gather_into_tensor(b, pad.cpu())
+            buf.copy_(b)
+        else:
+            dist.all_gather_into_tensor(buf, pad)
+        full = out if out is not None else mine.new_empty(npix)
+        for j in range(world):
+            full[int(pb[j]):int(pb[j + 1])] = buf[j * L:j * L + lens[j]]
+        return full
+    assert result == 'root', "result must be 'root' or 'all'"
+    ins = [lens[rank]] + [0] * (world - 1)
+    outs = lens if rank == 0 else [0] * world
+    if rank == 0 and out is not None and recv is None:
+        recv = out                                        # the slices arrive in rank order = pixel order: receive in place
+    if recv is None:
+        recv = mine.new_empty(sum(outs))
+    _a2a(recv, mine, outs, ins)
     if rank != 0:
         return None
-    full = out if out is not None else win.new_zeros(npix)
-    if out is not None:
-        full.zero_()
-    o = 0
-    for (lo, hi), n in zip(windows, lens):
-        full[int(lo):int(hi)] += recv[o:o + n]
-        o += n
-    return full
+    return recv
 
 
 def _hip_bounds(runner, plan, world):
     first = plan.bands()
     cuts = band_partition(first, world)
-    return cuts, first[cuts]
+    needs = [plan.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
+    return cuts, first[cuts], needs
 
 
-def _hip_regrid_slice(runner, plan, my_off, b0, b1, wlo, whi, device):
-    """K2 on the bands [b0, b1) this rank owns; returns the window tensor (pixels [wlo, whi))"""
+def _hip_regrid_slice(runner, plan, off_apron, olo, ohi, b0, b1, p0, p1, device):
+    """K2 for the output pixels [p0, p1) of the bands [b0, b1) this rank owns; returns (slice tensor, far pixels, far values,
+    [sum of the rank's source pixels, sum of its deposits])"""
     import torch
     dev = torch.device('cuda', device)
     hmap = torch.from_numpy(np.ascontiguousarray(runner.LightconeShell.map, dtype=np.float64)).to(dev)
-    win = torch.zeros(int(whi - wlo), dtype=torch.float64, device=dev)
-    plan.regrid_bands(b0, b1, hmap.data_ptr(), my_off.data_ptr(), win.data_ptr(), wlo, whi, acc_f64=False)
-    plan.status()
-    return win
-
-
-def window_margin(nside):
-    """pixels by which a rank's output window exceeds its slice on either side: more than 4 rings anywhere"""
-    return 16 * int(nside)
+    out = torch.empty(int(p1 - p0), dtype=torch.float64, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.regrid_bands(b0, b1, hmap.data_ptr(), off_apron.data_ptr(), olo, ohi, out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    pix, val = plan.far_fetch()
+    return out, pix, val, sums.cpu().numpy()
 
 
 def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid=None, exchange='slices', bounds=None,
-                        regrid_slice=None):
+                        regrid_slice=None, result='root'):
     """Run `runner` (holding the FULL catalog on every rank) halo-sharded over the ranks of the default
-    torch.distributed group.  Returns the final map on rank 0, None elsewhere.
+    torch.distributed group.  Returns the final map on rank 0 (`result='root'`; None elsewhere) or on every rank
+    (`result='all'`, exchange='slices').
 
     compute(runner, kind, cat_cols, device) -> (tensor accumulator, ctx); exchange='reduce': regrid(runner, ctx, acc,
-    device) -> ndarray on rank 0; exchange='slices': bounds(runner, ctx, world) -> (band cuts, pixel bounds) and
-    regrid_slice(runner, ctx, my_offsets, b0, b1, wlo, whi, device) -> window tensor.  All default to the HIP engine."""
+    device) -> ndarray on rank 0; exchange='slices': bounds(runner, ctx, world) -> (band cuts, pixel bounds, needs) and
+    regrid_slice(runner, ctx, offsets_with_apron, olo, ohi, b0, b1, p0, p1, device) -> (slice tensor, far pixels, far
+    values, sums).  All default to the HIP engine."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -186,7 +247,15 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
     cols = {k: np.ascontiguousarray(cat[k][mine]) for k in cat.dtype.names}
     if device is None:
         device = int(os.environ.get('LOCAL_RANK', rank))
-    acc, ctx = compute(runner, kind, cols, device)
+    # a failure on ONE rank (device out of memory, entry-list overflow) must not leave the others waiting in a collective:
+    # the ranks agree on success before every exchange step and raise together
+    err = None
+    acc = ctx = None
+    try:
+        acc, ctx = compute(runner, kind, cols, device)
+    except Exception as e:        # noqa: BLE001
+        err = e
+    _agree(err, acc.device if acc is not None else None)
     if exchange == 'reduce':
         regrid = regrid or _hip_regrid
         dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
@@ -198,22 +267,51 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
     assert exchange == 'slices', "exchange must be 'slices' or 'reduce'"
     nside = int(runner.LightconeShell.NSIDE)
     npix = 12 * nside * nside
-    cuts, pb = (bounds or _hip_bounds)(runner, ctx, world)
+    cuts, pb, needs = (bounds or _hip_bounds)(runner, ctx, world)
     if kind != 'baryonify':
         mine_sum = sliced_reduce(acc, pb, 1)
-        full = gather_windows(mine_sum, [(pb[j], pb[j + 1]) for j in range(world)], npix)
-        return None if rank != 0 else full.cpu().numpy().astype(np.float64)
+        full = gather_slices(mine_sum, pb, npix, result)
+        return None if full is None else full.cpu().numpy().astype(np.float64)
     my_off = sliced_reduce(acc, pb, 3)
-    m = window_margin(nside)
-    wins = [(max(0, int(pb[j]) - m), min(npix, int(pb[j + 1]) + m)) for j in range(world)]
-    win = (regrid_slice or _hip_regrid_slice)(runner, ctx, my_off, int(cuts[rank]), int(cuts[rank + 1]), wins[rank][0], wins[rank][1], device)
-    full = gather_windows(win, wins, npix)
-    if rank != 0:
+    off_apron = halo_exchange(my_off, pb, needs, 3)
+    err, sl, fpix, fval, sums = None, None, np.zeros(0, dtype=np.int64), np.zeros(0), np.zeros(2)
+    try:
+        sl, fpix, fval, sums = (regrid_slice or _hip_regrid_slice)(runner, ctx, off_apron, int(needs[rank][0]), int(needs[rank][1]),
+                                                                  int(cuts[rank]), int(cuts[rank + 1]), int(pb[rank]), int(pb[rank + 1]), device)
+    except Exception as e:        # noqa: BLE001
+        err = e
+    _agree(err, my_off.device)
+    # far deposits (global pixel numbers, almost always none): every rank learns all of them and adds those in its slice
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (np.asarray(fpix), np.asarray(fval), np.asarray(sums)))
+    p0, p1 = int(pb[rank]), int(pb[rank + 1])
+    for fp, fv, _ in gathered:
+        if len(fp):
+            m = (fp >= p0) & (fp < p1)
+            if m.any():
+                sl.index_add_(0, torch.from_numpy(fp[m] - p0).to(sl.device), torch.from_numpy(fv[m]).to(sl.device))
+    full = gather_slices(sl, pb, npix, result)
+    if full is None:
         return None
     new_map = full.cpu().numpy().astype(np.float64)
-    new_sum, old_sum = new_map.sum(), np.sum(runner.LightconeShell.map)
+    new_sum = sum(float(g[2][1]) + float(np.sum(g[1])) for g in gathered)
+    old_sum = sum(float(g[2][0]) for g in gathered)
     assert np.isclose(new_sum, old_sum), "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
     return new_map
+
+
+def _agree(err, device):
+    """collective: raise on every rank if any rank failed"""
+    import torch
+    import torch.distributed as dist
+    use_cuda = dist.get_backend() == 'nccl'
+    flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=(device if (use_cuda and device is not None) else
+                                                                                  ('cuda' if use_cuda else 'cpu')))
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if err is not None:
+        raise err
+    if int(flag.item()):
+        raise RuntimeError("another rank failed in the halo-sharded run (see its log)")
 
 
 def _spawn_worker(rank, world, port, runner, kind, seed, backend, out_path):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BFGX_ABI_VERSION 1
+#define BFGX_ABI_VERSION 2
 #define BFGX_MAX_EXTRA 2          /* extra (per-halo parameter) table axes, model.p_keys */
 #define BFGX_MAX_DIM (3 + BFGX_MAX_EXTRA)
 
@@ -157,15 +157,24 @@ int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offset
 int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
                         double *map_out_dev, double *sums_dev);
 /* Multi-GPU form of K2: the sphere is cut into bands of consecutive rings (contiguous RING pixel ranges); a rank that
- * owns bands [band0, band1) regrids only their source pixels.  bfgx_plan_bands returns the number of bands and, in
- * band_first_pixel[nbands + 1] (may be NULL), the first pixel of every band (+ npix).  offsets_slice_dev holds the
- * summed pix_offsets of the owned pixels only ([p1 - p0][3], p0 = band_first_pixel[band0]); window_dev holds the
- * output pixels [wlo, whi) (zeroed by the caller), a superset of [p0, p1) widened by a margin of a few rings for the
- * deposits that cross the band boundary; map_in_dev is the full map.  A deposit outside the window is dropped and
- * reported by the next bfgx_plan_status (never happens for sub-pixel displacements). */
+ * owns bands [band0, band1) produces exactly THEIR output pixels.  bfgx_plan_bands returns the number of bands and, in
+ * band_first_pixel[nbands + 1] (may be NULL), the first pixel of every band (+ npix).  The gathering regrid evaluates
+ * the displaced position of the rank's own pixels and of one ring either side: bfgx_plan_band_apron returns that pixel
+ * range [olo, ohi) -- the summed pix_offsets the rank must hold (offsets_dev points at pixel olo, [ohi - olo][3]).
+ * out_slice_dev points at the rank's first own pixel ([p1 - p0] values, every one stored exactly once, no zero-fill);
+ * map_in_dev is the full map; sums_dev (optional, double[2]) receives {sum of the rank's source pixels, sum of its
+ * deposits}.  Deposits that need the generic route (pole caps, displacements of more than 3 pixel columns / one ring)
+ * are NOT applied by this call: they are listed with global pixel numbers; bfgx_plan_far_fetch copies the list of the
+ * last regrid to the host (blocking; n_host = 0 almost always; NULL buffers: count only) so that the caller can add
+ * them to whichever rank's slice holds the pixel.  (bfgx_regrid_device applies its own list.) */
 int  bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel);
+int  bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *olo, int64_t *ohi);
 int  bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev,
-                              const void *offsets_slice_dev, int acc_f64, double *window_dev, int64_t wlo, int64_t whi);
+                              const void *offsets_dev, int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev);
+int  bfgx_plan_far_fetch(bfgx_plan *p, int64_t cap, int64_t *pix_host, double *val_host, int64_t *n_host);
+/* enqueue-only alternative: adds the listed deposits whose pixel lies in [p0, p1) to out_slice_dev (which starts at pixel
+ * p0) and adds the number of the others to *foreign_dev (optional device counter the caller inspects later) */
+int  bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0, int64_t p1, unsigned long long *foreign_dev);
 /* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */
 int  bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *map_out_dev, int acc_f64);
 /* optional per-kernel timing with HIP events recorded on the plan's stream around every launch.

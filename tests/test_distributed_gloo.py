@@ -49,28 +49,50 @@ def _ring_bands(nside, BR=8):
     return np.array(first + [12 * nside * nside], dtype=np.int64)
 
 
-def _oracle_bounds(runner, ctx, world):
-    first = _ring_bands(runner._golden['nside'])
+APRON_RINGS = 4          # the oracle regrids by scattering: sources up to 4 rings outside a slice are evaluated for it
+
+
+def _ring_first(nside, ring):
+    if ring < 1:
+        return 0
+    if ring >= 4 * nside:
+        return 12 * nside * nside
+    if ring < nside:
+        return 2 * ring * (ring - 1)
+    if ring < 3 * nside:
+        return 2 * nside * (nside - 1) + (ring - nside) * 4 * nside
+    q = 4 * nside - ring
+    return 12 * nside * nside - 2 * q * (q + 1)
+
+
+def _oracle_bounds(runner, ctx, world, BR=8):
+    nside = runner._golden['nside']
+    first = _ring_bands(nside, BR)
     cuts = band_partition(first, world)
-    return cuts, first[cuts]
+    needs = [(_ring_first(nside, 1 + BR * int(cuts[j]) - APRON_RINGS), _ring_first(nside, 1 + BR * int(cuts[j + 1]) + APRON_RINGS))
+             for j in range(world)]
+    return cuts, first[cuts], needs
 
 
-def _oracle_regrid_slice(runner, ctx, my_off, b0, b1, wlo, whi, device):
-    """regrid of the source pixels of this rank's slice only (oracle bfgo_regrid_range), returned as the window"""
+def _oracle_regrid_slice(runner, ctx, off_apron, olo, ohi, b0, b1, p0, p1, device):
+    """The output pixels [p0, p1) of this rank's bands: the oracle scatters the source pixels [olo, ohi) it was handed (its
+    own + the apron) and keeps what lands in the slice.  Returns (slice, far pixels, far values, [sum in, sum out])."""
     from oracle import oracle as O
     g = runner._golden
-    first = _ring_bands(g['nside'])
-    p0, p1 = int(first[b0]), int(first[b1])
     npix = 12 * g['nside'] ** 2
+    assert olo <= p0 and p1 <= ohi and off_apron.numel() == 3 * (ohi - olo)
     off = np.zeros((npix, 3))
-    off[p0:p1] = my_off.numpy().reshape(-1, 3)
+    off[olo:ohi] = off_apron.numpy().reshape(-1, 3)
     new_map = np.zeros(npix)
-    O.lib().bfgo_regrid_range(g['nside'], p0, p1, O._ptr(O._f8(g['map_in'])), O._ptr(off), O._ptr(new_map))
-    assert new_map[:wlo].sum() == 0 and new_map[whi:].sum() == 0         # deposits stay inside the window
-    return torch.from_numpy(new_map[wlo:whi].copy())
+    O.lib().bfgo_regrid_range(g['nside'], olo, ohi, O._ptr(O._f8(g['map_in'])), O._ptr(off), O._ptr(new_map))
+    own = np.zeros(npix)
+    O.lib().bfgo_regrid_range(g['nside'], p0, p1, O._ptr(O._f8(g['map_in'])), O._ptr(off), O._ptr(own))
+    assert own[:olo].sum() == 0 and own[ohi:].sum() == 0                 # the apron is wide enough for every deposit
+    sl = new_map[p0:p1].copy()
+    return torch.from_numpy(sl), np.zeros(0, dtype=np.int64), np.zeros(0), np.array([g['map_in'][p0:p1].sum(), sl.sum()])
 
 
-def _worker(rank, world, port, name, out_path, exchange='slices'):
+def _worker(rank, world, port, name, out_path, exchange='slices', result='root'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -80,11 +102,41 @@ def _worker(rank, world, port, name, out_path, exchange='slices'):
         runner._golden = g
         kind = 'baryonify' if g['kind'] == 'baryonify' else 'paint'
         out = distributed_process(runner, kind, seed=42, device=rank, compute=_oracle_compute, regrid=_oracle_regrid, exchange=exchange,
-                                  bounds=_oracle_bounds, regrid_slice=_oracle_regrid_slice)
-        if rank == 0:
+                                  bounds=_oracle_bounds, regrid_slice=_oracle_regrid_slice, result=result)
+        if result == 'all':
+            np.save(out_path + '.%d.npy' % rank, out)            # every rank holds the map
+        elif rank == 0:
             np.save(out_path, out)
         else:
             assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _failing_compute(runner, kind, cols, device):
+    if dist.get_rank() == 1:
+        raise MemoryError("rank 1 ran out of device memory")
+    return _oracle_compute(runner, kind, cols, device)
+
+
+def _worker_one_rank_fails(rank, world, port, name, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        runner = product_runner(g)
+        runner._golden = g
+        try:
+            distributed_process(runner, 'baryonify', seed=42, device=rank, compute=_failing_compute, bounds=_oracle_bounds,
+                                regrid_slice=_oracle_regrid_slice)
+            raised = 'none'
+        except MemoryError:
+            raised = 'own'
+        except RuntimeError as e:
+            raised = 'peer' if 'another rank failed' in str(e) else 'other'
+        with open(out_path + '.%d.txt' % rank, 'w') as f:
+            f.write(raised)
     finally:
         dist.destroy_process_group()
 
@@ -125,7 +177,7 @@ def test_multi_rank_gloo_equals_single_process(tmp_path, name, world, exchange):
 
 
 def test_five_rank_slice_exchange(tmp_path):
-    """more ranks than a fixture usually sees: interior ranks have windows overlapping both neighbours"""
+    """more ranks than a fixture usually sees: interior ranks exchange a ring apron with both neighbours"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -134,3 +186,28 @@ def test_five_rank_slice_exchange(tmp_path):
     out = np.load(out_path)
     ref = oracle_run(load_golden('lowz_baryonify'))
     assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('name', ['lowz_baryonify', 'lowz_paint'])
+def test_eight_rank_slice_exchange_both_runners(tmp_path, name):
+    """the node size the scaling bench uses (8 ranks), both runners, result on every rank (all_gather of the slices)"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / 'out')
+    mp.spawn(_worker, args=(8, port, name, out_path, 'slices', 'all'), nprocs=8, join=True)
+    ref = oracle_run(load_golden(name))
+    for rank in range(8):
+        out = np.load(out_path + '.%d.npy' % rank)
+        assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_one_failing_rank_raises_on_every_rank(tmp_path):
+    """a rank that fails before a collective must not leave its peers blocked in it: all ranks raise"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / 'flag')
+    mp.spawn(_worker_one_rank_fails, args=(3, port, 'lowz_baryonify', out_path), nprocs=3, join=True)
+    got = [open(out_path + '.%d.txt' % r).read() for r in range(3)]
+    assert got == ['peer', 'own', 'peer']

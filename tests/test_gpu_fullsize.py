@@ -128,14 +128,16 @@ def test_config3_paint_full_size_properties(gpu):
 
 
 def test_banded_regrid_equals_full_regrid(gpu):
-    """multi-GPU building block on one GPU: regridding the source pixels band range by band range into windows and
-    adding the windows reproduces the full-map regrid (what N ranks + gather_windows do)"""
+    """multi-GPU building block on one GPU: every "rank" regrids the OUTPUT pixels of its bands from the summed pix_offsets of
+    those bands + one ring either side (what sliced_reduce + halo_exchange hand it); the disjoint slices put side by side
+    (+ the listed far deposits) are the full-map regrid (what N ranks + gather_slices do)"""
     import torch
     from baryonification_amd import _lib, engine, synthetic as syn
-    from baryonification_amd.utils.Parallelize import band_partition, window_margin
+    from baryonification_amd.utils.Parallelize import band_partition
     nside, nh = 256, 60_000
     npix = 12 * nside * nside
     cat = syn.make_catalog(nh)
+    cat['dec'][:6] = [89.9, -89.95, 89.99, -89.8, 89.7, -89.999]        # some halos on the pole caps: pixels of the first / last rings move
     z, M, r = syn.table_grid(cat)
     model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
     dev = torch.device('cuda:0')
@@ -145,33 +147,42 @@ def test_banded_regrid_equals_full_regrid(gpu):
     off = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
     plan.offsets(cd, off.data_ptr(), acc_f64=False)
     hmap = torch.from_numpy(syn.make_map(nside)).to(dev)
-    full = torch.zeros(npix, dtype=torch.float64, device=dev)
-    plan.regrid(hmap.data_ptr(), off.data_ptr(), full.data_ptr(), 0, acc_f64=False)
+    full = torch.full((npix,), np.nan, dtype=torch.float64, device=dev)          # not zeroed: every pixel must be stored
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.regrid(hmap.data_ptr(), off.data_ptr(), full.data_ptr(), sums.data_ptr(), acc_f64=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all().item() and np.isclose(sums[1].item(), sums[0].item()) and np.isclose(full.sum().item(), hmap.sum().item())
     first = plan.bands()
     assert first[0] == 0 and first[-1] == npix and np.all(np.diff(first) > 0)
     for world in (2, 5):
         cuts = band_partition(first, world)
         pb = first[cuts]
-        m = window_margin(nside)
-        acc = torch.zeros(npix, dtype=torch.float64, device=dev)
+        acc = torch.full((npix,), np.nan, dtype=torch.float64, device=dev)
+        s_in = s_out = 0.0
+        far_p, far_v = [], []
         for rk in range(world):
             p0, p1 = int(pb[rk]), int(pb[rk + 1])
-            wlo, whi = max(0, p0 - m), min(npix, p1 + m)
-            my_off = off[3 * p0:3 * p1].clone()                     # what sliced_reduce hands to rank rk
-            win = torch.zeros(whi - wlo, dtype=torch.float64, device=dev)
-            plan.regrid_bands(int(cuts[rk]), int(cuts[rk + 1]), hmap.data_ptr(), my_off.data_ptr(), win.data_ptr(), wlo, whi)
-            acc[wlo:whi] += win
-        plan.status()                                              # no deposit fell outside a window
-        torch.cuda.synchronize()
-        # the full-map regrid gathers per output tile, the banded one scatters per source tile: the fp32 per-pixel geometry of a
-        # pixel seen from two tiles differs by an fp32 ulp of its ~1e-5 rad displacement
-        assert (acc - full).abs().max().item() <= 1e-9 * full.abs().max().item()
-    # a window without margin must be reported, not silently corrupt memory
-    p0, p1 = int(pb[1]), int(pb[2])
-    win = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
-    plan.regrid_bands(int(cuts[1]), int(cuts[2]), hmap.data_ptr(), off[3 * p0:3 * p1].clone().data_ptr(), win.data_ptr(), p0, p1)
-    with pytest.raises(ValueError, match='window'):
+            olo, ohi = plan.band_apron(int(cuts[rk]), int(cuts[rk + 1]))
+            assert olo <= p0 and ohi >= p1 and (rk == 0) == (olo == 0) and (rk == world - 1) == (ohi == npix)
+            my_off = off[3 * olo:3 * ohi].clone()                   # what sliced_reduce + halo_exchange hand to rank rk
+            sl = acc[p0:p1]
+            sm = torch.zeros(2, dtype=torch.float64, device=dev)
+            plan.regrid_bands(int(cuts[rk]), int(cuts[rk + 1]), hmap.data_ptr(), my_off.data_ptr(), olo, ohi, sl.data_ptr(), sm.data_ptr())
+            fp, fv = plan.far_fetch()
+            far_p.append(fp); far_v.append(fv)
+            s_in += sm[0].item(); s_out += sm[1].item()
+        fp, fv = np.concatenate(far_p), np.concatenate(far_v)
+        if fp.size:
+            acc.index_add_(0, torch.from_numpy(fp).to(dev), torch.from_numpy(fv).to(dev))
         plan.status()
+        torch.cuda.synchronize()
+        assert np.isclose(s_in, hmap.sum().item()) and np.isclose(s_out, s_in)
+        # identical tiles evaluate identical pixels: the banded slices ARE the full-map regrid up to the order of LDS additions
+        assert (acc - full).abs().max().item() <= 1e-12 * full.abs().max().item()
+    # an offsets range that does not reach one ring beyond the bands is refused
+    p0, p1 = int(pb[1]), int(pb[2])
+    with pytest.raises(ValueError, match='one ring'):
+        plan.regrid_bands(int(cuts[1]), int(cuts[2]), hmap.data_ptr(), off[3 * p0:3 * p1].clone().data_ptr(), p0, p1, acc[p0:p1].data_ptr())
     plan.close()
 
 
