@@ -57,8 +57,25 @@ class DefaultRunner(object):
             assert ok, txt
 
     def _catalog(self, keys):
+        """bfgx_catalog over contiguous float64 columns.  The catalog is a structured array (strided columns), so every
+        process() call would gather M, z, ra, dec into contiguous buffers and take two numpy logs over all halos (the table
+        coordinates np.log(1/a), np.log(M)); these are kept on the catalog object between calls instead.  A cheap fingerprint
+        (size, end points and a strided sample of every column) guards against in-place edits of the catalog."""
         cat = self.HaloLightConeCatalog.cat
-        return _lib.make_catalog_host(cat['M'], cat['z'], cat['ra'], cat['dec'], [cat[k] for k in keys])
+        names = ['M', 'z', 'ra', 'dec'] + list(keys)
+        step = max(1, cat.size // 4096)
+        finger = (cat.size, tuple(names)) + tuple(float(np.sum(cat[k][::step], dtype=np.float64)) + float(cat[k][-1] if cat.size else 0.0)
+                                                  for k in names)
+        cached = getattr(self.HaloLightConeCatalog, '_bfgx_columns', None)
+        if cached is None or cached[0] != finger:
+            cols = [_lib.f8(cat[k]) for k in names]
+            cached = (finger, cols, _lib.table_coords(cols[0], cols[1]))
+            try:
+                self.HaloLightConeCatalog._bfgx_columns = cached
+            except AttributeError:
+                pass
+        cols = cached[1]
+        return _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], cols[4:], coords=cached[2])
 
 
 class BaryonifyShell(DefaultRunner):
@@ -72,7 +89,7 @@ class BaryonifyShell(DefaultRunner):
         cat, cols = self._catalog(p_keys)
         orig_map = _lib.f8(self.LightconeShell.map)
         nside = int(self.LightconeShell.NSIDE)
-        new_map = np.empty(orig_map.size, dtype=np.float64)
+        new_map = _lib.pinned_empty(orig_map.size)          # page-locked: the D2H copy of the result runs at PCIe rate
         opts = _lib.bfgx_opts(int(self.device), int(bool(self.acc_f64)), 1, 1, int(self.algo), 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_baryonify_shell(C.byref(cat), C.byref(model), nside, orig_map.ctypes.data,
@@ -93,7 +110,7 @@ class PaintProfilesShell(DefaultRunner):
         model, p_keys, keep = build_model(self, 'projected')
         cat, cols = self._catalog(p_keys)
         nside = int(self.LightconeShell.NSIDE)
-        new_map = np.empty(self.LightconeShell.map.size, dtype=np.float64)
+        new_map = _lib.pinned_empty(self.LightconeShell.map.size)
         acc64 = 1 if self.acc_f64 is None else int(bool(self.acc_f64))
         opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0, int(self.algo), 0)
         stats = _lib.bfgx_stats()

@@ -86,6 +86,10 @@ SYMBOLS = {
                                        _P(bfgx_opts), _P(bfgx_stats)]),
     'bfgx_paint_shell': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_void_p,
                                    _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_cache_clear': (None, []),
+    'bfgx_debug_alloc_count': (C.c_longlong, []),
+    'bfgx_host_alloc': (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
+    'bfgx_host_free': (None, [C.c_void_p]),
     'bfgx_plan_create': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, _P(bfgx_model), _P(C.c_void_p)]),
     'bfgx_plan_destroy': (None, [C.c_void_p]),
     'bfgx_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
@@ -258,14 +262,65 @@ def table_coords(M, z):
         return f8(np.log(1.0 / a)), f8(np.log(M))
 
 
-def make_catalog_host(M, z, ra, dec, extra=()):
+# ---- page-locked output arrays -----------------------------------------------------------------------------------
+# The map a runner returns is a plain numpy array whose memory is page-locked (hipHostMalloc), so that the device-to-host
+# copy of the result runs at the full PCIe rate.  Page-locking is slow (tens of ms for a 100 MB map), so buffers are pooled:
+# when the array (and every view of it) is garbage-collected its buffer returns to the pool and the next process() call of
+# the same size gets it back.  At most _PINNED_POOL_BYTES are kept; bfgx_cache_clear() style cleanup: pinned_pool_clear().
+_PINNED_POOL_BYTES = 4 << 30
+_pinned_pool = {}          # nbytes -> [ptr, ...]
+_pinned_pooled = 0
+
+
+def _pinned_release(ptr, nbytes):
+    global _pinned_pooled
+    try:
+        if _pinned_pooled + nbytes <= _PINNED_POOL_BYTES:
+            _pinned_pool.setdefault(nbytes, []).append(ptr)
+            _pinned_pooled += nbytes
+        else:
+            load().bfgx_host_free(C.c_void_p(ptr))
+    except Exception:        # interpreter shutdown
+        pass
+
+
+def pinned_pool_clear():
+    global _pinned_pooled
+    for nbytes, ptrs in _pinned_pool.items():
+        for ptr in ptrs:
+            load().bfgx_host_free(C.c_void_p(ptr))
+    _pinned_pool.clear()
+    _pinned_pooled = 0
+
+
+def pinned_empty(n, dtype=np.float64):
+    """np.empty(n, dtype) in page-locked memory (falls back to ordinary memory if page-locking fails)"""
+    global _pinned_pooled
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = max(int(n) * dtype.itemsize, 1)
+    ptrs = _pinned_pool.get(nbytes)
+    if ptrs:
+        ptr = ptrs.pop()
+        _pinned_pooled -= nbytes
+    else:
+        out = C.c_void_p(0)
+        if load().bfgx_host_alloc(nbytes, C.byref(out)) != OK or not out.value:
+            return np.empty(int(n), dtype=dtype)
+        ptr = out.value
+    raw = (C.c_char * nbytes).from_address(ptr)
+    weakref.finalize(raw, _pinned_release, ptr, nbytes)       # runs when the last numpy view of `raw` is gone
+    return np.frombuffer(raw, dtype=dtype, count=int(n))
+
+
+def make_catalog_host(M, z, ra, dec, extra=(), coords=None):
     cols = [f8(M), f8(z), f8(ra), f8(dec)] + [f8(e) for e in extra]
     c = bfgx_catalog()
     c.n = cols[0].size
     c.M, c.z, c.ra, c.dec = (cols[i].ctypes.data for i in range(4))
     for k, e in enumerate(cols[4:]):
         c.extra[k] = e.ctypes.data
-    lnz, lnM = table_coords(cols[0], cols[1])
+    lnz, lnM = coords if coords is not None else table_coords(cols[0], cols[1])
     c.ln1pz, c.lnM = lnz.ctypes.data, lnM.ctypes.data
     cols += [lnz, lnM]
     return c, cols

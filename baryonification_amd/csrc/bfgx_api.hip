@@ -13,11 +13,18 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/bfgx.h"
+
+// every device allocation the library makes is counted (bfgx_debug_alloc_count): a warm one-shot call must make none
+#include <atomic>
+static std::atomic<long long> g_bfgx_allocs{0};
+template <typename T> static inline hipError_t bfgx_counted_malloc(T **p, size_t bytes) { ++g_bfgx_allocs; return hipMalloc((void **)p, bytes); }
+#define hipMalloc(ptr, bytes) bfgx_counted_malloc(ptr, bytes)
 #include "bfgx_cosmo.hpp"
 #include "bfgx_kernels.hpp"
 #include "bfgx_scatter2.hpp"
@@ -962,6 +969,168 @@ int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[kCatCols], b
 
 }  // namespace
 
+// ---- plan cache of the one-shot API: a process() call re-uses the plan (model on the device, tiling, binning workspace) and
+// the device buffers of the previous call with the same model / nside / device, so that a warm call performs no hipMalloc
+namespace {
+
+struct PoolBuf {
+    void *p = nullptr; size_t cap = 0;
+    int need(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return 1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct CacheEntry {
+    uint64_t key = 0, stamp = 0;
+    bfgx_plan *plan = nullptr;
+    PoolBuf cols[kCatCols], in, out, off, sums;
+};
+
+std::mutex g_cache_mu;
+std::vector<CacheEntry *> g_cache;
+uint64_t g_cache_stamp = 0;
+constexpr size_t kCacheMax = 4;
+
+uint64_t hash_bytes(uint64_t h, const void *data, size_t bytes)
+{
+    const unsigned char *c = (const unsigned char *)data;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, c + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+    for (; i < bytes; ++i) h = (h ^ c[i]) * 0x100000001b3ull;
+    return h;
+}
+
+uint64_t model_key(int device, int64_t nside, const bfgx_model *m)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    h = hash_bytes(h, &device, sizeof(device));
+    h = hash_bytes(h, &nside, sizeof(nside));
+    const bfgx_table &t = m->table;
+    h = hash_bytes(h, &t.ndim, sizeof(t.ndim));
+    h = hash_bytes(h, t.n, sizeof(t.n));
+    size_t nv = 1;
+    for (int d = 0; d < t.ndim; ++d) { h = hash_bytes(h, t.axis[d], sizeof(double) * (size_t)t.n[d]); nv *= (size_t)t.n[d]; }
+    h = hash_bytes(h, t.values, sizeof(double) * nv);
+    h = hash_bytes(h, &t.rdelta_sampling, sizeof(int32_t) * 2);
+    h = hash_bytes(h, &t.eps_model, sizeof(double));
+    h = hash_bytes(h, &m->cosmo_runner, sizeof(bfgx_cosmo));
+    h = hash_bytes(h, &m->cosmo_model, sizeof(bfgx_cosmo));
+    h = hash_bytes(h, &m->massdef_runner.Delta, sizeof(double)); h = hash_bytes(h, &m->massdef_runner.rho_type, sizeof(int32_t));
+    h = hash_bytes(h, &m->massdef_model.Delta, sizeof(double)); h = hash_bytes(h, &m->massdef_model.rho_type, sizeof(int32_t));
+    h = hash_bytes(h, &m->eps_runner, sizeof(double));
+    return h;
+}
+
+void cache_drop(CacheEntry *e)
+{
+    if (e->plan) { (void)hipSetDevice(e->plan->device); bfgx_plan_destroy(e->plan); }
+    for (auto &c : e->cols) c.release();
+    e->in.release(); e->out.release(); e->off.release(); e->sums.release();
+    delete e;
+}
+
+// the cached entry for (device, nside, model), its plan large enough for n halos; g_cache_mu is held by the caller
+int cache_acquire(int device, int64_t nside, const bfgx_model *model, int64_t n, CacheEntry **out)
+{
+    if (int rc = validate_model(model)) return rc;           // before hashing: the table pointers must be readable
+    const uint64_t key = model_key(device, nside, model);
+    CacheEntry *e = nullptr;
+    for (CacheEntry *c : g_cache) if (c->key == key) e = c;
+    if (e && e->plan->max_halos < n) {                       // grew: rebuild the plan (its workspace scales with max_halos)
+        (void)hipSetDevice(device);
+        bfgx_plan_destroy(e->plan);
+        e->plan = nullptr;
+    }
+    if (!e) {
+        if (g_cache.size() >= kCacheMax) {                   // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < g_cache.size(); ++i) if (g_cache[i]->stamp < g_cache[lru]->stamp) lru = i;
+            cache_drop(g_cache[lru]);
+            g_cache.erase(g_cache.begin() + (long)lru);
+        }
+        e = new CacheEntry();
+        e->key = key;
+        g_cache.push_back(e);
+    }
+    if (!e->plan) {
+        const int64_t cap = std::max<int64_t>(n + n / 4, 1024);
+        if (int rc = bfgx_plan_create(device, nullptr, nside, cap, model, &e->plan)) {
+            e->plan = nullptr;
+            g_cache.erase(std::find(g_cache.begin(), g_cache.end(), e));
+            cache_drop(e);
+            return rc;
+        }
+        e->plan->blocking_growth = true;
+    }
+    e->stamp = ++g_cache_stamp;
+    *out = e;
+    return BFGX_OK;
+}
+
+int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d, std::vector<double> &hostlog)
+{
+    bfgx_plan *p = e->plan;
+    const int nex = p->model.tab.ndim - 3;
+    const double *lnz = h->ln1pz, *lnm = h->lnM;
+    if (h->n > 0 && (!lnz || !lnm)) {                        // see upload_catalog
+        if (!h->M || !h->z) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
+        hostlog.resize(2 * (size_t)h->n);
+        for (int64_t i = 0; i < h->n; ++i) {
+            const double a = 1.0 / (1.0 + h->z[i]);
+            hostlog[i] = std::log(1.0 / a);
+            hostlog[(size_t)h->n + i] = std::log(h->M[i]);
+        }
+        if (!lnz) lnz = hostlog.data();
+        if (!lnm) lnm = hostlog.data() + h->n;
+    }
+    const double *src[kCatCols] = {h->M, h->z, h->ra, h->dec, nex > 0 ? h->extra[0] : nullptr, nex > 1 ? h->extra[1] : nullptr, lnz, lnm};
+    const double *dp[kCatCols] = {};
+    for (int i = 0; i < kCatCols; ++i) {
+        const bool wanted = i < 4 + nex || i >= 4 + BFGX_MAX_EXTRA;
+        if (!wanted) continue;
+        if (h->n > 0 && !src[i]) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
+        if (e->cols[i].need(sizeof(double) * (size_t)std::max<int64_t>(h->n, 1))) return fail(BFGX_ERR_HIP, "hipMalloc(catalog) failed");
+        if (h->n > 0) HIP_TRY(hipMemcpyAsync(e->cols[i].p, src[i], sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, p->stream));
+        dp[i] = (const double *)e->cols[i].p;
+    }
+    std::memset(d, 0, sizeof(*d));
+    d->n = h->n;
+    d->M = dp[0]; d->z = dp[1]; d->ra = dp[2]; d->dec = dp[3];
+    for (int k = 0; k < nex; ++k) d->extra[k] = dp[4 + k];
+    d->ln1pz = dp[4 + BFGX_MAX_EXTRA]; d->lnM = dp[5 + BFGX_MAX_EXTRA];
+    return BFGX_OK;
+}
+
+}  // namespace
+
+void bfgx_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (CacheEntry *e : g_cache) cache_drop(e);
+    g_cache.clear();
+}
+
+long long bfgx_debug_alloc_count(void) { return (long long)g_bfgx_allocs.load(); }
+
+int bfgx_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(BFGX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (bfgx_device_count() <= 0) return fail(BFGX_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return BFGX_OK;
+}
+
+void bfgx_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t nside,
                          const double *map_in, double *map_out, const bfgx_opts *opts, bfgx_stats *stats)
 {
@@ -971,39 +1140,43 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     o.check_mass = 1;
     o.algo = 1;
     if (opts) o = *opts;
-    bfgx_plan *p = nullptr;
-    if (int rc = bfgx_plan_create(o.device, nullptr, nside, cat->n, model, &p)) return rc;
-    struct Guard { bfgx_plan *p; ~Guard() { bfgx_plan_destroy(p); } } guard{p};
-    p->blocking_growth = true;
-    if (o.algo == 0 || o.algo == 1) p->algo = o.algo; else return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
+    if (o.algo != 0 && o.algo != 1) return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
+    if (cat->n < 0) return fail(BFGX_ERR_INVALID, "catalog size < 0");
+    std::lock_guard<std::mutex> lk(g_cache_mu);              // one one-shot call at a time (they share the cached plans)
+    CacheEntry *e = nullptr;
+    if (int rc = cache_acquire(o.device, nside, model, cat->n, &e)) return rc;
+    bfgx_plan *p = e->plan;
+    p->algo = o.algo;
+    HIP_TRY(hipSetDevice(p->device));
 
     const size_t npix = (size_t)p->hpx.npix;
     const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
-    DevBuf cols[kCatCols], d_in, d_out, d_off, d_sums;
     std::vector<double> hostlog;
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);
-    if (int rc = upload_catalog(p, cat, cols, &dcat, hostlog)) return rc;
-    if (d_in.alloc(npix * sizeof(double)) || d_out.alloc(npix * sizeof(double)) || d_off.alloc(acc_bytes) || d_sums.alloc(2 * sizeof(double)))
+    if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog)) return rc;
+    if (e->in.need(npix * sizeof(double)) || e->out.need(npix * sizeof(double)) || e->off.need(acc_bytes) || e->sums.need(2 * sizeof(double)))
         return fail(BFGX_ERR_HIP, "hipMalloc(map buffers) failed");
-    HIP_TRY(hipMemcpyAsync(d_in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(e->in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, p->stream));
     const double ms_h2d = t.stop(p->stream);
 
     t.start(p->stream);
-    HIP_TRY(hipMemsetAsync(d_off.p, 0, acc_bytes, p->stream));
-    HIP_TRY(hipMemsetAsync(d_out.p, 0, npix * sizeof(double), p->stream));
-    HIP_TRY(hipMemsetAsync(d_sums.p, 0, 2 * sizeof(double), p->stream));
-    if (int rc = bfgx_offsets_device(p, &dcat, d_off.p, o.acc_offsets_f64)) return rc;
-    if (int rc = bfgx_regrid_device(p, (const double *)d_in.p, d_off.p, o.acc_offsets_f64, (double *)d_out.p, (double *)d_sums.p)) return rc;
+    if (o.algo == 0) {                                       // global-atomic kernels accumulate; the tiled ones store every element once
+        HIP_TRY(hipMemsetAsync(e->off.p, 0, acc_bytes, p->stream));
+        HIP_TRY(hipMemsetAsync(e->out.p, 0, npix * sizeof(double), p->stream));
+    }
+    if (int rc = bfgx_offsets_device(p, &dcat, e->off.p, o.acc_offsets_f64)) return rc;
+    if (int rc = bfgx_regrid_device(p, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p)) return rc;
     const double ms_k = t.stop(p->stream);
 
     t.start(p->stream);
     double sums[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(map_out, d_out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipMemcpyAsync(sums, d_sums.p, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(sums, e->sums.p, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
     const double ms_d2h = t.stop(p->stream);
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (int rc = bfgx_plan_status(p)) return rc;             // far-deposit list / entry list
 
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -1027,36 +1200,39 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     o.acc_paint_f64 = 1;
     o.algo = 1;
     if (opts) o = *opts;
-    bfgx_plan *p = nullptr;
-    if (int rc = bfgx_plan_create(o.device, nullptr, nside, cat->n, model, &p)) return rc;
-    struct Guard { bfgx_plan *p; ~Guard() { bfgx_plan_destroy(p); } } guard{p};
-    p->blocking_growth = true;
-    if (o.algo == 0 || o.algo == 1) p->algo = o.algo; else return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
+    if (o.algo != 0 && o.algo != 1) return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
+    if (cat->n < 0) return fail(BFGX_ERR_INVALID, "catalog size < 0");
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CacheEntry *e = nullptr;
+    if (int rc = cache_acquire(o.device, nside, model, cat->n, &e)) return rc;
+    bfgx_plan *p = e->plan;
+    p->algo = o.algo;
+    HIP_TRY(hipSetDevice(p->device));
 
     const size_t npix = (size_t)p->hpx.npix;
-    DevBuf cols[kCatCols], d_out;
     std::vector<double> hostlog;
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);
-    if (int rc = upload_catalog(p, cat, cols, &dcat, hostlog)) return rc;
-    if (d_out.alloc(npix * sizeof(double))) return fail(BFGX_ERR_HIP, "hipMalloc(map) failed");
+    if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog)) return rc;
+    if (e->out.need(npix * sizeof(double))) return fail(BFGX_ERR_HIP, "hipMalloc(map) failed");
     const double ms_h2d = t.stop(p->stream);
     t.start(p->stream);
-    HIP_TRY(hipMemsetAsync(d_out.p, 0, npix * sizeof(double), p->stream));
-    if (int rc = bfgx_paint_device(p, &dcat, d_out.p, o.acc_paint_f64)) return rc;
+    if (o.algo == 0) HIP_TRY(hipMemsetAsync(e->out.p, 0, npix * sizeof(double), p->stream));
+    if (int rc = bfgx_paint_device(p, &dcat, e->out.p, o.acc_paint_f64)) return rc;
     const double ms_k = t.stop(p->stream);
     t.start(p->stream);
     if (o.acc_paint_f64) {
-        HIP_TRY(hipMemcpyAsync(map_out, d_out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
     } else {
         std::vector<float> tmp(npix);
-        HIP_TRY(hipMemcpyAsync(tmp.data(), d_out.p, npix * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(tmp.data(), e->out.p, npix * sizeof(float), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
         for (size_t i = 0; i < npix; ++i) map_out[i] = (double)tmp[i];
     }
     const double ms_d2h = t.stop(p->stream);
+    if (int rc = bfgx_plan_status(p)) return rc;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->ms_h2d = ms_h2d; stats->ms_kernels = ms_k; stats->ms_d2h = ms_d2h;

@@ -5,15 +5,21 @@ NSIDE=1024 HEALPix shell (BASELINE.json configs[1]), inputs resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    ... bench.py --gpus N --scaling strong            # ONE 1e6-halo catalog split over the N GPUs (north_star's wording)
+    ... bench.py --gpus 8 --config 4                  # BASELINE config 4: 1e7 halos, NSIDE 2048, over the GPUs given
 
-One step = one full pass of the hot path: zero accumulators -> K0 halo_prep -> K1 halo_scatter
-(pix_offsets, fp32 atomics) -> [N>1: RCCL reduce of pix_offsets to rank 0] -> K2 regrid (fp64) -> sums
-of the mass-conservation check.  N>1 is weak scaling: every rank owns its own 1e6-halo shard (seed +
-rank) of an N x 1e6 catalog on the same shell; value = all halos / max-over-ranks time.
+One step = one full pass of the hot path: K0 halo_prep (per-halo scalars, halo -> tile binning) -> K1 tile_scatter2
+(pix_offsets; tile-owned LDS accumulation, no global atomics) -> [N>1: RCCL all_to_all reduce-scatter by pixel slices +
+one-ring halo exchange] -> K2 tile_regrid3 (gathering regrid: every output pixel stored once) -> the two sums of the
+mass-conservation check [-> N>1: disjoint slices to rank 0].  N>1 is weak scaling by default (every rank owns its own
+1e6-halo shard of an N x 1e6 catalog on the same shell); value = all halos / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (by measured time), its duration
-measured with HIP events on the launch stream (bfgx_plan_timing_*); `cpu_baseline` times the CPU oracle
-(oracle/, the checker -- never the product) on a bounded sample, rank 0, N=1 only.
+Prints ONE JSON line (rank 0).  `value` / `ms_per_step` come from a timed region of exactly --steps steps between
+barrier + synchronize fences WITHOUT per-kernel events; the same K steps are then repeated with HIP events around every
+kernel on the launch stream (bfgx_plan_timing_*) for `kernel_ms` and `roofline` (dominant kernel by measured time;
+`ms_per_step_with_kernel_events` shows what the events cost).  At N = 1 the line also carries `value_acc_f64` (the same
+step in fp64 throughout), `end_to_end` (the drop-in BaryonifyShell.process() from numpy arrays, PCIe-inclusive) and
+`cpu_baseline` (the CPU oracle -- oracle/, the checker, never the product -- on the box's host cores).
 """
 import argparse
 import json
@@ -32,8 +38,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=600, help='timed steps (default 600: a timed region of ~0.5 s at config 2)')
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="N > 1: 'weak' = --halos per GPU (default), 'strong' = ONE --halos catalog split over the GPUs (north_star's wording)")
+    ap.add_argument('--config', type=int, default=0, choices=[0, 4],
+                    help='4 = BASELINE config 4: 1e7 halos, NSIDE 2048, BaryonifyShell, strong scaling over the GPUs given (8 in the config)')
+    ap.add_argument('--no-extras', action='store_true', help='skip value_acc_f64 and end_to_end (N = 1 only)')
     ap.add_argument('--halos', type=int, default=1_000_000, help='halos per GPU (default: BASELINE config 2)')
     ap.add_argument('--nside', type=int, default=1024)
     ap.add_argument('--eps', type=float, default=10.0)
@@ -279,13 +290,28 @@ def main():
     if world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1':
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
-    nside, npix = args.nside, 12 * args.nside ** 2
-    cat = syn.make_catalog(args.halos, seed=syn.SEED_CATALOG + rank)
-    if world == 1:
-        z, M, r = syn.table_grid(cat)                    # README.md:78-80: edges = catalog min/max
-    else:                                                # shards differ: analytic support of the catalog
-        z, M, r = np.geomspace(0.2, 0.3, 10), np.geomspace(1e12, 1e15, 10), np.geomspace(1e-3, 3e2, 500)
     paint = args.mode == 'paint'
+    if args.config == 4:            # BASELINE config 4: 1e7 halos, BaryonifyShell, NSIDE 2048, halo-sharded over 8 GPUs
+        args.nside, args.scaling = 2048, 'strong'
+        args.halos = 10_000_000 if args.halos == 1_000_000 else args.halos
+    nside, npix = args.nside, 12 * args.nside ** 2
+    strong = args.scaling == 'strong'
+    total_halos = args.halos if strong else args.halos * world
+    if strong:
+        # ONE catalog (BASELINE seeds), shuffled as Parallelize.py:255 does, rank r takes the r-th ceil(N/world) slice
+        from baryonification_amd.utils.Parallelize import shard_slices, shuffled_order
+        full = syn.make_catalog(total_halos)
+        mine = shuffled_order(total_halos, 42)[shard_slices(total_halos, world)[rank]]
+        cat = {k: np.ascontiguousarray(v[mine]) for k, v in full.items()}
+        z, M, r = syn.table_grid(full)                   # README.md:78-80: edges = catalog min/max
+        del full
+    else:
+        cat = syn.make_catalog(args.halos, seed=syn.SEED_CATALOG + rank)
+        if world == 1:
+            z, M, r = syn.table_grid(cat)
+        else:                                            # shards differ: analytic support of the catalog
+            z, M, r = np.geomspace(0.2, 0.3, 10), np.geomspace(1e12, 1e15, 10), np.geomspace(1e-3, 3e2, 500)
+    nh = cat['M'].size
     if args.table == 's19' and not paint:
         table = syn.s19_displacement_table(z, M, r)
     else:
@@ -297,173 +323,242 @@ def main():
     model, keep = engine.model_from_tables(axes, values, syn.COSMO, args.eps, args.eps, log_values=paint)
 
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}
+    lnz, lnM = _lib.table_coords(cat['M'], cat['z'])      # numpy's np.log(1/a), np.log(M): exact table-edge classification
+    t['lnz'], t['lnM'] = torch.from_numpy(lnz).to(dev), torch.from_numpy(lnM).to(dev)
     d_map = torch.from_numpy(hmap).to(dev)
-    acc_dtype = torch.float64 if args.acc_f64 else torch.float32
-    d_off = torch.zeros(npix * 3, dtype=acc_dtype, device=dev)
     d_out = torch.zeros(npix, dtype=torch.float64, device=dev)
     d_sums = torch.zeros(2, dtype=torch.float64, device=dev)
-    d_fin = torch.zeros(npix if ((world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1') and rank == 0) else 0, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    plan = engine.ShellPlan(model, keep, nside, args.halos, device=local_rank, stream=stream)
-    cat_dev = _lib.make_catalog_dev(args.halos, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr())
+    plan = engine.ShellPlan(model, keep, nside, nh, device=local_rank, stream=stream)
+    cat_dev = _lib.make_catalog_dev(nh, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr(),
+                                    ln1pz_ptr=t['lnz'].data_ptr(), lnM_ptr=t['lnM'].data_ptr())
     plan.set_algo(args.algo)
     n_pairs = plan.count_pairs(cat_dev, fallback4=not paint)
     plan.status()
 
-    # N > 1: slice exchange (utils/Parallelize.py): all_to_all reduce-scatter of the accumulator by pixel slices, every rank
-    # regrids the bands it owns, windows travel to rank 0.  --exchange reduce keeps the single reduce(sum) to rank 0.
+    # N > 1: slice exchange (utils/Parallelize.py): all_to_all reduce-scatter of the accumulator by pixel slices, one-ring
+    # halo exchange, every rank regrids the OUTPUT pixels of its bands, disjoint slices travel to rank 0.
+    # --exchange reduce keeps the single reduce(sum) to rank 0.
     # BFGX_FORCE_EXCHANGE=1: run the N > 1 exchange code with a single rank too (exercises the RCCL calls on a one-GPU box)
     force_x = os.environ.get('BFGX_FORCE_EXCHANGE') == '1'
     slices = (world > 1 or force_x) and args.exchange == 'slices' and args.algo == 1
+    d_fin = torch.zeros(npix if ((world > 1 or force_x) and rank == 0) else 0, dtype=torch.float64, device=dev)
+    d_foreign = torch.zeros(1, dtype=torch.int64, device=dev)          # far deposits that belong to another rank's slice
     if slices:
-        from baryonification_amd.utils.Parallelize import band_partition, gather_windows, sliced_reduce, window_margin
+        from baryonification_amd.utils.Parallelize import band_partition, gather_slices, halo_exchange, sliced_reduce
         first = plan.bands()
         cuts = band_partition(first, world)
         pb = first[cuts]
-        margin = 0 if paint else window_margin(nside)
-        wins = [(max(0, int(pb[j]) - margin), min(npix, int(pb[j + 1]) + margin)) for j in range(world)]
-        width = 1 if paint else 3
-        my_len = int(pb[rank + 1] - pb[rank])
-        x_recv = torch.empty(world * my_len * width, dtype=torch.float64 if paint else acc_dtype, device=dev)
-        d_win = torch.zeros(wins[rank][1] - wins[rank][0], dtype=torch.float64, device=dev)
-        w_recv = torch.empty(sum(hi - lo for lo, hi in wins) if rank == 0 else 0, dtype=torch.float64, device=dev)
-        map_sum = float(d_map.sum().item())
+        needs = [plan.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
+        p0, p1 = int(pb[rank]), int(pb[rank + 1])
+        d_slice = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
 
-    def step_paint():
-        if args.algo == 0:
-            d_out.zero_()
-        plan.paint(cat_dev, d_out.data_ptr(), acc_f64=True)
-        if slices:
-            mine = sliced_reduce(d_out, pb, 1, recv=x_recv)
-            gather_windows(mine, wins, npix, recv=w_recv, out=d_fin)
-        elif world > 1:
-            dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318
+    def run_steps(acc_f64):
+        """returns a closure doing one full pass of the hot path with the given accumulator type"""
+        acc_dtype = torch.float64 if acc_f64 else torch.float32
+        d_off = torch.zeros(npix * 3, dtype=acc_dtype, device=dev)
+        x_recv = torch.empty(world * (p1 - p0) * (1 if paint else 3), dtype=torch.float64 if paint else acc_dtype, device=dev) if slices else None
 
-    def step():
-        if paint:
-            return step_paint()
-        if args.algo == 0:
-            d_off.zero_()                      # algo 1 stores every element of pix_offsets exactly once
-        plan.offsets(cat_dev, d_off.data_ptr(), acc_f64=args.acc_f64)
-        if slices:
-            my_off = sliced_reduce(d_off, pb, 3, recv=x_recv)
-            d_win.zero_()
-            plan.regrid_bands(int(cuts[rank]), int(cuts[rank + 1]), d_map.data_ptr(), my_off.data_ptr(), d_win.data_ptr(),
-                              wins[rank][0], wins[rank][1], acc_f64=args.acc_f64)
-            full = gather_windows(d_win, wins, npix, recv=w_recv, out=d_fin)
+        def step_paint():
+            if args.algo == 0:
+                d_out.zero_()
+            plan.paint(cat_dev, d_out.data_ptr(), acc_f64=True)
+            if slices:
+                mine = sliced_reduce(d_out, pb, 1, recv=x_recv)
+                gather_slices(mine, pb, npix, 'root', out=d_fin if rank == 0 else None)
+            elif world > 1:
+                dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318
+
+        def step():
+            if paint:
+                return step_paint()
+            if args.algo == 0:
+                d_off.zero_()                      # algo 1 stores every element of pix_offsets exactly once
+            plan.offsets(cat_dev, d_off.data_ptr(), acc_f64=acc_f64)
+            if slices:
+                my_off = sliced_reduce(d_off, pb, 3, recv=x_recv)
+                off_apron = halo_exchange(my_off, pb, needs, 3)
+                plan.regrid_bands(int(cuts[rank]), int(cuts[rank + 1]), d_map.data_ptr(), off_apron.data_ptr(), needs[rank][0], needs[rank][1],
+                                  d_slice.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
+                plan.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
+                gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
+                return
+            if args.algo == 0:
+                d_out.zero_()                      # algo 1: the gathering regrid stores every pixel of the map exactly once
+            if world > 1:
+                assert backend == 'nccl', "--exchange reduce needs RCCL"
+                dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318 counterpart, before the regrid
             if rank == 0:
-                d_sums[0] = map_sum
-                d_sums[1] = full.sum()
-            return
-        if args.algo == 0:
-            d_out.zero_()                      # algo 1: the gathering regrid stores every pixel of the map exactly once
-        if world > 1:
-            assert backend == 'nccl', "--exchange reduce needs RCCL"
-            dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318 counterpart, before the regrid
-        if rank == 0:
-            plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=args.acc_f64)
+                plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
+        return step
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step, steps, events):
+        plan.timing_enable(events)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        kt = plan.timing_read() if events else None
+        plan.timing_enable(False)
+        if world > 1:
+            te = torch.tensor([el], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el, kt
+
+    step = run_steps(args.acc_f64)
     if slices:
-        # one untimed trial of the slice exchange: an exception here (argument validation of the collective is identical
-        # on every rank) switches all ranks to the plain reduce instead of losing the run
+        # one untimed trial of the slice exchange; the ranks AGREE on whether it worked (a failure on one rank only -- out of
+        # memory, an overflowing entry list -- must not leave the others in a different collective)
+        ok = 1
         try:
             step()
             fence()
         except Exception as e:        # noqa: BLE001
+            ok = 0
+            print("bench[rank %d]: slice exchange failed (%s: %s)" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+        if dist.is_initialized():
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == 'nccl' else 'cpu')
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            except Exception:         # noqa: BLE001  the communicator itself is broken: do not continue on it
+                sys.exit(3)
+        if not ok:
             if rank == 0:
-                print("bench: slice exchange failed (%s: %s); falling back to --exchange reduce" % (type(e).__name__, e), file=sys.stderr, flush=True)
+                print("bench: falling back to --exchange reduce on every rank", file=sys.stderr, flush=True)
             slices = False
+            step = run_steps(args.acc_f64)
     for _ in range(args.warmup):
         step()
-    fence()
-    # per-kernel HIP events live on the launch stream inside the timed region (bfgx_plan_timing_*)
-    plan.timing_enable(not args.no_kernel_events)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kt = plan.timing_read()
-    plan.timing_enable(False)
-    plan.status()                              # entry-list capacity, no regrid deposit outside a window
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    # the timed region proper: EXACTLY --steps passes, no per-kernel events (they cost ~0.05 ms per step); `value` comes from it
+    elapsed, _ = timed(step, args.steps, False)
+    # the same K steps again with HIP events around every kernel on the launch stream (bfgx_plan_timing_*): kernel_ms, roofline
+    elapsed_ev, kt = timed(step, args.steps, True) if not args.no_kernel_events else (None, None)
+    plan.status()                              # entry-list capacity, far-deposit list
+    if slices and not paint:
+        assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
+
+    extra = {}
+    if world == 1 and not paint and not args.acc_f64 and args.algo == 1 and not args.no_extras:
+        # the same step with fp64 pix_offsets accumulators and fp64 pair math (1e-10 parity path)
+        step64 = run_steps(True)
+        for _ in range(3):
+            step64()
+        n64 = max(20, args.steps // 4)
+        el64, _ = timed(step64, n64, False)
+        extra["value_acc_f64"] = {"value": total_halos / el64 * n64, "unit": "halos/s", "ms_per_step": el64 / n64 * 1e3, "steps": n64,
+                                  "dtype": "f64 throughout (fp64 pair math, fp64 pix_offsets, fp64 regrid)"}
+        del step64
+        torch.cuda.empty_cache()
+        # the drop-in call from numpy arrays (BaryonifyShell.process(): PCIe both ways, plan cache warm after the first call)
+        extra["end_to_end"] = end_to_end(args, cat, hmap, z, M, r, table)
 
     if rank == 0:
         sums = d_sums.cpu().numpy()
         ms_step = elapsed / args.steps * 1e3
-        total_halos = args.halos * world
-        kernels = {k: (ms / n if n else None) for k, (ms, n) in kt.items() if n}
-        if args.no_kernel_events:
-            print(json.dumps({"ms_per_step": ms_step, "value": total_halos / elapsed * args.steps, "kernel_ms": {},
-                              "mass_conserved": None if paint else bool(np.isclose(sums[1], sums[0])), "note": "no kernel events"}), flush=True)
-            plan.close()
-            return
-        # algorithmic bytes per launch: K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo;
-        # K2 60 B per map pixel
-        acc_b = 8 if args.acc_f64 else 4
-        alg = {'offsets': n_pairs * 3 * acc_b + args.halos * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8),
-               'paint': n_pairs * 8 + args.halos * 32 + npix * 8}
-        dom = 'paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
-        names = {"offsets": "tile_scatter_kernel<OFFSETS>" if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
-                 "regrid": "tile_regrid_kernel" if args.algo == 1 else "regrid_kernel",
-                 "paint": "tile_scatter_kernel<PAINT>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
-        ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
-        traffic = None           # HBM bytes per launch from a separate rocprofv3 --pmc run of this same configuration
-        valu = None              # wave-level VALU instructions per launch (SQ_INSTS_VALU) from the same run
-        try:
-            tj = json.load(open(os.path.join(HERE, 'profiles', 'traffic_latest.json')))
-            c = tj['config']
-            if (c['halos_per_gpu'], c['nside'], c['algo'], c['mode']) == (args.halos, nside, args.algo, args.mode) and not args.acc_f64:
-                traffic = tj['kernels'].get(dom)
-                valu = tj.get('valu_wave_insts', {}).get(dom)
-        except Exception:
-            traffic = None
         out = {
-            "metric": "halos/sec for %s NSIDE=%d (1e6-halo synthetic catalog per GPU)" % ("PaintProfilesShell" if paint else "BaryonifyShell", nside),
+            "metric": "halos/sec for %s NSIDE=%d (1e6-halo synthetic catalog%s)" % (
+                "PaintProfilesShell" if paint else "BaryonifyShell", nside, " per GPU" if not strong else ", halo-sharded over the GPUs"),
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config %d: %d-halo synthetic catalog per GPU (SURVEY 8d seeds), %s, "
-                                   "NSIDE=%d shell, epsilon_max=%g, 10x10x500 %s %s table" % (
-                                       3 if paint else 2, args.halos, "PaintProfilesShell" if paint else "BaryonifyShell", nside, args.eps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": ("f64" if (args.acc_f64 or paint) else
+                      "f64 ring-row geometry + f64 LDS accumulation / map; f32 pair math, f32 pix_offsets, f32 regrid geometry"),
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: %d-halo synthetic catalog %s (SURVEY 8d seeds), %s, "
+                                   "NSIDE=%d shell, epsilon_max=%g, 10x10x500 %s %s table (edges = catalog min/max)" % (
+                                       4 if args.config == 4 else (3 if paint else 2), total_halos if strong else args.halos,
+                                       "split over the GPUs" if strong else "per GPU", "PaintProfilesShell" if paint else "BaryonifyShell", nside, args.eps,
                                        "Schneider19 (K4-K6 built)" if (args.table == 's19' and not paint) else "closed-form",
                                        "profile" if paint else "displacement"),
-                       "halos_per_gpu": args.halos, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
+                       "halos_per_gpu": nh, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
                        "parallelism": ("single GPU" if world == 1 else
-                                       "halo shards x%d + RCCL all_to_all reduce-scatter by pixel slices, banded regrid on every rank, windows -> rank 0" % world
+                                       "halo shards x%d + RCCL all_to_all reduce-scatter by pixel slices, one-ring halo exchange, banded gathering regrid on "
+                                       "every rank, disjoint slices -> rank 0" % world
                                        if slices else "halo shards x%d + RCCL reduce(accumulator) -> rank 0" % world)},
             "map_pixels_per_s": npix / elapsed * args.steps,
-            "kernel_ms": kernels,
             "mass_conserved": None if paint else bool(np.isclose(sums[1], sums[0])),
-            "roofline": {"kernel": names[dom],
-                         "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg[dom],
-                         # what really bounds the kernel: VALU issue.  1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-                         "valu_issue": None if not valu else {"wave_insts_per_launch": valu, "achieved_per_s": valu / (kernels[dom] * 1e-3),
-                                                              "peak_per_s": 1024 * 2.4e9 / 4, "frac": valu / (kernels[dom] * 1e-3) / (1024 * 2.4e9 / 4)},
-                         "note": ("tile-owned LDS accumulation, no global atomics: 12 B of algorithmic HBM traffic against ~300 VALU "
-                                  "instructions per (halo, pixel) pair (fp64 chord, fp32 tail), so the kernel sits far below the HBM "
-                                  "roof; it is bounded by VALU issue and latency at 2 waves/SIMD (valu_issue, DESIGN.md section 4)") if args.algo == 1 else
-                                 ("scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s "
-                                  "(gfx950 memory-side float atomics), not the 8 TB/s stream peak")},
         }
+        if kt is not None:
+            kernels = {k: (ms / n if n else None) for k, (ms, n) in kt.items() if n}
+            out["ms_per_step_with_kernel_events"] = elapsed_ev / args.steps * 1e3
+            out["kernel_ms"] = kernels
+            out["roofline"] = roofline(args, kernels, n_pairs, nh, npix, paint)
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline and not paint:
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
         print(json.dumps(out), flush=True)
     plan.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def roofline(args, kernels, n_pairs, nh, npix, paint):
+    """The dominant kernel (by measured time) against the HBM roof SURVEY 8(d) defines: algorithmic bytes per launch / average
+    launch duration (HIP events on the launch stream over K steps).  traffic / VALU counts come from the committed rocprofv3 --pmc
+    passes of this same configuration (profiles/traffic_latest.json)."""
+    acc_b = 8 if args.acc_f64 else 4
+    # SURVEY 8d: K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo; K2 60 B per map pixel (3 acc + 8 + 4 x 8 + 8); K3 8 B/pair
+    alg = {'offsets': n_pairs * 3 * acc_b + nh * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8), 'paint': n_pairs * 8 + nh * 32 + npix * 8}
+    dom = 'paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
+    real = 'double' if (args.acc_f64 or paint) else 'float'
+    names = {"offsets": ("tile_scatter2_kernel<OFFSETS, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
+             "regrid": ("tile_regrid3_kernel<%s>" % real) if args.algo == 1 else "regrid_kernel",
+             "paint": "tile_scatter2_kernel<PAINT, double>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
+    ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
+    traffic = valu = None
+    try:
+        tj = json.load(open(os.path.join(HERE, 'profiles', 'traffic_latest.json')))
+        c = tj['config']
+        if (c['halos_per_gpu'], c['nside'], c['algo'], c['mode']) == (nh, args.nside, args.algo, args.mode) and not args.acc_f64:
+            traffic = tj['kernels'].get(dom)
+            valu = tj.get('valu_wave_insts', {}).get(dom)
+    except Exception:        # noqa: BLE001
+        pass
+    r = {"kernel": names[dom], "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
+         "launch_ms": kernels[dom]}
+    if valu:
+        # what binds the kernel: vector issue.  Measured on MI355X (scripts/ubench/valu_rate.hip, profiles/r02_ubench_valu_rate.txt):
+        # one wave64 fp32 instruction per ~1.0 ns per SIMD with >= 2 waves resident, fp64 / packed fp32 2.0 ns; 1024 SIMDs
+        r["valu_issue"] = {"wave_insts_per_launch": valu, "achieved_per_s": valu / (kernels[dom] * 1e-3),
+                           "peak_per_s": 1024 / 1.0e-9, "frac": valu / (kernels[dom] * 1e-3) / (1024 / 1.0e-9)}
+    r["note"] = ("tile-owned LDS accumulation, no global atomics, every output element stored once: the algorithmic HBM traffic is 12 B per "
+                 "(halo, pixel) pair against ~115 vector instructions per pair (fp32 pair math; the fp64 ring-row phase adds ~350 per 64 rows), so the "
+                 "kernel sits below the HBM roof and is bounded by vector issue + latency at 4 waves/SIMD (DESIGN.md section 4)") if args.algo == 1 else \
+                ("scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s (gfx950 memory-side float atomics), not the 8 TB/s stream peak")
+    return r
+
+
+def end_to_end(args, cat, hmap, z, M, r, table, calls=5):
+    """bfg.Runners.BaryonifyShell(...).process() from numpy arrays: what a user of the drop-in hits (H2D of catalog + map, kernels,
+    D2H of the map).  The first call builds and caches the plan; the median of the following calls is reported."""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    Shell = bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO)
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO), epsilon_max=args.eps)
+    model.set_table(z, M, r, table)
+    runner = bfg.Runners.BaryonifyShell(Catalog, Shell, args.eps, model, verbose=False)
+    ts, st = [], None
+    for i in range(calls + 1):
+        t0 = time.perf_counter()
+        out = runner.process()
+        ts.append(time.perf_counter() - t0)
+        st = runner.last_stats
+    med = float(np.median(ts[1:]))
+    return {"what": "BaryonifyShell.process() from numpy arrays, PCIe-inclusive (never `value`)", "ms_per_call": med * 1e3,
+            "ms_first_call": ts[0] * 1e3, "halos_per_s": cat['M'].size / med, "mass_conserved": bool(np.isclose(out.sum(), hmap.sum())),
+            "phases_ms": {k: st[k] for k in ('ms_h2d', 'ms_kernels', 'ms_d2h')} if st else None}
 
 
 if __name__ == '__main__':

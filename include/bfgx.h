@@ -25,6 +25,7 @@
 #ifndef BFGX_H
 #define BFGX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -137,6 +138,15 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat_host, const bfgx_model *model, 
                          const bfgx_opts *opts, bfgx_stats *stats);
 int bfgx_paint_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside,
                      double *map_out_host, const bfgx_opts *opts, bfgx_stats *stats);
+
+/* The one-shot calls keep the plan (model on the device, tiling, binning workspace) and their device buffers in a small
+ * process-wide cache keyed by (device, nside, model contents): a repeated call with the same model performs no device
+ * allocation.  bfgx_cache_clear frees the cache; bfgx_debug_alloc_count = device allocations made so far (tests).
+ * bfgx_host_alloc / bfgx_host_free: page-locked host memory for map_out (D2H at full PCIe rate; plain memory works too). */
+void      bfgx_cache_clear(void);
+long long bfgx_debug_alloc_count(void);
+int       bfgx_host_alloc(size_t bytes, void **out);
+void      bfgx_host_free(void *p);
 
 /* ---- resident API (inputs already in HBM; enqueue-only on `hip_stream`) ------------------
  * hip_stream is a hipStream_t; NULL = the legacy default stream (torch's default stream). */

@@ -17,5 +17,5 @@ runner.process()
 ts = []
 for _ in range(5):
     t0 = time.perf_counter(); out = runner.process(); ts.append(time.perf_counter() - t0)
-print(json.dumps({"what": "BaryonifyShell.process() one-shot host API, 1e6 halos, NSIDE 1024, pageable numpy buffers",
+print(json.dumps({"what": "BaryonifyShell.process() one-shot host API, 1e6 halos, NSIDE 1024, pageable numpy inputs, page-locked result, cached plan",
                   "wall_s_best": min(ts), "halos_per_s_incl_pcie": N / min(ts), "stats_ms": runner.last_stats}))

@@ -160,3 +160,44 @@ def test_grid_runner_contract():
         bfg.Runners.regrid_pixels_2D(np.zeros((8, 8), dtype=np.float32), np.zeros((3, 2)), np.zeros(3))
     with pytest.raises(ValueError):
         bfg.Runners.regrid_pixels_3D(np.zeros((8, 8, 8)), np.zeros((3, 2)), np.zeros(3))
+
+
+@pytest.mark.gpu
+def test_warm_process_call_allocates_nothing(gpu):
+    """the one-shot calls re-use a cached plan and pooled device buffers: after the first call with a model, further calls
+    (same model, same or smaller catalog) perform no hipMalloc; a different model builds its own plan; results are unchanged"""
+    from baryonification_amd import _lib
+    from helpers import load_golden, product_runner
+    L = _lib.load()
+    L.bfgx_cache_clear()
+    g = load_golden('lowz_baryonify')
+    r = product_runner(g, acc_f64=True)
+    out1 = r.process()
+    n1 = L.bfgx_debug_alloc_count()
+    out2 = r.process()
+    out3 = r.process()
+    assert L.bfgx_debug_alloc_count() == n1                      # warm calls: no device allocation at all
+    assert np.array_equal(out1, out2) or np.abs(out1 - out2).max() <= 1e-13 * np.abs(out1).max()      # LDS add order only
+    assert np.abs(out3 - g['expected']).max() <= 1e-10 * np.abs(g['expected']).max()
+    # the returned maps are independent arrays (page-locked, pooled on release), not views of one buffer
+    assert out1.ctypes.data != out2.ctypes.data and out2.ctypes.data != out3.ctypes.data
+    # another model -> another plan (allocations), and both stay cached
+    gp = load_golden('lowz_paint')
+    rp = product_runner(gp)
+    p1 = rp.process()
+    n2 = L.bfgx_debug_alloc_count()
+    assert n2 > n1
+    p2 = rp.process()
+    out4 = r.process()
+    assert L.bfgx_debug_alloc_count() == n2
+    assert np.abs(p2 - gp['expected']).max() <= 1e-10 * np.abs(gp['expected']).max() and np.abs(p1 - p2).max() <= 1e-13 * np.abs(p1).max()
+    assert np.abs(out4 - g['expected']).max() <= 1e-10 * np.abs(g['expected']).max()
+    # a released map returns its page-locked buffer to the pool
+    addr = out1.ctypes.data
+    del out1
+    import gc
+    gc.collect()
+    out5 = r.process()
+    assert out5.ctypes.data == addr
+    L.bfgx_cache_clear()
+    _lib.pinned_pool_clear()
