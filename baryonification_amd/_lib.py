@@ -86,6 +86,10 @@ SYMBOLS = {
                                        _P(bfgx_opts), _P(bfgx_stats)]),
     'bfgx_paint_shell': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_void_p,
                                    _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_baryonify_shell_multi': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                             _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_paint_shell_multi': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
+                                         _P(bfgx_opts), _P(bfgx_stats)]),
     'bfgx_cache_clear': (None, []),
     'bfgx_debug_alloc_count': (C.c_longlong, []),
     'bfgx_host_alloc': (C.c_int, [C.c_size_t, _P(C.c_void_p)]),

@@ -12,6 +12,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -1380,6 +1381,9 @@ int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const d
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------ all GPUs of a node from one call
+#include "bfgx_multi_api.inc"
 
 // ------------------------------------------------------------------------------ pixel-window convolution (8f-3)
 #include "bfgx_fftlog_api.inc"

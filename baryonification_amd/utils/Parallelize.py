@@ -68,9 +68,11 @@ def _hip_compute(runner, kind, cat_cols, device):
     dev = torch.device('cuda', device)
     n = cat_cols['M'].size
     t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev) for k, v in cat_cols.items()}
+    lnz, lnM = _lib.table_coords(cat_cols['M'], cat_cols['z'])        # numpy's np.log(1/a), np.log(M): table-edge halos as the reference
+    t['_lnz'], t['_lnM'] = torch.from_numpy(lnz).to(dev), torch.from_numpy(lnM).to(dev)
     plan = engine.ShellPlan(model, keep, nside, n, device=device, stream=torch.cuda.current_stream(dev).cuda_stream)
     cd = _lib.make_catalog_dev(n, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr(),
-                               [t[k].data_ptr() for k in p_keys])
+                               [t[k].data_ptr() for k in p_keys], ln1pz_ptr=t['_lnz'].data_ptr(), lnM_ptr=t['_lnM'].data_ptr())
     if kind == 'baryonify':
         acc = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
         plan.offsets(cd, acc.data_ptr(), acc_f64=False)
@@ -294,7 +296,7 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
     if full is None:
         return None
     new_map = full.cpu().numpy().astype(np.float64)
-    new_sum = sum(float(g[2][1]) + float(np.sum(g[1])) for g in gathered)
+    new_sum = sum(float(g[2][1]) for g in gathered)              # (a rank's deposit sum includes the deposits it listed as far)
     old_sum = sum(float(g[2][0]) for g in gathered)
     assert np.isclose(new_sum, old_sum), "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
     return new_map
@@ -314,7 +316,7 @@ def _agree(err, device):
         raise RuntimeError("another rank failed in the halo-sharded run (see its log)")
 
 
-def _spawn_worker(rank, world, port, runner, kind, seed, backend, out_path):
+def _spawn_worker(rank, world, port, runner, kind, seed, backend, pipe):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -324,42 +326,101 @@ def _spawn_worker(rank, world, port, runner, kind, seed, backend, out_path):
         torch.cuda.set_device(rank)
     dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        out = distributed_process(runner, kind, seed=seed, device=rank)
-        if rank == 0:
-            np.save(out_path, out)
+        try:
+            out = distributed_process(runner, kind, seed=seed, device=rank)
+        except BaseException as e:        # noqa: BLE001  the parent re-raises
+            out = e
+        if rank == 0 and pipe is not None:
+            pipe.send(out)
+            pipe.close()
     finally:
         dist.destroy_process_group()
 
 
 class SplitJoinParallel(object):
-    """Drop-in for Parallelize.py:116-320 where `njobs` = number of GPUs.  `process()` blocks and returns
-    the summed map.  Unlike the reference it also accepts BaryonifyShell (offsets are reduced, not maps)."""
+    """Drop-in for Parallelize.py:116-320 where `njobs` = number of GPUs.  `process()` blocks and returns the summed map.
+    Unlike the reference it also accepts BaryonifyShell (offsets are reduced before the regrid, not final maps).
 
-    def __init__(self, Runner, njobs=-1, seed=42):
+    backend='capi' (default): ONE process drives all GPUs through the C ABI (bfgx_*_shell_multi: halo shards, peer-to-peer
+    slice exchange over xGMI, every device regrids and returns its own slice of the map).  backend='nccl': one process per
+    GPU over torch.distributed / RCCL (distributed_process); the result comes back through a pipe, not a file.
+    `devices`: explicit device list (default range(njobs)); a device may be named more than once."""
+
+    def __init__(self, Runner, njobs=-1, seed=42, backend='capi', devices=None):
         from ..Runners import BaryonifyShell, PaintProfilesShell
         assert isinstance(Runner, (BaryonifyShell, PaintProfilesShell)), \
             f"Runner of type {type(Runner)} is not supported for SplitJoinParallel."
-        self.Runner, self.seed = Runner, seed
+        assert backend in ('capi', 'nccl'), "backend must be 'capi' or 'nccl'"
+        self.Runner, self.seed, self.backend = Runner, seed, backend
         if njobs == -1:
             from .. import _lib
-            njobs = max(1, _lib.load().bfgx_device_count())
+            njobs = max(1, _lib.load().bfgx_device_count()) if devices is None else len(devices)
         self.njobs = njobs
+        self.devices = list(range(njobs)) if devices is None else [int(d) for d in devices]
+        assert len(self.devices) == self.njobs, "len(devices) must equal njobs"
         self.kind = 'baryonify' if isinstance(Runner, BaryonifyShell) else 'paint'
+        self.last_stats = None
 
     def process(self):
-        if self.njobs == 1:
-            return self.Runner.process()
-        import tempfile
+        if self.njobs == 1 and self.devices == [0]:
+            out = self.Runner.process()
+            self.last_stats = self.Runner.last_stats
+            return out
+        if self.backend == 'capi':
+            return self._process_capi()
         import torch.multiprocessing as mp
         import socket
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0))
             port = s.getsockname()[1]
-        with tempfile.TemporaryDirectory() as d:
-            out_path = os.path.join(d, 'map.npy')
-            mp.spawn(_spawn_worker, args=(self.njobs, port, self.Runner, self.kind, self.seed, 'nccl', out_path),
-                     nprocs=self.njobs, join=True)
-            return np.load(out_path)
+        ctx = mp.get_context('spawn')
+        recv, send = ctx.Pipe(duplex=False)
+        procs = [ctx.Process(target=_spawn_worker, args=(r, self.njobs, port, self.Runner, self.kind, self.seed, 'nccl', send if r == 0 else None))
+                 for r in range(self.njobs)]
+        for p in procs:
+            p.start()
+        send.close()
+        try:
+            out = recv.recv()
+        except EOFError:
+            out = None
+        for p in procs:
+            p.join()
+        if out is None or any(p.exitcode != 0 for p in procs):
+            raise RuntimeError("a rank of the halo-sharded run failed (exit codes %r)" % ([p.exitcode for p in procs],))
+        if isinstance(out, BaseException):
+            raise out
+        return out
+
+    def _process_capi(self):
+        import ctypes as C
+        from .. import _lib
+        from ..Runners._model import build_model
+        runner = self.Runner
+        model, p_keys, keep = build_model(runner, 'displacement' if self.kind == 'baryonify' else 'projected')
+        cat = runner.HaloLightConeCatalog.cat
+        order = shuffled_order(cat.size, self.seed)                                 # Parallelize.py:255
+        cols = [np.ascontiguousarray(cat[k][order], dtype=np.float64) for k in ['M', 'z', 'ra', 'dec'] + list(p_keys)]
+        c, keep_cols = _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], cols[4:])
+        nside = int(runner.LightconeShell.NSIDE)
+        npix = 12 * nside * nside
+        new_map = _lib.pinned_empty(npix)
+        devs = (C.c_int32 * self.njobs)(*self.devices)
+        stats = _lib.bfgx_stats()
+        acc64 = getattr(runner, 'acc_f64', None)
+        if self.kind == 'baryonify':
+            opts = _lib.bfgx_opts(0, int(bool(acc64)), 1, 1, 1, 0)
+            orig_map = _lib.f8(runner.LightconeShell.map)
+            rc = _lib.load().bfgx_baryonify_shell_multi(C.byref(c), C.byref(model), nside, orig_map.ctypes.data, new_map.ctypes.data,
+                                                        self.njobs, devs, C.byref(opts), C.byref(stats))
+        else:
+            opts = _lib.bfgx_opts(0, 0, 1, 0, 1, 0)
+            rc = _lib.load().bfgx_paint_shell_multi(C.byref(c), C.byref(model), nside, new_map.ctypes.data, self.njobs, devs,
+                                                    C.byref(opts), C.byref(stats))
+        _lib.check(rc)
+        self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+        del keep, keep_cols
+        return new_map
 
 
 class SimpleParallel(object):

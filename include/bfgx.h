@@ -139,6 +139,18 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat_host, const bfgx_model *model, 
 int bfgx_paint_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside,
                      double *map_out_host, const bfgx_opts *opts, bfgx_stats *stats);
 
+/* ---- all GPUs of one node from ONE call (SURVEY 8b "multi-GPU variant taking a device list") -----------------------
+ * The counterpart of SplitJoinParallel (utils/Parallelize.py:191-320) for a binder that has nothing but this C ABI: the
+ * catalog (already shuffled by the caller if wanted, Parallelize.py:255) is cut into ndev contiguous shards
+ * (ceil(n / ndev) halos, :250-266), device devices[d] runs shard d, the partial accumulators are exchanged by pixel slices
+ * with peer-to-peer copies over xGMI (each device pulls the range it owns from every other one), every device regrids the
+ * OUTPUT pixels of its ring bands and copies its slice straight into map_out_host.  Same arguments, results and errors as
+ * the single-device calls; opts->device is ignored, opts->algo must be 1.  `devices` may repeat a device. */
+int bfgx_baryonify_shell_multi(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside, const double *map_in_host,
+                               double *map_out_host, int32_t ndev, const int32_t *devices, const bfgx_opts *opts, bfgx_stats *stats);
+int bfgx_paint_shell_multi(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside, double *map_out_host,
+                           int32_t ndev, const int32_t *devices, const bfgx_opts *opts, bfgx_stats *stats);
+
 /* The one-shot calls keep the plan (model on the device, tiling, binning workspace) and their device buffers in a small
  * process-wide cache keyed by (device, nside, model contents): a repeated call with the same model performs no device
  * allocation.  bfgx_cache_clear frees the cache; bfgx_debug_alloc_count = device allocations made so far (tests).
@@ -173,7 +185,7 @@ int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offs
  * range [olo, ohi) -- the summed pix_offsets the rank must hold (offsets_dev points at pixel olo, [ohi - olo][3]).
  * out_slice_dev points at the rank's first own pixel ([p1 - p0] values, every one stored exactly once, no zero-fill);
  * map_in_dev is the full map; sums_dev (optional, double[2]) receives {sum of the rank's source pixels, sum of its
- * deposits}.  Deposits that need the generic route (pole caps, displacements of more than 3 pixel columns / one ring)
+ * deposits, the listed far ones included}.  Deposits that need the generic route (pole caps, displacements of more than 3 pixel columns / one ring)
  * are NOT applied by this call: they are listed with global pixel numbers; bfgx_plan_far_fetch copies the list of the
  * last regrid to the host (blocking; n_host = 0 almost always; NULL buffers: count only) so that the caller can add
  * them to whichever rank's slice holds the pixel.  (bfgx_regrid_device applies its own list.) */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Functional rehearsal of the N > 1 product path on a ONE-GPU box: every rank uses device 0, the process group is
-gloo and utils/Parallelize stages its two all_to_all steps through the host.  Checks that
-distributed_process(runner, ...) with the HIP engine (halo shards -> sliced reduce-scatter -> banded regrid -> windows to
+gloo and utils/Parallelize stages its all_to_all steps through the host.  Checks that
+distributed_process(runner, ...) with the HIP engine (halo shards -> sliced reduce-scatter -> one-ring halo exchange -> banded gathering regrid -> disjoint slices to
 rank 0) returns what a single-process runner.process() returns.  Launch:
 
     GLOO_SOCKET_IFNAME=lo python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29577 scripts/rehearse_multi_gpu.py
@@ -27,6 +27,7 @@ def main():
     ok = True
     for kind, nside, nh in (('baryonify', 256, 60_000), ('paint', 128, 20_000)):
         cat = syn.make_catalog(nh)
+        cat['dec'][:4] = [89.95, -89.9, 89.99, -89.999]          # halos on the pole caps: pixels that take the far-deposit route
         z, M, r = syn.table_grid(cat)
         cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
         Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)

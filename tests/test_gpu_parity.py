@@ -213,3 +213,25 @@ def test_randomized_regimes_vs_oracle(gpu, seed, nside, zr, logM, eps):
     with np.errstate(divide='ignore'):
         orap = O.paint_shell(nside, used, O.Table(axes, np.log(P)), eps, bg)
     assert np.abs(out - orap).max() <= 1e-10 * np.abs(orap).max()
+
+
+@pytest.mark.parametrize('name', ['lowz_baryonify', 'c1_baryonify', 'rdelta_baryonify', 'lowz_paint', 'param1_paint'])
+@pytest.mark.parametrize('ndev', [1, 3])
+def test_multi_device_c_entry_on_one_gpu(gpu, name, ndev):
+    """bfgx_*_shell_multi (all GPUs of a node from one C call) with the ONE device of this box named `ndev` times: the halo
+    shards, the peer-to-peer slice exchange (device-to-device copies here), the banded gathering regrid and the assembly of the
+    disjoint slices are the code an 8-GPU node runs.  Through the drop-in SplitJoinParallel; result == single-device run."""
+    import baryonification_amd as bfg
+    g = load_golden(name)
+    exp = g['expected']
+    r = product_runner(g, acc_f64=True)
+    sj = bfg.utils.SplitJoinParallel(r, njobs=ndev, devices=[0] * ndev)
+    out = sj.process()
+    assert out.dtype == np.float64 and out.shape == exp.shape
+    assert np.abs(out - exp).max() <= 1e-10 * np.abs(exp).max()
+    if g['kind'] == 'baryonify':
+        assert np.isclose(sj.last_stats['sum_out'], sj.last_stats['sum_in']) and np.isclose(out.sum(), g['map_in'].sum())
+        # default accumulators (f32 pix_offsets) through the same path
+        r32 = product_runner(g)
+        out32 = bfg.utils.SplitJoinParallel(r32, njobs=ndev, devices=[0] * ndev).process()
+        assert np.abs(out32 - exp).max() <= 1e-6 * exp.mean()
