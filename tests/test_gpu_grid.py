@@ -236,3 +236,44 @@ def test_grid_edge_cases(gpu):
     assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max() and r1.last_stats['n_pairs'] > 20000
     zero = bfg.utils.GriddedMap(map=np.zeros((32,) * 3), redshift=c['redshift'], bins=c['bins'], cosmo=cos)
     assert np.all(bfg.Runners.BaryonifyGrid(one, zero, 40.0, model, verbose=False).process() == 0)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 5 sizes
+def test_config5_size_512_cubed(gpu):
+    """512^3 (BASELINE config 5's grid): the 512-point LDS FFT lines and the 512^3 deposit / regrid meet the oracle.
+    P(k) of a 512^3 map against the numpy restatement of the notebook cells (np.fft.fftn, np.bincount); make_map of 3e6
+    particles against the oracle's histogramdd; regrid_pixels_3D of 2e6 displaced pixels against the oracle's 5^3-cell loops."""
+    import baryonification_amd as bfg
+    from baryonification_amd.engine import power_spectrum
+    from oracle import grid as G
+    N, L = 512, 1000.0
+    rng = np.random.default_rng(512)
+    # (a) deposit
+    npart = 3_000_000
+    xyz = rng.uniform(0, L, (npart, 3))
+    xyz[:5] = [[0, 0, 0], [L, L, L], [L / 2, 0, L], [1e-12, L - 1e-12, 500.0], [L / N, 2 * L / N, 3 * L / N]]     # edges: inclusive last edge
+    mass = rng.uniform(0.5, 2.0, npart)
+    Snap = bfg.utils.ParticleSnapshot(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2], M=mass, L=L, redshift=0.0,
+                                      cosmo=H.load_grid_golden('grid2d_paint')['cosmo_runner'])
+    Map = Snap.make_map(N)
+    ora = G.make_map([xyz[:, 0], xyz[:, 1], xyz[:, 2]], mass, L, N)
+    assert Map.shape == (N, N, N) and np.abs(Map - ora).max() <= 1e-12 * ora.max() and np.array_equal(Map != 0, ora != 0)
+    assert np.isclose(Map.sum(), mass.sum(), rtol=1e-12)
+    del ora
+    # (b) P(k): every 512-point line of the LDS FFT, all 180 bins
+    k_cen, Pk, k_c = power_spectrum(Map, L, 180)
+    ok_cen, oPk, ok_c = G.power_spectrum(Map, L, 180)
+    assert np.array_equal(k_c, ok_c) and np.all(ok_c > 0)
+    assert np.abs(Pk / oPk - 1).max() <= 1e-10 and np.abs(k_cen / ok_cen - 1).max() <= 1e-11      # (means over ~1e6 modes per bin)
+    del Map
+    # (c) regrid: 2e6 pixels of the 512^3 grid displaced by up to two cells, some across the periodic faces
+    n = 2_000_000
+    idx = rng.choice(N ** 3, n, replace=False)
+    base = np.stack(np.unravel_index(idx, (N, N, N)), axis=1).astype(np.float64)
+    pos = base + rng.normal(0, 0.7, (n, 3))
+    pos[:1000] = base[:1000]                              # undisplaced pixels deposit into themselves
+    val = rng.uniform(0.1, 3.0, n)
+    grid = np.zeros((N, N, N))
+    bfg.Runners.regrid_pixels_3D(grid, pos, val)
+    ora = G.regrid_pixels(np.zeros((N, N, N)), pos, val)
+    assert np.abs(grid - ora).max() <= 1e-12 * ora.max() and np.isclose(grid.sum(), val.sum(), rtol=1e-12)
