@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 10 --warmup 2 --no-cpu-baseline $@"
+BENCH_ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extras $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $BENCH_ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "trace rc=$?"
 for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

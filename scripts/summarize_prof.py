@@ -10,16 +10,23 @@ out = sys.argv[1]
 
 
 def short(name):
-    for k in ('halo_prep_kernel', 'halo_scatter_kernel', 'tile_regrid_kernel', 'regrid_kernel', 'sum2_kernel'):
+    """kernel name as the summaries print it"""
+    tags = (('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
+            ('halo_prep_kernel', 'halo_prep'), ('halo_scatter_kernel', 'halo_scatter'), ('regrid_far_kernel', 'regrid_far'),
+            ('regrid_kernel', 'regrid(algo0)'), ('sum2_kernel', 'sum2'), ('sum_tiles_kernel', 'sum_tiles'), ('tile_scan_kernel', 'tile_scan'),
+            ('tile_place_kernel', 'tile_place'))
+    for k, t in tags:
         if k in name:
-            if k == 'halo_scatter_kernel':
-                mode = {'ILi0E': 'OFFSETS', 'ILi1E': 'PAINT', 'ILi2E': 'COUNT'}
-                for m, v in mode.items():
-                    if m in name:
-                        return 'halo_scatter<%s,%s>' % (v, 'f64' if (m + 'd') in name else 'f32')
-                if '<0' in name or '<(int)0' in name:
-                    return 'halo_scatter<OFFSETS>'
-            return k
+            mode = ''
+            for m, v in (('<0', 'OFFSETS'), ('<(int)0', 'OFFSETS'), ('<1', 'PAINT'), ('<(int)1', 'PAINT'), ('<2', 'COUNT'), ('<(int)2', 'COUNT')):
+                if k + m in name.replace('bfgx::', '').replace('void ', ''):
+                    mode = '<' + v + (',f64' if 'double' in name else ',f32') + '>'
+                    break
+            if not mode and 'regrid3' in k:
+                mode = '<f64>' if 'regrid3_kernel<double' in name else '<f32>'
+            elif not mode and 'scatter' in k:
+                mode = '<f64>' if 'double' in name else '<f32>'
+            return t + mode
     return name[:60]
 
 
@@ -41,3 +48,34 @@ for k in sorted(agg):
     for c in sorted(agg[k]):
         v = agg[k][c]
         print("    %-28s %18.1f   (n=%d)" % (c, sum(v) / len(v), len(v)))
+
+# machine-readable: per-launch HBM traffic and VALU instruction counts of the two big kernels (bench.py reads this file)
+import json
+cfg = None
+for f in glob.glob(os.path.join(out, 'bench_trace.json')):
+    try:
+        cfg = json.loads(open(f).read().strip().splitlines()[-1])['config']
+    except Exception:
+        pass
+
+
+def mean(k, c):
+    v = agg.get(k, {}).get(c)
+    return sum(v) / len(v) if v else None
+
+
+pick = {'offsets': 'tile_scatter2<OFFSETS,f32>', 'regrid': 'tile_regrid3<f32>', 'paint': 'tile_scatter2<PAINT,f64>', 'prep': 'halo_prep'}
+res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline` (scripts/profile_bench.sh), mean per "
+                 "dispatch; traffic = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024 bytes: on gfx950 FETCH_SIZE reports half the bytes of wide "
+                 "coalesced reads (MI355X_MICROARCH.md, HBM section) -- the correction is applied although part of these kernels' reads are "
+                 "narrow gathers, so the figure is an upper bound; valu_wave_insts = SQ_INSTS_VALU",
+       "config": None if cfg is None else {"halos_per_gpu": cfg.get('halos_per_gpu'), "nside": cfg.get('nside'), "algo": 1, "mode": "baryonify"},
+       "kernels": {}, "valu_wave_insts": {}, "fetch_kb": {}, "write_kb": {}}
+for key, kn in pick.items():
+    fs, ws, vi = mean(kn, 'FETCH_SIZE'), mean(kn, 'WRITE_SIZE'), mean(kn, 'SQ_INSTS_VALU')
+    if fs is not None and ws is not None:
+        res["kernels"][key] = fs * 1024 * 2 + ws * 1024
+        res["fetch_kb"][key], res["write_kb"][key] = fs, ws
+    if vi is not None:
+        res["valu_wave_insts"][key] = vi
+json.dump(res, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
