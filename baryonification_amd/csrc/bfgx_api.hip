@@ -90,7 +90,7 @@ int validate_table(const bfgx_table &t)
 }  // namespace
 
 struct bfgx_plan {
-    int device = 0;
+    int device = 0, num_cus = 256;
     hipStream_t stream = nullptr;
     int64_t nside = 0, max_halos = 0;
     Hpx hpx;
@@ -297,7 +297,7 @@ static int launch_place(bfgx_plan *p, const bfgx_catalog *c)
 static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool f64)
 {
     const size_t nt = (size_t)p->tiling.ntiles;
-    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 5 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w
+    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 6 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel
     if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, (const int32_t *)p->tile_count,
@@ -351,11 +351,15 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     tb.v = (sizeof(real) == 4) ? (const real *)p->tab8f : (const real *)p->tab8d;
     tb.r0 = (real)p->model.tab.r0; tb.r1 = (real)p->model.tab.r1; tb.inv_dr = (real)p->model.tab.inv_dr;
     tb.nr = p->model.tab.n[2]; tb._pad = 0;
+    // persistent grid: two 512-thread workgroups per CU (LDS and registers allow exactly that) draw tiles from a counter that the
+    // binning step has reset (the sixth block of the counter array)
+    unsigned int *tile_counter = (unsigned int *)(p->tile_count + 5 * ((size_t)p->tiling.ntiles + 1));
+    const int grid = std::min(p->tiling.ntiles, 2 * p->num_cus);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
-    hipLaunchKernelGGL(kern, dim3(p->tiling.ntiles), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
-                       (const int32_t *)p->entries, p->capacity, out, p->pair_total);
+                       (const int32_t *)p->entries, p->capacity, out, p->pair_total, tile_counter);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -518,6 +522,10 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
 
     bfgx_plan *p = new bfgx_plan();
     p->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->num_cus = cus;
+    }
     p->nside = nside;
     p->max_halos = max_halos;
     p->hpx = make_hpx(nside);
@@ -598,7 +606,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             return 0;
         };
         void *d0 = nullptr, *d1 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr, *d6 = nullptr;
-        if (dalloc(sizeof(int32_t) * 5 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
+        if (dalloc(sizeof(int32_t) * 6 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
             dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
             dalloc(sizeof(unsigned long long), &d5) || dalloc(sizeof(TileRef) * (size_t)(max_halos > 0 ? max_halos : 1), &d6))
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(binning workspace) failed"));

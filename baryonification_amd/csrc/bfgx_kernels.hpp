@@ -23,6 +23,9 @@
 #ifndef BFGX_ABLATE
 #define BFGX_ABLATE 0      // >0: timing-only ablation builds (scripts/ablate.sh); never shipped
 #endif
+#ifndef BFGX_ABL0
+#define BFGX_ABL0 0        // K0 ablations (timing only): 1 no record stores, 2 no tile binning, 3 neither, 4 geometry only
+#endif
 #include "bfgx_cosmo.hpp"
 #include "bfgx_math.hpp"
 
@@ -561,6 +564,16 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         __syncthreads();
     }
     const double *gz = ax_in_lds ? ax_lds : m.tab.axis[0], *gm = ax_in_lds ? ax_lds + kAxisLds : m.tab.axis[1];
+    // the per-band tables of the tiling (first tile, azimuth slices, shortest ring) go to LDS too: the tile enumeration of
+    // every halo reads them through chains of dependent loads
+    constexpr int kBandLds = 1024;
+    __shared__ int32_t band_lds[3 * kBandLds + 1];
+    if (o.tref && T.nbands <= kBandLds) {
+        for (int i = threadIdx.x; i <= T.nbands; i += blockDim.x) band_lds[i] = T.band_tile0[i];
+        for (int i = threadIdx.x; i < T.nbands; i += blockDim.x) { band_lds[kBandLds + 1 + i] = T.band_nphi[i]; band_lds[2 * kBandLds + 1 + i] = T.band_nrmin[i]; }
+        __syncthreads();
+        T.band_tile0 = band_lds; T.band_nphi = band_lds + kBandLds + 1; T.band_nrmin = band_lds + 2 * kBandLds + 1;
+    }
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
     HaloRec r;
@@ -681,7 +694,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         if (r.fb) for (int q = 0; q < 4; ++q) if (r.fb_ring[q] < 16 || r.fb_ring[q] > (int)nl4 - 16) cls = kClsWide;
     }
     if (o.rec && (o.rec_all || cls == kClsWide)) o.rec[j] = r;
-    if (cls == kClsNarrow) {
+    if (cls == kClsNarrow && !(BFGX_ABL0 & 1)) {
         RowRec rr;
         rr.z0 = r.z0; rr.s0 = r.s0; rr.xa = r.xa; rr.cosr = r.cosr; rr.phi0 = r.phi0;
         rr.rfirst = r.rfirst; rr.rlast = r.rlast; rr.fb = r.fb; rr._pad = 0;
@@ -713,7 +726,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
             o.fbrec[j] = f;
         }
     }
-    if (o.tref) {           // tile binning, pass 1: reserve one slot per touched tile
+    if (BFGX_ABL0 & 1) { if (r.cosr == 1.2345 && wv[0] == 0.5) o.rowrec[j].z0 = r.lnoff + r.rcut; }      // keep the values alive
+    if (o.tref && !(BFGX_ABL0 & 2)) {           // tile binning, pass 1: reserve one slot per touched tile
         DiscSpan ds;
         ds.fb = r.fb; ds.rfirst = r.rfirst; ds.rlast = r.rlast; ds.allphi = r.allphi; ds.flo = r.flo; ds.fhi = r.fhi;
         for (int q = 0; q < 4; ++q) { ds.fb_ring[q] = r.fb_ring[q]; ds.fb_k[q] = r.fb_k[q]; }
@@ -1186,7 +1200,10 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
     int64_t e1 = tile_start[tile + 1];
     if (e1 > capacity) e1 = capacity;
     const int ne = (int)(e1 > e0 ? e1 - e0 : 0);
-    const int nchunks = (ne + kChunk - 1) / kChunk;
+    // entries a wave takes at a time: the wide pass visits a few polar tiles with a handful of entries each (and thousands of
+    // pixels per entry), so small chunks keep all four waves of the tile busy
+    const int chunk = wide_tiles ? 2 : kChunk;
+    const int nchunks = (ne + chunk - 1) / chunk;
     TileWaveLds &L = wl[wid];
     unsigned long long npairs = 0;
 
@@ -1198,8 +1215,8 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
 
         // ---- lanes = entries of this chunk
         int nrows = 0;
-        if (lane < kChunk && c * kChunk + lane < ne) {
-            const int hidx = entries[e0 + c * kChunk + lane];
+        if (lane < chunk && c * chunk + lane < ne) {
+            const int hidx = entries[e0 + c * chunk + lane];
             const HaloRec &r = recs[hidx];
             RingSlot rs;
             rs.z0 = r.z0; rs.xa = r.xa; rs.cosr = r.cosr; rs.phi0 = r.phi0;

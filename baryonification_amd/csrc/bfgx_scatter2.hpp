@@ -255,11 +255,19 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                      const int32_t *__restrict__ entries, int64_t capacity,
-                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total)
+                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    const int tile = T.tile_order[blockIdx.x];        // heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
+    // persistent workgroups (two per CU): tiles are drawn from a device counter in the order of T.tile_order -- heavy
+    // (equatorial) tiles first, the light polar ones fill the tail -- so that no workgroup launch sits between two tiles
+    __shared__ int s_tile;
+    while (true) {
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    const int tile_idx = s_tile;
+    if (tile_idx >= T.ntiles) break;
+    const int tile = T.tile_order[tile_idx];
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
@@ -502,7 +510,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 
     if (MODE == MODE_COUNT) {
         if (lane == 0 && npairs) atomicAdd(pair_total, npairs);
-        return;
+        continue;
     }
     // ---- flush: every pixel of the tile is stored exactly once (plain, row-contiguous stores of [pixel][component])
     for (int rr = wid; rr < i1 - i0; rr += kW2) {
@@ -519,6 +527,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
             const int cc = x - px * NCOMP;
             dst[x] = (ACC)src[cc * PL + ((px + rot) & wmask)];
         }
+    }
+    __syncthreads();                                   // the LDS tile is reused by the next tile
     }
 }
 

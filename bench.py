@@ -442,7 +442,8 @@ def main():
     elapsed, _ = timed(step, args.steps, False)
     # the same K steps again with HIP events around every kernel on the launch stream (bfgx_plan_timing_*): kernel_ms, roofline
     elapsed_ev, kt = timed(step, args.steps, True) if not args.no_kernel_events else (None, None)
-    plan.status()                              # entry-list capacity, far-deposit list
+    if os.environ.get('BFGX_BENCH_NOSTATUS') != '1':   # (timing-only ablation builds produce meaningless offsets)
+        plan.status()                          # entry-list capacity, far-deposit list
     if slices and not paint:
         assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
 

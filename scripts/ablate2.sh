@@ -17,6 +17,6 @@ else
   for N in 0 ${ABL_LIST:-1 2 3 4}; do
     L=$PWD/$D/build/libbfgx_abl$N.so; [ $N = 0 ] && L=$PWD/$D/libbfgx.so
     echo -n "ABL2=$N  "
-    BFGX_LIB=$L python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_ms'])"
+    BFGX_BENCH_NOSTATUS=1 BFGX_LIB=$L python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_ms'])"
   done
 fi
