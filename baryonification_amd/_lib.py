@@ -99,6 +99,9 @@ SYMBOLS = {
     'bfgx_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'bfgx_plan_bands': (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_void_p]),
+    'bfgx_baryonify_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'bfgx_plan_reach_rings': (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int32)]),
+    'bfgx_plan_set_band_reach': (C.c_int, [C.c_void_p, C.c_int32]),
     'bfgx_plan_band_apron': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_int64), _P(C.c_int64)]),
     'bfgx_regrid_bands_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                            C.c_void_p]),

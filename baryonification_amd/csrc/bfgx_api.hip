@@ -107,6 +107,12 @@ struct bfgx_plan {
             *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
     TileRef *tref = nullptr;
     FarList far;                     // deposits of the gathering regrid that need the generic route (bfgx_regrid2.hpp)
+    int32_t *far_overflow_full = nullptr;   // full-map regrid: overflow of the list is repaired in-stream (pass 1), not an error
+    int32_t *regrid_todo = nullptr;  // [0] = count, then the tiles the lean gather kernel leaves to the one with the ring walk
+    float *tile_omax = nullptr;      // largest |offset|^2 of every tile (K1's flush or tile_reach_kernel): the reach of the gathering regrid
+    bool omax_from_k1 = false;       // set while a fused offsets + regrid call is in flight
+    int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
+    int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
     int32_t *wide_tiles = nullptr;   // [1 + ntiles]: number of tiles with wide entries, then those tiles (tile_scan_kernel)
     // fast tiled scatter (bfgx_scatter2.hpp): slim per-halo records + interleaved copies of the table
     bool fast_ok = false;            // 3-axis table with a uniform ln r axis, small enough to interleave
@@ -297,7 +303,7 @@ static int launch_place(bfgx_plan *p, const bfgx_catalog *c)
 static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool f64)
 {
     const size_t nt = (size_t)p->tiling.ntiles;
-    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 6 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel
+    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 7 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel, largest |offset|^2 per tile
     if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, (const int32_t *)p->tile_count,
@@ -334,7 +340,8 @@ static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out, bool wide_only)
                        (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total,
                        wide_only ? (const int32_t *)p->tile_count : (const int32_t *)nullptr,
                        wide_only ? (const int32_t *)p->tile_count_b : (const int32_t *)nullptr, wide_only ? 1 : 0,
-                       wide_only ? (const int32_t *)p->wide_tiles : (const int32_t *)nullptr);
+                       wide_only ? (const int32_t *)p->wide_tiles : (const int32_t *)nullptr,
+                       (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -359,7 +366,8 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
-                       (const int32_t *)p->entries, p->capacity, out, p->pair_total, tile_counter);
+                       (const int32_t *)p->entries, p->capacity, out, p->pair_total, tile_counter,
+                       (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -606,7 +614,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             return 0;
         };
         void *d0 = nullptr, *d1 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr, *d6 = nullptr;
-        if (dalloc(sizeof(int32_t) * 6 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
+        if (dalloc(sizeof(int32_t) * 7 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
             dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
             dalloc(sizeof(unsigned long long), &d5) || dalloc(sizeof(TileRef) * (size_t)(max_halos > 0 ? max_halos : 1), &d6))
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(binning workspace) failed"));
@@ -617,12 +625,23 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
         {
             void *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *f3 = nullptr;
-            p->far.cap = (int64_t)1 << 20;
-            if (dalloc(sizeof(unsigned long long), &f0) || dalloc(sizeof(int64_t) * (size_t)p->far.cap, &f1) ||
-                dalloc(sizeof(double) * (size_t)p->far.cap, &f2) || dalloc(sizeof(int32_t), &f3))
+            p->far.cap = std::max<int64_t>((int64_t)1 << 20, p->hpx.npix / 16);
+            // control words in one allocation: [0..7] entries listed, [8..11] overflow (full-map regrid), [12..15] tiles left to
+            // the walking kernel (followed by their numbers), ... ; the banded regrid's overflow flag lives after the tile list
+            void *f4 = nullptr;
+            if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 8), &f0) || dalloc(sizeof(int64_t) * (size_t)p->far.cap, &f1) ||
+                dalloc(sizeof(double) * (size_t)p->far.cap, &f2) ||
+                dalloc(sizeof(int32_t) * 2 * (size_t)(T.ntiles + 1), &f3))
                 return bail(fail(BFGX_ERR_HIP, "hipMalloc(far list) failed"));
-            p->far.count = (unsigned long long *)f0; p->far.pix = (int64_t *)f1; p->far.val = (double *)f2; p->far.overflow = (int32_t *)f3;
-            if (hipMemsetAsync(p->far.overflow, 0, sizeof(int32_t), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
+            p->tile_apron = (int32_t *)f3;
+            int32_t *ctrl = (int32_t *)f0;
+            p->far.count = (unsigned long long *)ctrl; p->far.pix = (int64_t *)f1; p->far.val = (double *)f2;
+            p->far_overflow_full = ctrl + 2;
+            p->regrid_todo = ctrl + 3;                       // [0] count, [1 ..] tiles
+            p->far.overflow = ctrl + 4 + T.ntiles;
+            p->tile_omax = (float *)(p->tile_count + 6 * ((size_t)T.ntiles + 1));
+            (void)f4;
+            if (hipMemsetAsync(ctrl, 0, sizeof(int32_t) * (size_t)(T.ntiles + 8), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
         }
         void *d9 = nullptr;
         if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 1), &d9)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(wide tile list) failed"));
@@ -722,6 +741,14 @@ int bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel)
     return BFGX_OK;
 }
 
+// arguments of the gathering regrid that do not depend on the data
+static ReachArgs reach_args(const bfgx_plan *p, double cap)
+{
+    const double ns = (double)p->hpx.nside, om = 1.0 / (3.0 * ns * ns);        // ring 1: z = 1 - 1 / (3 nside^2)
+    const double th1 = std::atan2(std::sqrt(om * (2.0 - om)), 1.0 - om);
+    return ReachArgs{p->tile_apron, cap, th1, 3.14159265358979323846 - th1};
+}
+
 // first pixel of ring `ring` (1 .. 4 nside - 1), npix beyond
 static int64_t ring_first_pixel(const Hpx &h, int64_t ring)
 {
@@ -737,8 +764,24 @@ int bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *ol
     if (!p || !olo || !ohi) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
     const int64_t i0 = 1 + (int64_t)p->tiling.BR * band0, i1 = 1 + (int64_t)p->tiling.BR * band1;      // rings [i0, i1)
-    *olo = ring_first_pixel(p->hpx, i0 - kGatherR);
-    *ohi = ring_first_pixel(p->hpx, i1 + kGatherR);
+    *olo = ring_first_pixel(p->hpx, i0 - p->band_reach);
+    *ohi = ring_first_pixel(p->hpx, i1 + p->band_reach);
+    return BFGX_OK;
+}
+
+int bfgx_plan_reach_rings(bfgx_plan *p, double max_offset, int32_t *rings)
+{
+    if (!p || !rings) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (!(max_offset >= 0.0)) return fail(BFGX_ERR_INVALID, "max_offset must be >= 0");
+    *rings = regrid_reach_rings(p->hpx.nside, std::min(max_offset * 1.001, regrid_cap(p->hpx.nside)));
+    return BFGX_OK;
+}
+
+int bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    if (rings < 1 || rings > kReachMax) return fail(BFGX_ERR_INVALID, "band reach must be 1 .. %d rings", kReachMax);
+    p->band_reach = rings;
     return BFGX_OK;
 }
 
@@ -750,8 +793,8 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
     int64_t need_lo = 0, need_hi = 0;
     if (int rc = bfgx_plan_band_apron(p, band0, band1, &need_lo, &need_hi)) return rc;
     if (olo > need_lo || ohi < need_hi || olo < 0 || ohi > p->hpx.npix)
-        return fail(BFGX_ERR_INVALID, "pix_offsets range [%lld, %lld) does not cover the bands and one ring either side [%lld, %lld)",
-                    (long long)olo, (long long)ohi, (long long)need_lo, (long long)need_hi);
+        return fail(BFGX_ERR_INVALID, "pix_offsets range [%lld, %lld) does not cover the bands and %d ring(s) either side [%lld, %lld)",
+                    (long long)olo, (long long)ohi, p->band_reach, (long long)need_lo, (long long)need_hi);
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
     if (band0 == band1) return BFGX_OK;
@@ -762,12 +805,26 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
         const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
         // virtual bases: the kernel indexes every array by global pixel number
         double *out_base = out_slice_dev - p0;
-        if (acc_f64)
-            hipLaunchKernelGGL((tile_regrid3_kernel<double, double>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
-                               (const double *)offsets_dev - 3 * olo, out_base, p->far, sums_dev ? p->tile_sums : nullptr, t0);
-        else
-            hipLaunchKernelGGL((tile_regrid3_kernel<float, float>), dim3(t1 - t0), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev,
-                               (const float *)offsets_dev - 3 * olo, out_base, p->far, sums_dev ? p->tile_sums : nullptr, t0);
+        // every rank gathers with the same fixed reach (so that all of them classify a source pixel the same way)
+        const ReachArgs reach = reach_args(p, regrid_cap_for_rings(p->hpx.nside, p->band_reach));
+        hipLaunchKernelGGL(tile_apron_kernel, dim3((t1 - t0 + 255) / 256), dim3(256), 0, p->stream, p->hpx, p->tiling, (const float *)nullptr,
+                           p->band_reach, reach.cap, t0, t1 - t0, p->tile_apron, (int32_t *)nullptr);
+        double *ts = sums_dev ? p->tile_sums : nullptr;
+        const dim3 grid(t1 - t0), blk(256);
+        int *none = nullptr;
+        if (acc_f64) {
+            const double *o = (const double *)offsets_dev - 3 * olo;
+            if (p->band_reach == 1)
+                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+            else
+                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+        } else {
+            const float *o = (const float *)offsets_dev - 3 * olo;
+            if (p->band_reach == 1)
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+            else
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (sums_dev) {
@@ -840,8 +897,34 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
     return launch_scatter<MODE_PAINT, float>(p, cat->n, (float *)map_out_dev, nullptr);
 }
 
-int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
-                       double *map_out_dev, double *sums_dev)
+}  // extern "C"
+
+// the gathering regrid (algo 1): [largest |offset|^2 per tile unless K1 left it], aprons, lean gather, gather with the ring
+// walk over the tiles that need it, far list / repair
+template <typename ACC, typename real>
+static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const ACC *o, double *map_out_dev, double *ts, bool from_k1)
+{
+    const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real));
+    FarList far = p->far;
+    far.overflow = p->far_overflow_full;
+    const int nt = p->tiling.ntiles, nfix = std::min(nt, 2 * p->num_cus), nwalk = std::min(nt, 4 * p->num_cus);
+    const ReachArgs reach = reach_args(p, regrid_cap(p->hpx.nside));
+    if (!from_k1)
+        hipLaunchKernelGGL(tile_reach_kernel<ACC>, dim3(nt), dim3(256), 0, p->stream, p->hpx, p->tiling, o, p->tile_omax);
+    hipLaunchKernelGGL(tile_apron_kernel, dim3((nt + 255) / 256), dim3(256), 0, p->stream, p->hpx, p->tiling, (const float *)p->tile_omax, 0,
+                       reach.cap, 0, nt, p->tile_apron, p->regrid_todo);
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0>), dim3(nt), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo);
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2>), dim3(nwalk), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo);
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 1>), dim3(nfix), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
+                       map_out_dev, far, reach, (double *)nullptr, -1, nt, p->regrid_todo);
+}
+
+extern "C" {
+
+static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64, double *map_out_dev, double *sums_dev,
+                       bool from_k1)
 {
     if (!p || !map_in_dev || !offsets_dev || !map_out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(p->device));
@@ -849,16 +932,11 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
     KernelTimer kt(p, BFGX_K_REGRID);
     if (p->algo == 1) {
         // gathering form: every output pixel is stored once by the tile that owns it (no atomics, no zero-fill needed);
-        // the few deposits that need the generic route are listed and added by a small fix-up kernel
-        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
-        HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
-        if (acc_f64)
-            hipLaunchKernelGGL((tile_regrid3_kernel<double, double>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const double *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr, -1);
-        else
-            hipLaunchKernelGGL((tile_regrid3_kernel<float, float>), dim3(p->tiling.ntiles), dim3(256), lds, p->stream, p->hpx,
-                               p->tiling, map_in_dev, (const float *)offsets_dev, map_out_dev, p->far, sums_dev ? p->tile_sums : nullptr, -1);
-        hipLaunchKernelGGL(regrid_far_kernel, dim3(64), dim3(256), 0, p->stream, p->far, map_out_dev);
+        // the few deposits that need the generic route are listed and added afterwards
+        HIP_TRY(hipMemsetAsync(p->far.count, 0, 4 * sizeof(int32_t), p->stream));      // entries, overflow, tiles left to the walking kernel
+        double *ts = sums_dev ? p->tile_sums : nullptr;
+        if (acc_f64) launch_regrid_gather<double, double>(p, map_in_dev, (const double *)offsets_dev, map_out_dev, ts, from_k1);
+        else launch_regrid_gather<float, float>(p, map_in_dev, (const float *)offsets_dev, map_out_dev, ts, from_k1);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
         if (acc_f64)
@@ -882,6 +960,24 @@ int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offse
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;
+}
+
+int bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
+                       double *map_out_dev, double *sums_dev)
+{
+    return regrid_impl(p, map_in_dev, offsets_dev, acc_f64, map_out_dev, sums_dev, false);
+}
+
+int bfgx_baryonify_device(bfgx_plan *p, const bfgx_catalog *cat, const double *map_in_dev, void *offsets_work_dev, int acc_f64,
+                          double *map_out_dev, double *sums_dev)
+{
+    if (!p || !map_in_dev || !offsets_work_dev || !map_out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    const bool fused = p->algo == 1;         // K1's flush leaves the largest |offset|^2 of every tile for the regrid's aprons
+    p->omax_from_k1 = fused;
+    const int rc = bfgx_offsets_device(p, cat, offsets_work_dev, acc_f64);
+    p->omax_from_k1 = false;
+    if (rc) return rc;
+    return regrid_impl(p, map_in_dev, offsets_work_dev, acc_f64, map_out_dev, sums_dev, fused);
 }
 
 int bfgx_count_pairs_device(bfgx_plan *p, const bfgx_catalog *cat, int fallback4, int64_t *counts_dev, int64_t *total_host)
@@ -1175,8 +1271,7 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
         HIP_TRY(hipMemsetAsync(e->off.p, 0, acc_bytes, p->stream));
         HIP_TRY(hipMemsetAsync(e->out.p, 0, npix * sizeof(double), p->stream));
     }
-    if (int rc = bfgx_offsets_device(p, &dcat, e->off.p, o.acc_offsets_f64)) return rc;
-    if (int rc = bfgx_regrid_device(p, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p)) return rc;
+    if (int rc = bfgx_baryonify_device(p, &dcat, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p)) return rc;
     const double ms_k = t.stop(p->stream);
 
     t.start(p->stream);

@@ -1148,7 +1148,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total,
                     const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, int addmode,
-                    const int32_t *__restrict__ wide_tiles)
+                    const int32_t *__restrict__ wide_tiles, unsigned int *__restrict__ omax2)
 {
     // wide_tiles != nullptr ("wide pass"): only the wide-halo region of every tile's entry list is processed (the narrow
     // halos went through the fast kernel, bfgx_scatter2.hpp, which has stored the tile: addmode) and only the tiles that
@@ -1377,6 +1377,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
         continue;
     }
     // ---- flush: every pixel of the tile is stored exactly once (plain, row-contiguous stores)
+    float mcomp = 0.0f;                                // largest |component| stored (by-product for the regrid, K2)
     for (int rr = wid; rr < i1 - i0; rr += kWavesPerBlock) {
         const int ring = i0 + rr;
         int64_t st, n64; bool shf;
@@ -1386,8 +1387,14 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
         const int n = (ke - ks) * NCOMP;
         ACC *dst = out + NCOMP * (st + ks);
         const double *src = acc + NCOMP * rr * T.W;
-        if (addmode) { for (int x = lane; x < n; x += kWave) dst[x] = (ACC)((double)dst[x] + src[x]); }
-        else { for (int x = lane; x < n; x += kWave) dst[x] = (ACC)src[x]; }
+        if (addmode) { for (int x = lane; x < n; x += kWave) { const ACC v = (ACC)((double)dst[x] + src[x]); dst[x] = v; mcomp = fmaxf(mcomp, fabsf((float)v)); } }
+        else { for (int x = lane; x < n; x += kWave) { const ACC v = (ACC)src[x]; dst[x] = v; mcomp = fmaxf(mcomp, fabsf((float)v)); } }
+    }
+    if (MODE == MODE_OFFSETS && omax2 != nullptr) {
+        // largest |offset|^2 of the tile as float bits, bounded by 3 max|component|^2 (zeroed with the binning counters)
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) mcomp = fmaxf(mcomp, __shfl_down(mcomp, sft, kWave));
+        if (lane == 0 && mcomp > 0.0f) atomicMax(omax2 + tile, __float_as_uint(3.0f * mcomp * mcomp * 1.0001f));
     }
     __syncthreads();                                   // the LDS tile is reused by the next visit
     }
@@ -1440,6 +1447,7 @@ struct RegRow {
     double c0, s0;                        // cos / sin of the azimuth of the tile's first pixel (ks) in this ring
     int64_t start;
     int32_t nr, ks, ke, shf;              // nr == 0: no such ring
+    double lim2;                          // gathering regrid: a pixel of this ring is gathered iff |offset|^2 < lim2
 };
 
 // colatitude of a ring centre without libm (atan2 of the ring's sin/cos), for the tiled regrid

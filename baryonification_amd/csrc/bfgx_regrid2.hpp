@@ -109,20 +109,199 @@ __device__ inline void regrid_targets_generic(const Hpx &h, const RegRow *rows, 
 
 __device__ inline float abs_(float v) { return __builtin_fabsf(v); }
 __device__ inline double abs_(double v) { return __builtin_fabs(v); }
+// small-angle pieces of the displaced position, valid for |o| <= 0.02, |t| <= 0.1: fp32 by series (truncation below the
+// fp32 rounding), fp64 through the fp64 helpers (1e-16)
 template <typename real> struct RMath;
 template <> struct RMath<float> {
     static __device__ inline float rcp(float x) { const float y = __builtin_amdgcn_rcpf(x); return y * __builtin_fmaf(-x, y, 2.0f); }
+    // 1 / sqrt(1 + e) = 1 - e/2 + 3 e^2/8 - 5 e^3/16 + 35 e^4/128
+    static __device__ inline float inv_norm(float e) { return fma_(e, fma_(e, fma_(e, fma_(e, 0.2734375f, -0.3125f), 0.375f), -0.5f), 1.0f); }
+    // sqrt(1 + t^2) - 1 = t^2/2 - t^4/8 + t^6/16
+    static __device__ inline float sqrt1pm1(float t2) { return t2 * fma_(t2, fma_(t2, 0.0625f, -0.125f), 0.5f); }
+    static __device__ inline float asin_(float q) { const float q2 = q * q; return q * fma_(q2, fma_(q2, fma_(q2, (float)(15.0 / 336.0), 0.075f), (float)(1.0 / 6.0)), 1.0f); }
+    static __device__ inline float atan_(float t) { const float t2 = t * t; return t * fma_(t2, fma_(t2, fma_(t2, fma_(t2, (float)(1.0 / 9.0), (float)(-1.0 / 7.0)), 0.2f), (float)(-1.0 / 3.0)), 1.0f); }
 };
 template <> struct RMath<double> {
     static __device__ inline double rcp(double x) { return fast_rcp(x); }
+    static __device__ inline double inv_norm(double e) { return fast_rsq(1.0 + e); }
+    static __device__ inline double sqrt1pm1(double t2) { const double h = 1.0 + t2; return t2 * fast_rcp(1.0 + h * fast_rsq(h)); }
+    static __device__ inline double asin_(double q) { return asin_small(q); }
+    static __device__ inline double atan_(double t) { return atan_small(t); }
 };
 
-// The 4 targets of one displaced pixel by the fast route (see the header comment); returns false when the pixel needs the
-// generic route: next to a pole, a move of more than one ring, more than `maxcols` columns or 0.02 rad.  x = column of the
-// pixel relative to the tile's first pixel of its ring (negative / beyond the tile for apron pixels of the gathering kernel).
-template <typename real>
-__device__ inline bool regrid_near_targets(const RegRow *rows, const RegRowC<real> *rowc, int rth0, int ti, int x,
-                                           real o0, real o1, real o2, real maxcols, int tr[4], int tk[4], double w[4])
+// ---------------------------------------------------------------------------------- K2, gathering form (full-map regrid)
+// Every OUTPUT pixel is the property of one workgroup: a tile evaluates the displaced position of its own pixels AND of the
+// pixels in an apron around it, keeps only the deposits that land inside the tile (LDS), and stores the tile once with plain
+// stores -- no global atomics, no zero-fill (the scatter form ends in ~1.3 global fp64 atomics per map pixel, which is what
+// bounds it: the memory-side atomic rate).
+//
+// Which pixels are gathered is a property of the SOURCE pixel alone, decided by arithmetic every tile repeats bit for bit:
+//     gathered  <=>  |o|^2 < lim(ring)^2,   lim = min(cap, 0.09 sin(theta_ring), 0.999 x the distance to the first / last ring)
+// (cap = regrid_cap(nside), at most kReachMax rings); the move is then small enough for the small-angle formulas (|t| < 0.1,
+// |q| < 0.021) and never crosses a pole.  Everything else (huge displacements, the pixels next to a pole) is appended by the
+// tile that OWNS the source pixel to a global list which a small fix-up kernel adds to the stored map afterwards; if that
+// list overflows, a second pass over the owners (regrid_far_pass_kernel) applies those deposits with atomics instead.
+//
+// The apron of a tile follows the data: tile_reach_kernel leaves the largest |o| of every tile, a tile takes the maximum m
+// over the tiles around it and evaluates R = regrid_reach_rings(m) rings and K columns beyond its own pixels -- 1 ring and
+// 4 columns (1.2x the evaluations) for sub-pixel displacements, more only where the map really moves that far.
+constexpr int kReachMax = 16;       // most rings a gathered deposit travels; the ring tables hold BR + 2 kReachMax + 2 rings
+constexpr int kReachColsMax = 256;  // most apron columns per side
+
+__host__ __device__ inline double regrid_cap(int64_t nside)
+{
+    const double c = 9.9 / (double)nside;                // 9.9 / nside radians = 14.85 ring spacings at most (below)
+    return c < 0.02 ? c : 0.02;
+}
+// rings a displacement of m radians can cross: neighbouring rings are at least 2 / (3 nside) apart everywhere
+__host__ __device__ inline int regrid_reach_rings(int64_t nside, double m)
+{
+    const double r = m * 1.5 * (double)nside;
+    const int R = (r < (double)kReachMax ? (int)r : kReachMax) + 1;
+    return R > kReachMax ? kReachMax : R;
+}
+// the largest displacement a fixed apron of R rings serves (banded regrid: every rank uses the same R)
+__host__ __device__ inline double regrid_cap_for_rings(int64_t nside, int R)
+{
+    const double c = 0.999 * (double)R / (1.5 * (double)nside), cap = regrid_cap(nside);
+    return (R >= kReachMax || c > cap) ? cap : c;
+}
+
+struct FarList {
+    unsigned long long *count;    // entries appended (may exceed cap: overflow)
+    int64_t *pix;
+    double *val;
+    int64_t cap;
+    int32_t *overflow;
+};
+
+struct ReachArgs {
+    const int32_t *apron;         // [ntiles][2]: rings / columns of apron of every tile (tile_apron_kernel)
+    double cap;                   // no pixel with |o| >= cap is gathered
+    double theta_first, theta_last;   // colatitude of the first / last ring
+};
+
+__host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size)
+{
+    return (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + 8 * real_size) + 16;
+}
+
+// largest |o|^2 of the pixels of every tile (offsets that did not come from this plan's K1, which leaves it as a by-product)
+template <typename ACC>
+__global__ void __launch_bounds__(256)
+tile_reach_kernel(Hpx h, Tiling T, const ACC *__restrict__ offsets, float *__restrict__ tile_omax)
+{
+    __shared__ float red[256 / kWave];
+    const int tile = blockIdx.x;
+    const int band = T.tile_band[tile];
+    const int nphi = T.band_nphi[band];
+    const int tj = tile - T.band_tile0[band];
+    const int nl4 = (int)(4 * h.nside);
+    const int i0 = 1 + band * T.BR, i1 = min(i0 + T.BR, nl4);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    float m2 = 0.0f;
+    for (int ring = i0 + wid; ring < i1; ring += 256 / kWave) {
+        int64_t st, nr64; bool shf;
+        ring_info_small(h, ring, st, nr64, shf);
+        const int nr = (int)nr64, ks = tile_ks(tj, nr, nphi), ke = tile_ks(tj + 1, nr, nphi);
+        const ACC *o = offsets + 3 * (st + ks);
+        for (int x = lane; x < ke - ks; x += kWave) {
+            const float a = (float)o[3 * x], b = (float)o[3 * x + 1], c = (float)o[3 * x + 2];
+            m2 = fmaxf(m2, fma_(a, a, fma_(b, b, c * c)));
+        }
+    }
+#pragma unroll
+    for (int sft = kWave >> 1; sft > 0; sft >>= 1) m2 = fmaxf(m2, __shfl_down(m2, sft, kWave));
+    if (lane == 0) red[wid] = m2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; ++w) m2 = fmaxf(m2, red[w]);
+        tile_omax[tile] = m2;
+    }
+}
+
+// The apron of every tile: R rings and K columns beyond its own pixels, from the largest |o| among the tiles a gathered
+// deposit could come from (tile_omax; nullptr: the fixed reach `rings` of the banded regrid, with m = cap).  Tiles whose
+// reach exceeds one ring are listed in todo ([0] = count) for the kernel with the ring walk.  One thread per tile.
+__global__ void __launch_bounds__(256)
+tile_apron_kernel(Hpx h, Tiling T, const float *__restrict__ tile_omax, int rings, double cap, int tile0, int ntiles,
+                  int32_t *__restrict__ apron, int32_t *__restrict__ todo)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntiles) return;
+    const int tile = tile0 + i;
+    const int band = T.tile_band[tile];
+    const int nphi = T.band_nphi[band];
+    const int tj = tile - T.band_tile0[band];
+    const int nl4 = (int)(4 * h.nside);
+    float m = (float)cap;
+    int R = rings;
+    if (tile_omax != nullptr) {
+        m = 0.0f;
+        const int nb = (kReachMax + T.BR - 1) / T.BR;
+        for (int db = -nb; db <= nb; ++db) {
+            const int b2 = band + db;
+            if (b2 < 0 || b2 >= T.nbands) continue;
+            const int n2 = T.band_nphi[b2], t20 = T.band_tile0[b2];
+            // tiles of band b2 that overlap this tile's azimuth range, one more either side (all of them for narrow tiles)
+            int lo = (int)(((int64_t)tj * n2) / nphi) - 1, hi = (int)(((int64_t)(tj + 1) * n2 + nphi - 1) / nphi) + 1;
+            if (T.W < 32 || hi - lo >= n2) { lo = 0; hi = n2; }
+            for (int t2 = lo; t2 < hi; ++t2) {
+                const int u = t2 < 0 ? t2 + n2 : (t2 >= n2 ? t2 - n2 : t2);
+                m = fmaxf(m, tile_omax[t20 + u]);
+            }
+        }
+        m = fminf(__builtin_sqrtf(m) * 1.001f, (float)cap);             // (tile_omax holds |o|^2)
+        R = regrid_reach_rings(h.nside, (double)m);
+    }
+    // apron columns: a source pixel c columns outside the tile on its ring reaches it only if
+    // c <= 1.5 + (its move in columns of its own ring) + nr_source / nr_target.  The move in columns, lim / (sth - lim) nr / 2 pi,
+    // grows towards the ring where the polar cap meets the equatorial belt (ring nside / 3 nside) on either side of it, and
+    // the ring length grows towards the belt: the first and last ring of the window and those two rings cover the extremes.
+    const int i0 = 1 + band * T.BR, i1 = min(i0 + T.BR, nl4);
+    const int rlo = max(i0 - R, 1), rhi = min(i1 + R, nl4) - 1, ns = (int)h.nside;
+    int nmin = 0x7fffffff, nmax = 0;
+    float mc = 0.0f;
+    const int probe[4] = {rlo, rhi, ns, 3 * ns};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ring = probe[q];
+        if (ring < rlo || ring > rhi) continue;
+        double z, sth;
+        ring_z_sth(h, ring, z, sth);
+        const int nr = ring_len(h, ring);
+        nmin = min(nmin, nr); nmax = max(nmax, nr);
+        const float limf = fminf(m, (float)(0.09 * sth)), den = (float)sth - limf;
+        if (den > 0.0f) mc = fmaxf(mc, limf / den * 1.02f * (float)nr * (float)kInvTwoPi);
+    }
+    const float kk = mc + (float)nmax / (float)nmin + 2.5f;
+    apron[2 * tile] = R;
+    apron[2 * tile + 1] = (nphi == 1) ? 0 : (kk < (float)kReachColsMax ? (int)kk + 1 : kReachColsMax);
+    if (todo != nullptr && R > 1) todo[1 + atomicAdd(todo, 1)] = tile;
+}
+
+// largest |o|^2 of n pixels as the bits of a float (non-negative floats order like unsigned integers); *out zeroed by the caller
+template <typename ACC>
+__global__ void __launch_bounds__(256)
+max_offset_kernel(int64_t n, const ACC *__restrict__ offsets, unsigned *__restrict__ out)
+{
+    float m2 = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = (float)offsets[3 * i], b = (float)offsets[3 * i + 1], c = (float)offsets[3 * i + 2];
+        m2 = fmaxf(m2, fma_(a, a, fma_(b, b, c * c)));
+    }
+#pragma unroll
+    for (int sft = kWave >> 1; sft > 0; sft >>= 1) m2 = fmaxf(m2, __shfl_down(m2, sft, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, __float_as_uint(m2));
+}
+
+// One source pixel of the gathering regrid: the 4 targets of its displaced position, (ring index in the tile's ring tables,
+// column) + weight.  The pixel must be a gathered one (see above).  Returns false
+// when the move leaves the ring tables (then no target lies in the tile).  x = column of the pixel relative to the tile's
+// first pixel of its ring (negative / beyond the tile for apron pixels).
+template <typename real, bool WALK>
+__device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<real> *rowc, int NT, int ti, int x,
+                                             real o0, real o1, real o2, int tt[4], int tk[4], real w[4])
 {
     const RegRowC<real> rc = rowc[ti];
     const RegRow &rw = rows[ti];
@@ -144,126 +323,134 @@ __device__ inline bool regrid_near_targets(const RegRow *rows, const RegRowC<rea
     const real xr = rc.sth + a;
     const real t = b * RMath<real>::rcp(xr);
     const real t2 = t * t;
-    // |v + o|^2 = 1 + e;  1/|v + o| = 1 - e/2 + 3 e^2/8 - 5 e^3/16
-    const real e = (real)2 * (rc.sth * a + rc.z * o2) + (a * a + b * b + o2 * o2);
-    const real invn = fma_(e, fma_(e, fma_(e, (real)-0.3125, (real)0.375), (real)-0.5), (real)1);
-    // sqrt(1 + t^2) - 1 = t^2/2 - t^4/8 + t^6/16
-    const real sq1 = t2 * fma_(t2, fma_(t2, (real)0.0625, (real)-0.125), (real)0.5);
-    const real q = (fma_(a, rc.z, -(o2 * rc.sth)) + xr * rc.z * sq1) * invn;              // sin(theta_new - theta)
-    const real q2 = q * q;
-    const real dth = q * fma_(q2, fma_(q2, fma_(q2, (real)(15.0 / 336.0), (real)0.075), (real)(1.0 / 6.0)), (real)1);   // asin q
-    const real dph = t * fma_(t2, fma_(t2, fma_(t2, (real)(-1.0 / 7.0), (real)0.2), (real)(-1.0 / 3.0)), (real)1);      // atan t
-    // ring above / below and the colatitude weight
-    const bool down = dth >= (real)0;                       // theta_new in [theta_r, theta_{r+1})
+    const real e = (real)2 * (rc.sth * a + rc.z * o2) + (a * a + b * b + o2 * o2);       // |v + o|^2 = 1 + e
+    const real invn = RMath<real>::inv_norm(e);
+    const real q = (fma_(a, rc.z, -(o2 * rc.sth)) + xr * rc.z * RMath<real>::sqrt1pm1(t2)) * invn;      // sin(theta_new - theta)
+    const real dth = RMath<real>::asin_(q);
+    const real dph = RMath<real>::atan_(t);
+    // ring above (t1) / below (t1 + 1) the new colatitude and the weight of the lower one
+    const bool down = dth >= (real)0;
     const real wq = down ? dth * rc.inv_dth_dn : -dth * rc.inv_dth_up;      // fraction of the ring spacing moved
-    const real wo_all = dph * rc.inv_dphi;                  // displacement along the own ring in pixels
-    const bool fast = (xr > (real)0) && (abs_(t) <= (real)0.02) && (abs_(q) <= (real)0.02) && (wq < (real)1) && (abs_(wo_all) <= maxcols) &&
-                      (down ? rc.inv_dth_dn : rc.inv_dth_up) > (real)0;
-    if (!fast) return false;
-    const real wtheta = down ? wq : (real)1 - wq;           // weight of the lower ring (ir2)
-    // own ring: u = k + dphi / (2 pi / nr)
+    int t1 = ti;
+    real wtheta;
+    const bool near = wq < (real)1 && (down ? rc.inv_dth_dn : rc.inv_dth_up) > (real)0;
+    if (!WALK || near) {                                                    // (!WALK: the tile's reach is one ring, the move is shorter)
+        wtheta = down ? wq : (real)1 - wq;
+    } else {                                                                // more than one ring: walk the table
+        const double d = (double)dth, th0 = rw.theta;
+        if (down) { while (t1 + 2 < NT && d >= rows[t1 + 1].theta - th0) ++t1; }
+        else      { while (t1 > 0 && d < rows[t1].theta - th0) --t1; }
+        const double lo = rows[t1].theta - th0, hi = rows[t1 + 1].theta - th0;
+        if (!(d >= lo && d < hi) || rows[t1].nr == 0 || rows[t1 + 1].nr == 0) return false;
+        wtheta = (real)((d - lo) * fast_rcp(hi - lo));
+    }
     const int nro = rw.nr;
     int kown = rw.ks + x;
     if (kown < 0) kown += nro;
     if (kown >= nro) kown -= nro;
-    const real fo = __builtin_floor(wo_all);
-    const real wo = wo_all - fo;
-    int jo = kown + (int)fo;
-    // neighbouring ring (r + 1 if down else r - 1): u' = (k + sh) nr' / nr - sh' + dphi / (2 pi / nr'), the first two terms
-    // as an exact rational evaluated in fp64 (never an integer for rings of different length or shift)
-    const RegRow &rn = rows[down ? ti + 1 : ti - 1];
-    const real inv_dphi_n = rowc[down ? ti + 1 : ti - 1].inv_dphi;
-    const double B = ((double)kown + (rw.shf ? 0.5 : 0.0)) * ((double)rn.nr * rw.dphi * kInvTwoPi) - (rn.shf ? 0.5 : 0.0);
-    const double Bf = floor(B);
-    const real wn_all = (real)(B - Bf) + dph * inv_dphi_n;
-    const real fn = __builtin_floor(wn_all);
-    const real wn = wn_all - fn;
-    int jn = (int)Bf + (int)fn;
-    const int nrn = rn.nr;
-    int jo2 = jo + 1, jn2 = jn + 1;
-    jo = jo < 0 ? jo + nro : (jo >= nro ? jo - nro : jo);
-    jo2 = jo2 < 0 ? jo2 + nro : (jo2 >= nro ? jo2 - nro : jo2);
-    jn = jn < 0 ? jn + nrn : (jn >= nrn ? jn - nrn : jn);
-    jn2 = jn2 < 0 ? jn2 + nrn : (jn2 >= nrn ? jn2 - nrn : jn2);
-    const int ring_o = rth0 + ti, ring_n = down ? ring_o + 1 : ring_o - 1;
-    // get_interpol order: upper ring (ir1) first
-    const real w_own = down ? (real)1 - wtheta : wtheta, w_nb = (real)1 - w_own;
-    tr[0] = down ? ring_o : ring_n; tr[1] = tr[0]; tr[2] = down ? ring_n : ring_o; tr[3] = tr[2];
-    const int ju = down ? jo : jn, ju2 = down ? jo2 : jn2, jl = down ? jn : jo, jl2 = down ? jn2 : jo2;
-    const real wu = down ? wo : wn, wl = down ? wn : wo;
-    const real wtu = down ? w_own : w_nb, wtl = down ? w_nb : w_own;
-    tk[0] = ju; tk[1] = ju2; tk[2] = jl; tk[3] = jl2;
-    w[0] = (double)(((real)1 - wu) * wtu); w[1] = (double)(wu * wtu);
-    w[2] = (double)(((real)1 - wl) * wtl); w[3] = (double)(wl * wtl);
+    // columns on two rings X and Y.  Usual case (the move stays within one ring spacing): X = the pixel's own ring, where
+    // u = k + dphi / (2 pi / nr), Y = the ring above or below.  After a walk: X = t1, Y = t1 + 1.  On a ring other than
+    // the pixel's own  u' = (k + sh) nr' / nr - sh' + dphi / (2 pi / nr'), the first two terms as an exact rational
+    // evaluated in fp64 (never an integer for rings of different length or shift).
+    auto other_ring = [&](int tr, int &j, real &wj) {
+        const RegRow &rn = rows[tr];
+        const double B = ((double)kown + (rw.shf ? 0.5 : 0.0)) * ((double)rn.nr * rw.dphi * kInvTwoPi) - (rn.shf ? 0.5 : 0.0);
+        const double Bf = floor(B);
+        const real wall = (real)(B - Bf) + dph * rowc[tr].inv_dphi, f = __builtin_floor(wall);
+        wj = wall - f; j = (int)Bf + (int)f;
+    };
+    const bool nr_ = !WALK || near;
+    const bool x_upper = !nr_ || down;                   // X is the upper ring of the pair
+    const int tx = nr_ ? ti : t1, ty = nr_ ? (down ? ti + 1 : ti - 1) : t1 + 1;
+    int jx, jy; real wx, wy;
+    if (nr_) {
+        const real wall = dph * rc.inv_dphi, f = __builtin_floor(wall);
+        wx = wall - f; jx = kown + (int)f;
+    } else {
+        other_ring(tx, jx, wx);
+    }
+    other_ring(ty, jy, wy);
+    const int nrx = rows[tx].nr, nry = rows[ty].nr;
+    int jx2 = jx + 1, jy2 = jy + 1;
+    jx = jx < 0 ? jx + nrx : (jx >= nrx ? jx - nrx : jx);
+    jx2 = jx2 < 0 ? jx2 + nrx : (jx2 >= nrx ? jx2 - nrx : jx2);
+    jy = jy < 0 ? jy + nry : (jy >= nry ? jy - nry : jy);
+    jy2 = jy2 < 0 ? jy2 + nry : (jy2 >= nry ? jy2 - nry : jy2);
+    // wtheta = weight of the lower ring of the pair (the order of the 4 deposits does not matter)
+    const real wtx = x_upper ? (real)1 - wtheta : wtheta, wty = (real)1 - wtx;
+    tt[0] = tx; tt[1] = tx; tk[0] = jx; tk[1] = jx2;
+    w[0] = ((real)1 - wx) * wtx; w[1] = wx * wtx;
+    tt[2] = ty; tt[3] = ty; tk[2] = jy; tk[3] = jy2;
+    w[2] = ((real)1 - wy) * wty; w[3] = wy * wty;
     return true;
 }
 
-// ---------------------------------------------------------------------------------- K2, gathering form (full-map regrid)
-// The scatter form above ends in ~1.3 global fp64 atomics per map pixel (tile + apron), which is what bounds it (the
-// memory-side atomic rate), and it needs a zeroed output.  The gathering form makes every OUTPUT pixel the property of one
-// workgroup: a tile evaluates the displaced position of its own pixels AND of the pixels in a thin apron around it
-// (kGatherR rings, kGatherK columns: 1.3x the evaluations), keeps only the deposits that land inside the tile (LDS), and
-// stores the tile once with plain stores -- no global atomics, no zero-fill.  A deposit is "near" when the fast route
-// applies with a move of at most 3 columns, a property of the source pixel alone, so every tile that sees the pixel
-// classifies it the same way; anything else (pole caps, very large displacements) is appended by the tile that OWNS the
-// source pixel to a global list that a small fix-up kernel adds to the stored map afterwards.
-constexpr int kGatherR = 1;       // apron rings above / below the tile (near deposits go to the own ring or the next one)
-constexpr int kGatherK = 7;       // apron columns left / right of the tile (3 columns of move + 1 + 2 of ring-to-ring column mapping + 1)
-
-struct FarList {
-    unsigned long long *count;    // entries appended (may exceed cap: overflow)
-    int64_t *pix;
-    double *val;
-    int64_t cap;
-    int32_t *overflow;
-};
-
-__host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size)
-{
-    return (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kGatherR + 2) * (sizeof(RegRow) + 8 * real_size);
-}
-
-template <typename ACC, typename real>
-__global__ void __launch_bounds__(256)
+// PASS 0: the gathering regrid of the tiles whose reach is ONE ring (no deposit travels further than the next ring: the
+// lean code, 4 waves / SIMD); tiles with a longer reach are appended to `todo` and left to PASS 2, the same kernel with the
+// ring walk compiled in, which a small persistent grid runs over that list (or over all tiles: banded regrid with a fixed
+// reach > 1).  PASS 1: the fall-back for an overflowing far list (every owner applies the deposits of its far pixels with
+// global atomics; runs after the map has been stored, does nothing unless the list overflowed).
+template <typename ACC, typename real, int PASS>
+__global__ void __launch_bounds__(256, 4)
 tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
-                    double *__restrict__ map_out, FarList far, double *__restrict__ tile_sums, int tile_off)
+                    double *__restrict__ map_out, FarList far, ReachArgs reach, double *__restrict__ tile_sums, int tile_off, int ntiles,
+                    int *__restrict__ todo)
 {
     // map_in, offsets and map_out are indexed by GLOBAL pixel number.  tile_off < 0: all tiles, heavy ones first; tile_off >= 0
     // (a rank that owns a range of bands): tiles tile_off + blockIdx.x, and the caller passes offsets / map_out pointers
-    // shifted so that only the pixels this rank holds (its bands + one ring either side / its bands) are touched.
+    // shifted so that only the pixels this rank holds (its bands + reach.rings rings either side / its bands) are touched.
     extern __shared__ __align__(16) unsigned char smem[];
-    const int NT = T.BR + 2 * kGatherR + 2;                    // rings rth0 .. rth0 + NT - 1 in the ring tables
+    const int NTmax = T.BR + 2 * kReachMax + 2;
     double *acc = reinterpret_cast<double *>(smem);            // [BR][W]: the tile's own pixels
     RegRow *rows = reinterpret_cast<RegRow *>(acc + T.BR * T.W);
-    RegRowC<real> *rowc = reinterpret_cast<RegRowC<real> *>(rows + NT);
-    const int tile = (tile_off < 0) ? T.tile_order[blockIdx.x] : tile_off + (int)blockIdx.x;
+    RegRowC<real> *rowc = reinterpret_cast<RegRowC<real> *>(rows + NTmax);
+    const int tid = threadIdx.x;
+    const int nl4 = (int)(4 * h.nside);
+    if (PASS == 1 && *far.overflow == 0) {                    // the usual case: add the listed far deposits to the stored map
+        const unsigned long long n = *far.count;
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + tid; i < n; i += (unsigned long long)gridDim.x * 256)
+            atomicAdd(map_out + far.pix[i], far.val[i]);
+        return;
+    }
+    const bool listed = (PASS == 2) && todo != nullptr;
+    if (listed) ntiles = todo[0];
+    for (int blk = blockIdx.x; blk < ntiles; blk += (PASS == 0 ? ntiles : (int)gridDim.x)) {      // (PASS 0: one tile per workgroup)
+    const int tile = listed ? todo[1 + blk] : ((tile_off < 0) ? T.tile_order[blk] : tile_off + blk);
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];
-    const int nl4 = (int)(4 * h.nside);
     const int i0 = 1 + band * T.BR;
     const int i1 = min(i0 + T.BR, nl4);                        // exclusive
-    const int tid = threadIdx.x;
-    const int rth0 = i0 - kGatherR - 1;
     double sum_in = 0.0, sum_out = 0.0;                        // mass-conservation sums (HealpixRunner.py:344-345)
+    __syncthreads();                                           // the previous tile of this workgroup is done with the tables
+
+    // ---- reach of this tile (tile_apron_kernel): R rings, K columns
+    const int R = (PASS == 2) ? reach.apron[2 * tile] : 1;     // (a compile-time constant in the lean kernel)
+    const int kap = (PASS == 1 || nphi == 1) ? 0 : reach.apron[2 * tile + 1];
+    if (PASS == 0 && reach.apron[2 * tile] > 1) continue;      // (block-uniform) left to the kernel with the ring walk
     for (int i = tid; i < T.BR * T.W; i += 256) acc[i] = 0.0;
+    const int NT = T.BR + 2 * R + 2;                           // rings rth0 .. rth0 + NT - 1 in the ring tables
+    const int rth0 = i0 - R - 1;
     if (tid < NT) {
         const int ring = rth0 + tid;
         RegRow rw;
         rw.theta = (ring < 1) ? -1.0e300 : 1.0e300;
         rw.z = rw.sth = rw.dphi = rw.inv_dphi = rw.c0 = rw.s0 = 0.0;
-        rw.start = 0; rw.nr = 0; rw.ks = 0; rw.ke = 0; rw.shf = 0;
+        rw.start = 0; rw.nr = 0; rw.ks = 0; rw.ke = 0; rw.shf = 0; rw.lim2 = 0.0;
         if (ring >= 1 && ring <= nl4 - 1) {
-            int64_t st, nr64; bool shf;
-            ring_info_small(h, ring, st, nr64, shf);
+            int64_t st, nr64; bool shf_;
+            ring_info_small(h, ring, st, nr64, shf_);
             ring_z_sth(h, ring, rw.z, rw.sth);
             rw.theta = atan2_generic(rw.sth, rw.z);
-            rw.start = st; rw.nr = (int)nr64; rw.shf = shf ? 1 : 0;
+            rw.start = st; rw.nr = (int)nr64; rw.shf = shf_ ? 1 : 0;
             rw.dphi = kTwoPi / (double)rw.nr;
             rw.inv_dphi = (double)rw.nr * kInvTwoPi;
             rw.ks = tile_ks(tj, rw.nr, nphi);
             rw.ke = tile_ks(tj + 1, rw.nr, nphi);
-            sincos_bounded(((double)rw.ks + (shf ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
+            sincos_bounded(((double)rw.ks + (shf_ ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
+            // gathered <=> |o|^2 < lim2
+            const double lim = fmin(fmin(reach.cap, 0.09 * rw.sth), 0.999 * fmin(rw.theta - reach.theta_first, reach.theta_last - rw.theta));
+            rw.lim2 = (lim > 0.0 && ring > 1 && ring < nl4 - 1) ? lim * lim : 0.0;
         }
         rows[tid] = rw;
     }
@@ -281,17 +468,19 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         rowc[tid] = rc;
     }
     __syncthreads();
-
     auto far_add = [&](int64_t p, double v) {
-        const unsigned long long i = atomicAdd(far.count, 1ull);
-        if ((int64_t)i < far.cap) { far.pix[i] = p; far.val[i] = v; } else atomicOr(far.overflow, 1);
-        sum_out += v;
+        if (PASS != 1) {
+            const unsigned long long i = atomicAdd(far.count, 1ull);
+            if ((int64_t)i < far.cap) { far.pix[i] = p; far.val[i] = v; } else atomicOr(far.overflow, 1);
+            sum_out += v;
+        } else {
+            atomicAdd(map_out + p, v);
+        }
     };
 
-    // source pixels: the tile's rings +- kGatherR, its columns +- kGatherK (a tile that spans whole rings has no column apron)
+    // source pixels: the tile's rings +- R, its columns +- K (a tile that spans whole rings has no column apron)
     // (in a short ring the apron is what is left of the ring, split between the two sides, so that no pixel is visited twice)
-    const int NR = T.BR + 2 * kGatherR;
-    const int kap = (nphi == 1) ? 0 : kGatherK;
+    const int NR = T.BR + 2 * R;
     int maxspan = 0;
     for (int i = 1; i <= NR; ++i) maxspan = max(maxspan, rows[i].ke - rows[i].ks);
     const int LWs = maxspan + 2 * kap;
@@ -310,10 +499,12 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 if (k < 0) k += rw.nr;
                 if (k >= rw.nr) k -= rw.nr;
                 const int64_t p = rw.start + k;
-                sx.ok = true; sx.ti = r + 1; sx.x = x;
-                sx.own = (r >= kGatherR) && (r < kGatherR + (i1 - i0)) && (x >= 0) && (x < rw.ke - rw.ks);
-                sx.val = map_in[p];
-                sx.o0 = offsets[3 * p + 0]; sx.o1 = offsets[3 * p + 1]; sx.o2 = offsets[3 * p + 2];
+                sx.own = (r >= R) && (r < R + (i1 - i0)) && (x >= 0) && (x < span);
+                if (PASS != 1 || sx.own) {
+                    sx.ok = true; sx.ti = r + 1; sx.x = x;
+                    sx.val = map_in[p];
+                    sx.o0 = offsets[3 * p + 0]; sx.o1 = offsets[3 * p + 1]; sx.o2 = offsets[3 * p + 2];
+                }
             }
         }
         return sx;
@@ -325,22 +516,28 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         if (cur.ok && cur.own) sum_in += cur.val;
         if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
         const double val = cur.val;
-        int tr[4], tk[4];
-        double w[4];
-        if (regrid_near_targets<real>(rows, rowc, rth0, cur.ti, cur.x, (real)cur.o0, (real)cur.o1, (real)cur.o2, (real)3, tr, tk, w)) {
+        const real o0 = (real)cur.o0, o1 = (real)cur.o1, o2 = (real)cur.o2;
+        const bool gathered = (double)fma_(o0, o0, fma_(o1, o1, o2 * o2)) < rows[cur.ti].lim2;
+        if (gathered) {
+            if (PASS == 1) continue;
+            int tt[4], tk[4];
+            real w[4];
+            if (!regrid_gather_targets<real, PASS == 2>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) continue;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
-                const int tt = tr[q4] - rth0;
-                if (tr[q4] >= i0 && tr[q4] < i1) {
-                    const RegRow &rt = rows[tt];
+                const int rr = tt[q4] - (R + 1);
+                if (rr >= 0 && rr < i1 - i0) {
+                    const RegRow &rt = rows[tt[q4]];
                     if (tk[q4] >= rt.ks && tk[q4] < rt.ke) {
-                        const double v = w[q4] * val;
-                        atomicAdd(acc + (tr[q4] - i0) * T.W + (tk[q4] - rt.ks), v);
+                        const double v = (double)w[q4] * val;
+                        atomicAdd(acc + rr * T.W + (tk[q4] - rt.ks), v);
                         sum_out += v;
                     }
                 }
             }
         } else if (cur.own) {                                                // rare: the owner of the source pixel lists its deposits
+            int tr[4], tk[4];
+            double w[4];
             regrid_targets_generic(h, rows, NT - 2, rth0, cur.ti, cur.x, (double)cur.o0, (double)cur.o1, (double)cur.o2, tr, tk, w);
             for (int q4 = 0; q4 < 4; ++q4) {
                 int64_t st_t, nr64; bool sh_t;
@@ -349,12 +546,13 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             }
         }
     }
+    if (PASS == 1) continue;
     __syncthreads();
 
     // flush: every pixel of the tile is stored exactly once
     const int lane = tid & (kWave - 1), wid = tid / kWave;
     for (int rr = wid; rr < i1 - i0; rr += 256 / kWave) {
-        const RegRow &rt = rows[rr + kGatherR + 1];
+        const RegRow &rt = rows[rr + R + 1];
         double *dst = map_out + rt.start + rt.ks;
         const int n = rt.ke - rt.ks;
         for (int xx = lane; xx < n; xx += kWave) dst[xx] = acc[rr * T.W + xx];
@@ -371,16 +569,8 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             tile_sums[2 * (int64_t)tile] = sa_; tile_sums[2 * (int64_t)tile + 1] = sb_;
         }
     }
-}
-
-// adds the listed far deposits to the stored map
-__global__ void __launch_bounds__(256)
-regrid_far_kernel(FarList far, double *__restrict__ map_out)
-{
-    unsigned long long n = *far.count;
-    if ((int64_t)n > far.cap) n = (unsigned long long)far.cap;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(map_out + far.pix[i], far.val[i]);
+    __syncthreads();
+    }
 }
 
 // banded regrid: adds the listed deposits whose pixel lies in [p0, p1) to the slice that starts at pixel p0, counts the others

@@ -255,7 +255,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                      const int32_t *__restrict__ entries, int64_t capacity,
-                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter)
+                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
+                     unsigned int *__restrict__ omax2)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
@@ -513,6 +514,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         continue;
     }
     // ---- flush: every pixel of the tile is stored exactly once (plain, row-contiguous stores of [pixel][component])
+    float om2 = 0.0f;
     for (int rr = wid; rr < i1 - i0; rr += kW2) {
         const int ring = i0 + rr;
         int64_t st, n64; bool shf;
@@ -522,11 +524,27 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         ACC *dst = out + NCOMP * (st + tr.ks);
         const double *src = acc + (rr << wsh);
         const int rot = ((rr & 7) << wsh) >> 3;
-        for (int x = lane; x < n; x += kWave) {
-            const int px = (NCOMP == 3) ? (int)(((unsigned)x * 43691u) >> 17) : x;      // x / 3 for x < 2^15
-            const int cc = x - px * NCOMP;
-            dst[x] = (ACC)src[cc * PL + ((px + rot) & wmask)];
+        if (NCOMP == 3) {
+            // one pixel per lane: three conflict-free LDS reads, one 3-component store (contiguous across the wave), and the
+            // largest |offset|^2 of the tile as a by-product for the regrid (K2)
+            struct alignas(sizeof(ACC)) Px { ACC c[3]; };
+            Px *dpx = reinterpret_cast<Px *>(dst);
+            for (int px = lane; px < tr.ke - tr.ks; px += kWave) {
+                const int ix = (px + rot) & wmask;
+                Px v;
+                v.c[0] = (ACC)src[ix]; v.c[1] = (ACC)src[PL + ix]; v.c[2] = (ACC)src[2 * PL + ix];
+                dpx[px] = v;
+                const float a = (float)v.c[0], b = (float)v.c[1], c = (float)v.c[2];
+                om2 = fmaxf(om2, fma_(a, a, fma_(b, b, c * c)));
+            }
+        } else {
+            for (int x = lane; x < n; x += kWave) dst[x] = (ACC)src[(x + rot) & wmask];
         }
+    }
+    if (MODE == MODE_OFFSETS && omax2 != nullptr) {      // (the array was zeroed with the binning counters; the wide pass may raise it)
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) om2 = fmaxf(om2, __shfl_down(om2, sft, kWave));
+        if (lane == 0 && om2 > 0.0f) atomicMax(omax2 + tile, __float_as_uint(om2 * 1.000001f));
     }
     __syncthreads();                                   // the LDS tile is reused by the next tile
     }

@@ -45,6 +45,11 @@ class ShellPlan(object):
                                                  int(acc_f64), C.c_void_p(int(map_out_ptr)),
                                                  C.c_void_p(int(sums_ptr) or None)))
 
+    def baryonify(self, cat_dev, map_in_ptr, offsets_work_ptr, map_out_ptr, sums_ptr=0, acc_f64=False):
+        """K0 + K1 + K2 in one enqueue-only call (HealpixRunner.py:291-346 on device buffers); offsets_work: [npix][3] scratch"""
+        _lib.check(_lib.load().bfgx_baryonify_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_work_ptr)),
+                                                    int(acc_f64), C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None)))
+
     def bands(self):
         """first RING pixel of every band of rings the tiling uses (+ npix): the unit of multi-GPU pixel ownership"""
         nb = C.c_int32(0)
@@ -53,8 +58,19 @@ class ShellPlan(object):
         _lib.check(_lib.load().bfgx_plan_bands(self._h, C.byref(nb), first.ctypes.data))
         return first
 
+    def reach_rings(self, max_offset):
+        """rings of apron the banded regrid needs for summed pix_offsets whose largest |offset| is `max_offset` [rad]"""
+        r = C.c_int32(0)
+        _lib.check(_lib.load().bfgx_plan_reach_rings(self._h, float(max_offset), C.byref(r)))
+        return int(r.value)
+
+    def set_band_reach(self, rings):
+        """every rank of a banded regrid must use the same apron (default 1 ring): see reach_rings"""
+        _lib.check(_lib.load().bfgx_plan_set_band_reach(self._h, int(rings)))
+
     def band_apron(self, band0, band1):
-        """pixel range [olo, ohi) of summed pix_offsets the owner of bands [band0, band1) needs: its pixels + one ring either side"""
+        """pixel range [olo, ohi) of summed pix_offsets the owner of bands [band0, band1) needs: its pixels + the band
+        reach (set_band_reach) in rings either side"""
         lo, hi = C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.load().bfgx_plan_band_apron(self._h, int(band0), int(band1), C.byref(lo), C.byref(hi)))
         return int(lo.value), int(hi.value)

@@ -216,6 +216,18 @@ def _hip_bounds(runner, plan, world):
     return cuts, first[cuts], needs
 
 
+def _hip_reach(runner, plan, my_off):
+    """collective: the rings of apron the gathering regrid needs follow the largest |offset| of the SUMMED pix_offsets over
+    all ranks; every rank sets the same value on its plan"""
+    import torch
+    import torch.distributed as dist
+    m2 = my_off.view(-1, 3).float().square().sum(1).max().reshape(1) if my_off.numel() else my_off.new_zeros(1, dtype=torch.float32)
+    if dist.get_backend() == 'gloo' and m2.is_cuda:
+        m2 = m2.cpu()
+    dist.all_reduce(m2, op=dist.ReduceOp.MAX)
+    plan.set_band_reach(plan.reach_rings(float(m2.item()) ** 0.5))
+
+
 def _hip_regrid_slice(runner, plan, off_apron, olo, ohi, b0, b1, p0, p1, device):
     """K2 for the output pixels [p0, p1) of the bands [b0, b1) this rank owns; returns (slice tensor, far pixels, far values,
     [sum of the rank's source pixels, sum of its deposits])"""
@@ -230,7 +242,7 @@ def _hip_regrid_slice(runner, plan, off_apron, olo, ohi, b0, b1, p0, p1, device)
 
 
 def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid=None, exchange='slices', bounds=None,
-                        regrid_slice=None, result='root'):
+                        regrid_slice=None, result='root', reach=None):
     """Run `runner` (holding the FULL catalog on every rank) halo-sharded over the ranks of the default
     torch.distributed group.  Returns the final map on rank 0 (`result='root'`; None elsewhere) or on every rank
     (`result='all'`, exchange='slices').
@@ -238,7 +250,8 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
     compute(runner, kind, cat_cols, device) -> (tensor accumulator, ctx); exchange='reduce': regrid(runner, ctx, acc,
     device) -> ndarray on rank 0; exchange='slices': bounds(runner, ctx, world) -> (band cuts, pixel bounds, needs) and
     regrid_slice(runner, ctx, offsets_with_apron, olo, ohi, b0, b1, p0, p1, device) -> (slice tensor, far pixels, far
-    values, sums).  All default to the HIP engine."""
+    values, sums); reach(runner, ctx, my_summed_offsets) (collective) fixes the apron before `bounds` is asked for the
+    ranges to exchange.  All default to the HIP engine."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -275,6 +288,16 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
         full = gather_slices(mine_sum, pb, npix, result)
         return None if full is None else full.cpu().numpy().astype(np.float64)
     my_off = sliced_reduce(acc, pb, 3)
+    if reach is None and bounds is None:
+        reach = _hip_reach
+    if reach is not None:
+        err = None
+        try:
+            reach(runner, ctx, my_off)
+        except Exception as e:        # noqa: BLE001
+            err = e
+        _agree(err, my_off.device)
+        cuts, pb, needs = (bounds or _hip_bounds)(runner, ctx, world)          # the apron ranges follow the reach
     off_apron = halo_exchange(my_off, pb, needs, 3)
     err, sl, fpix, fval, sums = None, None, np.zeros(0, dtype=np.int64), np.zeros(0), np.zeros(2)
     try:

@@ -345,7 +345,7 @@ def main():
     d_fin = torch.zeros(npix if ((world > 1 or force_x) and rank == 0) else 0, dtype=torch.float64, device=dev)
     d_foreign = torch.zeros(1, dtype=torch.int64, device=dev)          # far deposits that belong to another rank's slice
     if slices:
-        from baryonification_amd.utils.Parallelize import band_partition, gather_slices, halo_exchange, sliced_reduce
+        from baryonification_amd.utils.Parallelize import _hip_reach, band_partition, gather_slices, halo_exchange, sliced_reduce
         first = plan.bands()
         cuts = band_partition(first, world)
         pb = first[cuts]
@@ -374,9 +374,17 @@ def main():
                 return step_paint()
             if args.algo == 0:
                 d_off.zero_()                      # algo 1 stores every element of pix_offsets exactly once
+                d_out.zero_()
+            if world == 1 and not slices:
+                # K0 + K1 + K2 in one call (bfgx_baryonify_device): K1's flush hands K2 the largest displacement of every tile
+                plan.baryonify(cat_dev, d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
+                return
             plan.offsets(cat_dev, d_off.data_ptr(), acc_f64=acc_f64)
             if slices:
                 my_off = sliced_reduce(d_off, pb, 3, recv=x_recv)
+                if dist.is_initialized():
+                    _hip_reach(None, plan, my_off)         # collective: rings of apron from the largest summed |offset|
+                needs = [plan.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
                 off_apron = halo_exchange(my_off, pb, needs, 3)
                 plan.regrid_bands(int(cuts[rank]), int(cuts[rank + 1]), d_map.data_ptr(), off_apron.data_ptr(), needs[rank][0], needs[rank][1],
                                   d_slice.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)

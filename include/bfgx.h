@@ -178,18 +178,30 @@ int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offset
  * sums_dev (optional, double[2]) receives {sum(map_in), sum(map_out)} */
 int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
                         double *map_out_dev, double *sums_dev);
+/* K0 + K1 + K2 in one enqueue-only call (BaryonifyShell.process() on device buffers): offsets_work_dev[npix][3] is the
+ * pix_offsets scratch (f32 or f64, every element overwritten), the other arguments as above.  Same results as
+ * bfgx_offsets_device followed by bfgx_regrid_device; K1 hands the regrid the largest displacement of every tile, which
+ * the separate calls have to find with one more pass over pix_offsets. */
+int  bfgx_baryonify_device(bfgx_plan *p, const bfgx_catalog *cat_dev, const double *map_in_dev, void *offsets_work_dev,
+                           int acc_f64, double *map_out_dev, double *sums_dev);
 /* Multi-GPU form of K2: the sphere is cut into bands of consecutive rings (contiguous RING pixel ranges); a rank that
  * owns bands [band0, band1) produces exactly THEIR output pixels.  bfgx_plan_bands returns the number of bands and, in
  * band_first_pixel[nbands + 1] (may be NULL), the first pixel of every band (+ npix).  The gathering regrid evaluates
- * the displaced position of the rank's own pixels and of one ring either side: bfgx_plan_band_apron returns that pixel
- * range [olo, ohi) -- the summed pix_offsets the rank must hold (offsets_dev points at pixel olo, [ohi - olo][3]).
+ * the displaced position of the rank's own pixels and of `rings` rings either side, where `rings` follows the largest
+ * displacement of the SUMMED pix_offsets over all ranks: bfgx_plan_reach_rings(max |offset| in radians) -> rings (1 for
+ * sub-pixel displacements, at most 16), bfgx_plan_set_band_reach(rings) -- every rank must set the same value (default
+ * 1).  bfgx_plan_band_apron then returns the pixel range [olo, ohi) of summed pix_offsets the rank must hold
+ * (offsets_dev points at pixel olo, [ohi - olo][3]; a wider range is accepted).
  * out_slice_dev points at the rank's first own pixel ([p1 - p0] values, every one stored exactly once, no zero-fill);
  * map_in_dev is the full map; sums_dev (optional, double[2]) receives {sum of the rank's source pixels, sum of its
- * deposits, the listed far ones included}.  Deposits that need the generic route (pole caps, displacements of more than 3 pixel columns / one ring)
- * are NOT applied by this call: they are listed with global pixel numbers; bfgx_plan_far_fetch copies the list of the
- * last regrid to the host (blocking; n_host = 0 almost always; NULL buffers: count only) so that the caller can add
- * them to whichever rank's slice holds the pixel.  (bfgx_regrid_device applies its own list.) */
+ * deposits, the listed far ones included}.  Deposits that need the generic route (pixels next to a pole, displacements
+ * beyond what `rings` rings of apron serve) are NOT applied by this call: they are listed with global pixel numbers;
+ * bfgx_plan_far_fetch copies the list of the last regrid to the host (blocking; n_host = 0 almost always; NULL
+ * buffers: count only) so that the caller can add them to whichever rank's slice holds the pixel.  (bfgx_regrid_device
+ * sizes its aprons tile by tile from the data, applies its own list, and repairs an overflowing list in-stream.) */
 int  bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel);
+int  bfgx_plan_reach_rings(bfgx_plan *p, double max_offset, int32_t *rings);
+int  bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings);
 int  bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *olo, int64_t *ohi);
 int  bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev,
                               const void *offsets_dev, int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev);

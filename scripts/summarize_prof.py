@@ -14,7 +14,7 @@ def short(name):
     tags = (('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
             ('halo_prep_kernel', 'halo_prep'), ('halo_scatter_kernel', 'halo_scatter'), ('regrid_far_kernel', 'regrid_far'),
             ('regrid_kernel', 'regrid(algo0)'), ('sum2_kernel', 'sum2'), ('sum_tiles_kernel', 'sum_tiles'), ('tile_scan_kernel', 'tile_scan'),
-            ('tile_place_kernel', 'tile_place'))
+            ('tile_place_kernel', 'tile_place'), ('tile_reach_kernel', 'tile_reach'), ('tile_apron_kernel', 'tile_apron'))
     for k, t in tags:
         if k in name:
             mode = ''
@@ -23,7 +23,13 @@ def short(name):
                     mode = '<' + v + (',f64' if 'double' in name else ',f32') + '>'
                     break
             if not mode and 'regrid3' in k:
-                mode = '<f64>' if 'regrid3_kernel<double' in name else '<f32>'
+                # <ACC, real, PASS>: 0 = lean gather (reach of one ring), 2 = gather with the ring walk, 1 = repair of an overflowing far list
+                ps = {'0': 'lean', '1': 'repair', '2': 'walk'}
+                mode = '<f64' if 'regrid3_kernel<double' in name else '<f32'
+                for d in '012':
+                    if (', %s>(' % d) in name or (', (int)%s>(' % d) in name:
+                        mode += ',' + ps[d]
+                mode += '>'
             elif not mode and 'scatter' in k:
                 mode = '<f64>' if 'double' in name else '<f32>'
             return t + mode
@@ -31,7 +37,7 @@ def short(name):
 
 
 print("== kernel trace stats ==")
-for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
+for f in glob.glob(os.path.join(out, 'trace*', '**', '*kernel_stats.csv'), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             print("%-40s calls %6s  avg %12.1f ns  total %14s ns  %6s %%" % (

@@ -181,8 +181,134 @@ def test_banded_regrid_equals_full_regrid(gpu):
         assert (acc - full).abs().max().item() <= 1e-12 * full.abs().max().item()
     # an offsets range that does not reach one ring beyond the bands is refused
     p0, p1 = int(pb[1]), int(pb[2])
-    with pytest.raises(ValueError, match='one ring'):
+    with pytest.raises(ValueError, match=r'1 ring\(s\) either side'):
         plan.regrid_bands(int(cuts[1]), int(cuts[2]), hmap.data_ptr(), off[3 * p0:3 * p1].clone().data_ptr(), p0, p1, acc[p0:p1].data_ptr())
+    plan.close()
+
+
+def _random_offsets(nside, scale_pix, seed):
+    """a displacement field with |offset| from 0 to `scale_pix` pixel sizes: smooth large-scale part + per-pixel scatter"""
+    rng = np.random.default_rng(seed)
+    npix = 12 * nside * nside
+    pix = np.sqrt(4 * np.pi / npix)
+    mag = scale_pix * pix * rng.random(npix) ** 2
+    d = rng.normal(size=(npix, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    return d * mag[:, None]
+
+
+@pytest.mark.parametrize('nside,scale', [(128, 0.4), (128, 2.5), (128, 9.0), (128, 40.0), (64, 25.0), (512, 6.0), (512, 60.0)])
+def test_regrid_any_displacement_vs_oracle(gpu, nside, scale):
+    """K2 for displacements from a fraction of a pixel to tens of pixels (the gathering regrid sizes its aprons from the data;
+    what it does not gather goes through the far list, and through the in-stream repair pass when that list overflows:
+    NSIDE 512 x 60 pixels lists ~8e6 deposits against a capacity of 1e6): fp64 route against the oracle's get_interpol
+    regrid to 1e-10, fp32 route to the accuracy of fp32 weights; every pixel stored, mass conserved."""
+    import torch
+    from baryonification_amd import engine, synthetic as syn
+    from oracle import oracle as O
+    npix = 12 * nside * nside
+    off = _random_offsets(nside, scale, seed=nside + int(scale * 10))
+    hmap = syn.make_map(nside)
+    hmap[::17] = 0.0                                                            # empty pixels are skipped (HealpixRunner.py:335)
+    ora = O.regrid(nside, hmap, off)
+    cat = syn.make_catalog(1000)
+    z, M, r = syn.table_grid(cat)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
+    dev = torch.device('cuda:0')
+    plan = engine.ShellPlan(model, keep, nside, 1000, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    d_map = torch.from_numpy(hmap).to(dev)
+    for f64, tol in ((True, 1e-10), (False, 3e-5 * max(1.0, scale))):
+        d_off = torch.from_numpy(off if f64 else off.astype(np.float32)).to(dev).reshape(-1)
+        out = torch.full((npix,), np.nan, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.regrid(d_map.data_ptr(), d_off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=f64)
+        torch.cuda.synchronize()
+        plan.status()
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert abs(sums[0].item() - hmap.sum()) <= 1e-9 * hmap.sum() and abs(sums[1].item() - sums[0].item()) <= 1e-9 * hmap.sum()
+        assert abs(got.sum() - hmap.sum()) <= 1e-9 * hmap.sum()
+        assert np.abs(got - ora).max() <= tol * np.abs(ora).max(), (f64, np.abs(got - ora).max() / np.abs(ora).max())
+    plan.close()
+
+
+def test_fused_baryonify_equals_offsets_then_regrid(gpu):
+    """bfgx_baryonify_device (K1 leaves the largest displacement per tile for K2's aprons) == offsets + regrid (K2 finds it
+    with its own pass), for a table whose displacements reach many pixels (aprons of several rings, far list in use)"""
+    N, nside = 200_000, 512
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    from baryonification_amd import engine
+    npix = 12 * nside * nside
+    hmap = torch.from_numpy(syn.make_map(nside)).to(dev)
+    for scale in (1.0, 300.0):                       # closed-form table: a few percent of a pixel; x 300: up to ~10 pixels
+        model, keep = engine.model_from_tables(axes, table * scale, syn.COSMO, 10.0, 10.0)
+        pl = engine.ShellPlan(model, keep, nside, N, 0, torch.cuda.current_stream().cuda_stream)
+        cd, cols = _cat_dev(torch, _lib, dev, cat)
+        for f64 in (False, True):
+            dt = torch.float64 if f64 else torch.float32
+            off_a, off_b = torch.zeros(npix * 3, dtype=dt, device=dev), torch.zeros(npix * 3, dtype=dt, device=dev)
+            out_a, out_b = torch.full((npix,), np.nan, dtype=torch.float64, device=dev), torch.full((npix,), np.nan, dtype=torch.float64, device=dev)
+            s_a, s_b = torch.zeros(2, dtype=torch.float64, device=dev), torch.zeros(2, dtype=torch.float64, device=dev)
+            pl.offsets(cd, off_a.data_ptr(), acc_f64=f64)
+            pl.regrid(hmap.data_ptr(), off_a.data_ptr(), out_a.data_ptr(), s_a.data_ptr(), acc_f64=f64)
+            pl.baryonify(cd, hmap.data_ptr(), off_b.data_ptr(), out_b.data_ptr(), s_b.data_ptr(), acc_f64=f64)
+            torch.cuda.synchronize()
+            pl.status()
+            # (K1 adds in LDS with atomics, and the wide pass rounds to the accumulator type once per visit of a tile: the order,
+            # hence the last bits, differ from run to run)
+            assert (off_a - off_b).abs().max().item() <= (1e-12 if f64 else 2e-6) * off_a.abs().max().item()
+            pix = np.sqrt(4 * np.pi / npix)
+            reach = off_a.view(-1, 3).double().norm(dim=1).max().item() / pix
+            assert (reach < 0.2) if scale == 1.0 else (2.0 < reach < 40.0), reach
+            assert torch.isfinite(out_b).all().item() and np.isclose(s_b[1].item(), s_b[0].item(), rtol=(1e-12 if f64 else 1e-6))
+            # the aprons may differ (K1's bound on |offset| for the few tiles of the wide pass is looser): same deposits, other order
+            assert (out_a - out_b).abs().max().item() <= (1e-10 if f64 else 1e-5) * max(1.0, reach) * out_a.abs().max().item()
+        pl.close()
+    plan.close()
+
+
+@pytest.mark.parametrize('scale', [0.5, 3.0, 12.0])
+def test_banded_regrid_with_reach(gpu, scale):
+    """the banded regrid with the apron every rank derives from the largest summed |offset| (reach_rings / set_band_reach):
+    slices + listed far deposits == the full-map regrid == the oracle"""
+    import torch
+    from baryonification_amd import engine, synthetic as syn
+    from baryonification_amd.utils.Parallelize import band_partition
+    from oracle import oracle as O
+    nside = 256
+    npix = 12 * nside * nside
+    off = _random_offsets(nside, scale, seed=7).astype(np.float32)
+    hmap = syn.make_map(nside)
+    ora = O.regrid(nside, hmap, off.astype(np.float64))
+    cat = syn.make_catalog(1000)
+    z, M, r = syn.table_grid(cat)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
+    dev = torch.device('cuda:0')
+    plan = engine.ShellPlan(model, keep, nside, 1000, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    d_map, d_off = torch.from_numpy(hmap).to(dev), torch.from_numpy(off).to(dev).reshape(-1)
+    rings = plan.reach_rings(float(np.linalg.norm(off, axis=1).max()))
+    assert 1 <= rings <= 16 and (rings == 1) == (scale < 0.6)
+    plan.set_band_reach(rings)
+    first = plan.bands()
+    world = 3
+    cuts = band_partition(first, world)
+    pb = first[cuts]
+    acc = torch.full((npix,), np.nan, dtype=torch.float64, device=dev)
+    far_p, far_v = [], []
+    for rk in range(world):
+        p0, p1 = int(pb[rk]), int(pb[rk + 1])
+        olo, ohi = plan.band_apron(int(cuts[rk]), int(cuts[rk + 1]))
+        my_off = d_off[3 * olo:3 * ohi].clone()
+        plan.regrid_bands(int(cuts[rk]), int(cuts[rk + 1]), d_map.data_ptr(), my_off.data_ptr(), olo, ohi, acc[p0:p1].data_ptr())
+        fp, fv = plan.far_fetch()
+        far_p.append(fp); far_v.append(fv)
+    fp, fv = np.concatenate(far_p), np.concatenate(far_v)
+    if fp.size:
+        acc.index_add_(0, torch.from_numpy(fp).to(dev), torch.from_numpy(fv).to(dev))
+    plan.status()
+    got = acc.cpu().numpy()
+    assert np.isfinite(got).all() and abs(got.sum() - hmap.sum()) <= 1e-9 * hmap.sum()
+    assert np.abs(got - ora).max() <= 3e-5 * max(1.0, scale) * np.abs(ora).max()
     plan.close()
 
 
