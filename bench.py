@@ -521,7 +521,7 @@ def roofline(args, kernels, n_pairs, nh, npix, paint):
     dom = 'paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
     real = 'double' if (args.acc_f64 or paint) else 'float'
     names = {"offsets": ("tile_scatter2_kernel<OFFSETS, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
-             "regrid": ("tile_regrid3_kernel<%s>" % real) if args.algo == 1 else "regrid_kernel",
+             "regrid": ("tile_regrid3_kernel<%s, %s, 0>" % (real, real)) if args.algo == 1 else "regrid_kernel",
              "paint": "tile_scatter2_kernel<PAINT, double>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
     ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
     traffic = valu = None
