@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -37,6 +38,7 @@ template <typename T> static inline hipError_t bfgx_counted_malloc(T **p, size_t
 #include "bfgx_grid.hpp"
 #include "bfgx_fft.hpp"
 #include "bfgx_snapshot.hpp"
+#include "bfgx_deposit.hpp"
 #include "bfgx_fftlog.hpp"
 
 using namespace bfgx;
@@ -921,6 +923,8 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
                        map_out_dev, far, reach, (double *)nullptr, -1, nt, p->regrid_todo);
 }
 
+namespace { void dep_release_all(); }
+
 extern "C" {
 
 static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64, double *map_out_dev, double *sums_dev,
@@ -1218,9 +1222,12 @@ int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d,
 
 void bfgx_cache_clear(void)
 {
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    for (CacheEntry *e : g_cache) cache_drop(e);
-    g_cache.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (CacheEntry *e : g_cache) cache_drop(e);
+        g_cache.clear();
+    }
+    dep_release_all();           // workspace of the tiled particle deposit (bfgx_grid_api.inc)
 }
 
 long long bfgx_debug_alloc_count(void) { return (long long)g_bfgx_allocs.load(); }

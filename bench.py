@@ -256,7 +256,7 @@ def main_grid(args):
                           "parallelism": "halo shards x%d + RCCL reduce(pix_offsets) -> rank 0 regrid + P(k)" % world if world > 1 else "single GPU"},
                "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
                "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),
-               "roofline": {"kernel": {"regrid": "grid_regrid_kernel<3>", "offsets": "grid_scatter_kernel<3,OFFSETS>", "deposit": "particle_deposit_kernel<3>",
+               "roofline": {"kernel": {"regrid": "grid_regrid_kernel<3>", "offsets": "grid_scatter_kernel<3,OFFSETS>", "deposit": "deposit_keys + 2 x deposit_split + deposit_tiles (bfgx_deposit.hpp)",
                                        "pk": "fft_r2c_lines + 2 x fft_c2c_strided + pk_bin", "displace": "snap_displace_kernel<3>"}[dom],
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_launch": alg[dom]}}

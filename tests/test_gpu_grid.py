@@ -61,6 +61,36 @@ def test_make_map_vs_reference_golden(gpu, name):
     assert np.array_equal(out != 0, g['expected'] != 0)            # bin membership is exact (edges, inclusive last edge)
 
 
+@pytest.mark.parametrize('mode', ['tiled', 'atomic'])
+@pytest.mark.parametrize('ndim,N,npart,kind', [(3, 80, 200_000, 'uniform'), (3, 33, 50_000, 'clustered'), (2, 100, 100_000, 'uniform'),
+                                               (2, 300, 150_000, 'clustered'), (3, 128, 5, 'uniform'), (3, 64, 70_000, 'one-cell')])
+def test_make_map_tiled_and_atomic_forms(gpu, monkeypatch, mode, ndim, N, npart, kind):
+    """ParticleSnapshot.make_map through both device forms (sort into 8192-cell tiles + LDS-owned accumulation; one global
+    atomic per particle) == the oracle's np.histogramdd restatement: grids that are not multiples of the tile shape,
+    particles outside the box / exactly on edges (dropped / inclusive last edge), everything in one cell, a handful of particles"""
+    import baryonification_amd as bfg
+    from oracle import grid as G
+    monkeypatch.setenv('BFGX_DEPOSIT', mode)
+    rng = np.random.default_rng(N + npart)
+    L = 250.0
+    if kind == 'uniform':
+        xyz = rng.uniform(-0.02 * L, 1.02 * L, (npart, ndim))              # ~8 % outside
+    elif kind == 'clustered':
+        c = rng.uniform(0, L, (40, ndim))
+        xyz = c[rng.integers(0, 40, npart)] + rng.normal(0, 0.01 * L, (npart, ndim))
+    else:
+        xyz = np.full((npart, ndim), 0.4321 * L) + rng.uniform(0, 1e-3, (npart, ndim))
+    k = min(4, npart)
+    xyz[:k] = np.array([[0.0] * ndim, [L] * ndim, [L / N] * ndim, [L * (1 - 1e-16)] * ndim])[:k]
+    mass = rng.uniform(0.5, 2.0, npart)
+    Snap = bfg.utils.ParticleSnapshot(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2] if ndim == 3 else None, M=mass, L=L, redshift=0.0,
+                                      cosmo=H.load_grid_golden('grid2d_paint')['cosmo_runner'])
+    Map = Snap.make_map(N)
+    ora = G.make_map([xyz[:, d] for d in range(ndim)], mass, L, N)
+    assert Map.shape == (N,) * ndim and np.array_equal(Map != 0, ora != 0)
+    assert np.abs(Map - ora).max() <= 1e-12 * ora.max()
+
+
 @pytest.mark.parametrize('N,Nk', [(8, 3), (16, 5), (32, 12), (64, 180), (128, 60)])
 def test_power_spectrum_vs_numpy_restatement(gpu, N, Nk):
     from baryonification_amd.engine import power_spectrum
