@@ -29,18 +29,20 @@ constexpr int kDepHist = 2048;                    // LDS histogram entries of a 
 
 struct DepGeom {
     int32_t dim, nb;                  // grid: nb^dim cells
+    int32_t plane_lo, plane_n;        // slab of the FIRST axis that is deposited ([plane_lo, plane_lo + plane_n); the whole grid: 0, nb):
+                                      // the output holds plane_n x nb (x nb) cells, particles of other planes are dropped
     int32_t sx, sy, sz;               // tile shape in cells
     int32_t ntx, nty, ntz;            // tiles per axis
     int32_t T, B1, B2;                // tiles; level-1 buckets; tiles per level-1 bucket (B1 * B2 >= T)
 };
 
-__host__ inline DepGeom dep_geom(int dim, int nb)
+__host__ inline DepGeom dep_geom(int dim, int nb, int plane_lo, int plane_n)
 {
     DepGeom g;
-    g.dim = dim; g.nb = nb;
+    g.dim = dim; g.nb = nb; g.plane_lo = plane_lo; g.plane_n = plane_n;
     if (dim == 3) { g.sx = 16; g.sy = 16; g.sz = 32; }
     else { g.sx = 64; g.sy = 128; g.sz = 1; }
-    g.ntx = (nb + g.sx - 1) / g.sx;
+    g.ntx = (plane_n + g.sx - 1) / g.sx;
     g.nty = (nb + g.sy - 1) / g.sy;
     g.ntz = (dim == 3) ? (nb + g.sz - 1) / g.sz : 1;
     g.T = g.ntx * g.nty * g.ntz;
@@ -90,9 +92,11 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
         for (int q = 0; q < kBatch; ++q) {
             const int64_t p = base + (q0 + q) * 256 + tid;
             if (p >= n) continue;
-            const int bx = histogram_bin(e, g.nb, vx[q]), by = histogram_bin(e, g.nb, vy[q]);
+            int bx = histogram_bin(e, g.nb, vx[q]);
+            const int by = histogram_bin(e, g.nb, vy[q]);
             const int bz = (DIM == 3) ? histogram_bin(e, g.nb, vz[q]) : 0;
             uint32_t key = kDepNoKey;
+            bx = (bx >= g.plane_lo && bx < g.plane_lo + g.plane_n) ? bx - g.plane_lo : -1;
             if (bx >= 0 && by >= 0 && bz >= 0) {
                 key = dep_key(g, bx, by, bz);
                 atomicAdd(hist + (int)((key >> kDepLocalBits) / (uint32_t)g.B2), 1);
@@ -244,7 +248,7 @@ deposit_tiles_kernel(DepGeom g, const int32_t *__restrict__ start2, const uint32
     for (int l = tid; l < g.sx * g.sy * g.sz; l += kDepTileThreads) {
         const int lz = l % g.sz, ly = (l / g.sz) % g.sy, lx = l / (g.sz * g.sy);
         const int bx = x0 + lx, by = y0 + ly, bz = z0 + lz;
-        if (bx >= g.nb || by >= g.nb || (g.dim == 3 && bz >= g.nb)) continue;
+        if (bx >= g.plane_n || by >= g.nb || (g.dim == 3 && bz >= g.nb)) continue;
         const int64_t flat = (g.dim == 3) ? ((int64_t)bx * g.nb + by) * g.nb + bz : (int64_t)bx * g.nb + by;
         out[flat] = acc[l];
     }

@@ -109,9 +109,10 @@ fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int
 
 // |F|^2, |k| and mode counts per linear k-bin.  F[a][b][c], c <= N/2; k = sqrt(klin[a]^2 + klin[c]^2 + klin[b]^2)
 // (the notebook's summation order); bin = floor((k - kb0) / dk); the c-mirrored half counts through a weight of 2.
+// F may hold only the columns b0 <= b < b0 + nb of the middle axis (slab decomposition after the transpose: [N][nb][nz]).
 __global__ void __launch_bounds__(256)
 pk_bin_kernel(const double2 *__restrict__ F, int N, const double *__restrict__ klin, double kb0, double dk, int nk,
-              double *__restrict__ pk_sum, double *__restrict__ k_sum, unsigned long long *__restrict__ counts)
+              double *__restrict__ pk_sum, double *__restrict__ k_sum, unsigned long long *__restrict__ counts, int nb, int b0)
 {
     extern __shared__ double hist[];                       // [nk] power, [nk] k, then [nk] counts (u64)
     double *hp = hist, *hk = hist + nk;
@@ -119,11 +120,11 @@ pk_bin_kernel(const double2 *__restrict__ F, int N, const double *__restrict__ k
     for (int i = threadIdx.x; i < nk; i += blockDim.x) { hp[i] = 0.0; hk[i] = 0.0; hc[i] = 0ull; }
     __syncthreads();
     const int nz = (N >> 1) + 1;
-    const int64_t total = (int64_t)N * N * nz;
+    const int64_t total = (int64_t)N * nb * nz;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(t % nz);
         const int64_t q = t / nz;
-        const int b = (int)(q % N), a = (int)(q / N);
+        const int b = b0 + (int)(q % nb), a = (int)(q / nb);
         const double ka = klin[a], kb = klin[b], kc = klin[c];
         const double k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
         const double u = floor((k - kb0) / dk);

@@ -32,6 +32,8 @@ struct GridGeom {
     double half_box;                  // max(bins) / 2
     double a;                         // 1 / (1 + redshift)
     int64_t ntot;                     // npix^ndim
+    int32_t slab_lo, slab_n;          // planes of the FIRST array axis this plan owns (the whole grid: 0, npix); outputs of the
+                                      // halo loop and inputs of the regrid hold slab_n x npix (x npix) cells
 };
 
 struct GridCatalog {
@@ -146,6 +148,17 @@ grid_prep_kernel(DevModel m, GridGeom g, GridCatalog c, int mode, GridHaloRec *_
                 while (lo < hi && !(cutout_coord(lo, nsize, r.step, r.start, r.top, g.res) + r.dax[ax] > -r.rcut)) ++lo;
                 while (hi > lo && !(cutout_coord(hi - 1, nsize, r.step, r.start, r.top, g.res) + r.dax[ax] < r.rcut)) --hi;
             }
+            if (ax == 0 && g.slab_n < g.npix) {
+                // slab decomposition: keep the cutout rows whose (periodic) plane can belong to this slab -- the hull of the
+                // intersections with the slab and its two periodic images; the scatter kernel checks ownership per pixel
+                const int off = r.cen[0] - (nsize >> 1), P0 = off + lo, P1 = off + hi;
+                int a = 0x7fffffff, b = -0x7fffffff;
+                for (int mm = -1; mm <= 1; ++mm) {
+                    const int lo_m = max(P0, g.slab_lo + mm * g.npix), hi_m = min(P1, g.slab_lo + g.slab_n + mm * g.npix);
+                    if (lo_m < hi_m) { a = min(a, lo_m); b = max(b, hi_m); }
+                }
+                if (a < b) { lo = a - off; hi = b - off; } else hi = lo;
+            }
             r.lo[ax] = lo; r.n[ax] = hi - lo;
             vol *= (hi - lo);
         }
@@ -204,6 +217,9 @@ grid_scatter_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restrict__ re
             pi += (pi < 0) ? N : 0; pi -= (pi >= N) ? N : 0;
             pj += (pj < 0) ? N : 0; pj -= (pj >= N) ? N : 0;
             if (DIM == 3) { pk += (pk < 0) ? N : 0; pk -= (pk >= N) ? N : 0; }
+            pi -= g.slab_lo;                                                      // plane inside the slab this plan owns
+            pi += (pi < 0) ? N : 0;
+            if (pi >= g.slab_n) continue;
             const int64_t flat = (DIM == 3) ? ((int64_t)pi * N + pj) * N + pk : (int64_t)pi * N + pj;
             const double lx = log(r_eval) + R.lnoff;
             double d = R.oob ? __builtin_nan("") : radial_readout<NC>(pt, R.rowoff, R.w, lx);
@@ -264,8 +280,20 @@ __device__ inline AxisSplit split_axis(double pos, int N)
     return s;
 }
 
+// plane of the first array axis -> plane of a slab buffer that holds [slab_lo - apron, slab_lo + slab_n + apron) (periodic);
+// -1: outside the buffer.  The whole grid: slab_lo = 0, slab_n = N, apron = 0 (identity).
+struct SlabWin { int lo, n, apron; };
+__device__ inline int slab_plane(const SlabWin &s, int plane, int N)
+{
+    int l = plane - s.lo + s.apron;
+    l += (l < 0) ? N : 0;
+    l -= (l >= N) ? N : 0;
+    return (l < s.n + 2 * s.apron) ? l : -1;
+}
+
 template <int DIM>
-__device__ inline double deposit_cell(const double pos[3], double v, int N, double *__restrict__ grid)
+__device__ inline double deposit_cell(const double pos[3], double v, int N, double *__restrict__ grid, const SlabWin sw = SlabWin{0, 0x40000000, 0},
+                                      int32_t *__restrict__ missed = nullptr)
 {
     double dep = 0.0;                     // what was actually added to the grid
     // pos[0] moves along the SECOND array axis (j), pos[1] along the first (i), pos[2] along the third (k)
@@ -281,7 +309,9 @@ __device__ inline double deposit_cell(const double pos[3], double v, int N, doub
                     const double dy = sy.w[a], dx = sx.w[b], dz = sz.w[c];
                     if (dx > 0.0 && dy > 0.0 && dz > 0.0) {
                         const double w = mul_nc(mul_nc(mul_nc(dx, dy), dz), v);
-                        atomicAdd(grid + ((int64_t)sy.cell[a] * N + sx.cell[b]) * N + sz.cell[c], w);
+                        const int pl = slab_plane(sw, sy.cell[a], N);
+                        if (pl < 0) { if (missed) atomicOr(missed, 1); continue; }
+                        atomicAdd(grid + ((int64_t)pl * N + sx.cell[b]) * N + sz.cell[c], w);
                         dep += w;
                     }
                 }
@@ -293,7 +323,9 @@ __device__ inline double deposit_cell(const double pos[3], double v, int N, doub
                 const double dy = sy.w[a], dx = sx.w[b];
                 if (dx > 0.0 && dy > 0.0) {
                     const double w = mul_nc(mul_nc(dx, dy), v);
-                    atomicAdd(grid + (int64_t)sy.cell[a] * N + sx.cell[b], w);
+                    const int pl = slab_plane(sw, sy.cell[a], N);
+                    if (pl < 0) { if (missed) atomicOr(missed, 1); continue; }
+                    atomicAdd(grid + (int64_t)pl * N + sx.cell[b], w);
                     dep += w;
                 }
             }
@@ -308,8 +340,10 @@ __device__ inline double deposit_cell(const double pos[3], double v, int N, doub
 template <int DIM>
 __global__ void __launch_bounds__(256)
 grid_regrid_kernel(int N, int64_t ntot, const double *__restrict__ offsets, const double *__restrict__ map_in,
-                   double *__restrict__ map_out, double *__restrict__ block_sums)
+                   double *__restrict__ map_out, double *__restrict__ block_sums, SlabWin sw, int32_t *__restrict__ missed)
 {
+    // ntot = cells of the slab (sw.n planes); map_in / offsets hold the slab, map_out the slab + sw.apron planes either side
+    const int64_t plane_cells = (DIM == 3) ? (int64_t)N * N : (int64_t)N;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double sum_in = 0.0, sum_out = 0.0;
     if (p < ntot) {
@@ -320,14 +354,14 @@ grid_regrid_kernel(int N, int64_t ntot, const double *__restrict__ offsets, cons
 #pragma unroll
             for (int c = 0; c < DIM; ++c) { o[c] = offsets[DIM * p + c]; if (!isfinite(o[c])) o[c] = 0.0; }
             if (o[0] == 0.0 && o[1] == 0.0 && o[2] == 0.0) {
-                atomicAdd(map_out + p, v);
+                atomicAdd(map_out + p + (int64_t)sw.apron * plane_cells, v);
                 sum_out = v;
             } else {
                 int p0, p1, p2 = 0;
                 if (DIM == 3) { p2 = (int)(p % N); const int64_t q = p / N; p1 = (int)(q % N); p0 = (int)(q / N); }
                 else { p1 = (int)(p % N); p0 = (int)(p / N); }
-                const double pos[3] = {o[0] + (double)p1, o[1] + (double)p0, o[2] + (double)p2};
-                sum_out = deposit_cell<DIM>(pos, v, N, map_out);
+                const double pos[3] = {o[0] + (double)p1, o[1] + (double)(p0 + sw.lo), o[2] + (double)p2};
+                sum_out = deposit_cell<DIM>(pos, v, N, map_out, sw, missed);
             }
         }
     }
@@ -395,12 +429,16 @@ __device__ inline int histogram_bin(const double *__restrict__ e, int nb, double
 template <int DIM>
 __global__ void __launch_bounds__(256)
 particle_deposit_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                        const double *__restrict__ mass, int nb, const double *__restrict__ edges, double *__restrict__ out)
+                        const double *__restrict__ mass, int nb, const double *__restrict__ edges, double *__restrict__ out,
+                        int plane_lo, int plane_n)
 {
+    // out holds the planes [plane_lo, plane_lo + plane_n) of the first axis (the whole grid: 0, nb)
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const int bx = histogram_bin(edges, nb, x[p]), by = histogram_bin(edges, nb, y[p]);
+    int bx = histogram_bin(edges, nb, x[p]);
+    const int by = histogram_bin(edges, nb, y[p]);
     const int bz = (DIM == 3) ? histogram_bin(edges, nb, z[p]) : 0;
+    bx = (bx >= plane_lo && bx < plane_lo + plane_n) ? bx - plane_lo : -1;
     if (bx < 0 || by < 0 || bz < 0) return;
     const int64_t flat = (DIM == 3) ? ((int64_t)bx * nb + by) * nb + bz : (int64_t)bx * nb + by;
     atomicAdd(out + flat, mass ? mass[p] : 1.0);

@@ -185,6 +185,18 @@ class GridPlan(object):
         _lib.check(_lib.load().bfgx_grid_regrid_device(self._h, C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_ptr)),
                                                       C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None)))
 
+    def set_slab(self, plane_lo, plane_n):
+        """slab decomposition over GPUs: this plan owns the planes [plane_lo, plane_lo + plane_n) of the first array axis;
+        offsets() / paint() then fill plane_n x npix (x npix) cells (pass the whole catalog), regrid_slab() regrids them"""
+        _lib.check(_lib.load().bfgx_grid_plan_set_slab(self._h, int(plane_lo), int(plane_n)))
+
+    def regrid_slab(self, map_in_ptr, offsets_ptr, apron, map_out_ptr, sums_ptr=0, missed_ptr=0):
+        """regrid of the slab's source cells into map_out = slab + `apron` planes either side (zeroed by the call, periodic);
+        *missed (int32, zeroed by the caller) is set if a deposit fell outside that buffer"""
+        _lib.check(_lib.load().bfgx_grid_regrid_slab_device(self._h, C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_ptr)), int(apron),
+                                                           C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None),
+                                                           C.c_void_p(int(missed_ptr) or None)))
+
     def timing_enable(self, on=True):
         _lib.check(_lib.load().bfgx_grid_plan_timing_enable(self._h, int(on)))
 
@@ -193,6 +205,27 @@ class GridPlan(object):
         n = np.zeros(len(_lib.KERNEL_KINDS), dtype=np.int64)
         _lib.check(_lib.load().bfgx_grid_plan_timing_read(self._h, ms.ctypes.data, n.ctypes.data))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_lib.KERNEL_KINDS)}
+
+
+def deposit_particles_slab_device(x_ptr, y_ptr, z_ptr, mass_ptr, n, n_grid, edges_ptr, plane_lo, plane_n, map_out_ptr, ndim=3, device=0, stream=0):
+    """ParticleSnapshot.make_map for the planes [plane_lo, plane_lo + plane_n) of the first axis (particles elsewhere are dropped)"""
+    _lib.check(_lib.load().bfgx_deposit_particles_slab_device(int(device), C.c_void_p(int(stream) or None), int(ndim), int(n),
+                                                             C.c_void_p(int(x_ptr)), C.c_void_p(int(y_ptr)), C.c_void_p(int(z_ptr) or None),
+                                                             C.c_void_p(int(mass_ptr) or None), int(n_grid), C.c_void_p(int(edges_ptr)),
+                                                             int(plane_lo), int(plane_n), C.c_void_p(int(map_out_ptr))))
+
+
+def fft_slab_planes_device(map_ptr, n_grid, planes, work_ptr, device=0, stream=0):
+    """slab P(k), step 1: transforms along the last two axes of `planes` planes; work = complex128 [planes][n][n/2+1]"""
+    _lib.check(_lib.load().bfgx_fft_slab_planes_device(int(device), C.c_void_p(int(stream) or None), int(n_grid), int(planes),
+                                                      C.c_void_p(int(map_ptr)), C.c_void_p(int(work_ptr))))
+
+
+def fft_slab_axis0_pk_device(work_ptr, n_grid, ncols, col0, L, nk, pk_sum_ptr, k_sum_ptr, counts_ptr, device=0, stream=0):
+    """slab P(k), step 3 (after the transpose): transform along the first axis of work [n][ncols][n/2+1] + partial bin sums"""
+    _lib.check(_lib.load().bfgx_fft_slab_axis0_pk_device(int(device), C.c_void_p(int(stream) or None), int(n_grid), int(ncols), int(col0),
+                                                        C.c_void_p(int(work_ptr)), float(L), int(nk), C.c_void_p(int(pk_sum_ptr)),
+                                                        C.c_void_p(int(k_sum_ptr)), C.c_void_p(int(counts_ptr))))
 
 
 def deposit_particles_device(x_ptr, y_ptr, z_ptr, mass_ptr, n, n_grid, edges_ptr, map_out_ptr, ndim=3, device=0, stream=0):

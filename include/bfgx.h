@@ -325,15 +325,38 @@ int  bfgx_grid_paint_device(bfgx_grid_plan *p, const bfgx_grid_catalog *cat_dev,
  * receives {sum(map_in), sum(map_out)} */
 int  bfgx_grid_regrid_device(bfgx_grid_plan *p, const double *map_in_dev, const double *offsets_dev,
                              double *map_out_dev, double *sums_dev);
+/* Slab decomposition over GPUs (BASELINE config 5): a plan may own the planes [plane_lo, plane_lo + plane_n) of the FIRST
+ * array axis.  bfgx_grid_offsets_device / _paint_device then fill plane_n x npix (x npix) cells (every rank passes the
+ * whole catalog; cutouts are clipped to the slab), and bfgx_grid_regrid_slab_device regrids the slab's source cells
+ * (map_in, offsets: the slab) into map_out = the slab + `apron` planes either side ([plane_n + 2 apron] planes, zeroed by
+ * the call, periodic): the caller adds the apron planes to the neighbours' slabs.  *missed_dev (optional, zeroed by the
+ * caller) is set when a deposit fell outside the buffer (apron too small). */
+int  bfgx_grid_plan_set_slab(bfgx_grid_plan *p, int32_t plane_lo, int32_t plane_n);
+int  bfgx_grid_regrid_slab_device(bfgx_grid_plan *p, const double *map_in_dev, const double *offsets_dev, int32_t apron,
+                                  double *map_out_dev, double *sums_dev, int32_t *missed_dev);
 int  bfgx_grid_plan_timing_enable(bfgx_grid_plan *p, int on);
 int  bfgx_grid_plan_timing_read(bfgx_grid_plan *p, double *ms_sum, int64_t *launches);
 /* device-resident variants of the two deposit kernels and the P(k) summary (all pointers device) */
 int  bfgx_deposit_particles_device(int device, void *hip_stream, int32_t ndim, int64_t n, const double *x, const double *y,
                                    const double *z, const double *mass, int32_t n_grid, const double *edges_dev,
                                    double *map_out_dev);
+/* the same for the planes [plane_lo, plane_lo + plane_n) of the FIRST axis only (slab decomposition over GPUs): map_out_dev
+ * holds plane_n x n_grid (x n_grid) cells, particles of other planes are dropped */
+int  bfgx_deposit_particles_slab_device(int device, void *hip_stream, int32_t ndim, int64_t n, const double *x, const double *y,
+                                        const double *z, const double *mass, int32_t n_grid, const double *edges_dev,
+                                        int32_t plane_lo, int32_t plane_n, double *map_out_dev);
 int  bfgx_power_spectrum_device(int device, void *hip_stream, int32_t n_grid, const double *map_dev, double L, int32_t nk,
                                 double *work_dev /* complex [n_grid][n_grid][n_grid/2+1] */, double *pk_sum_dev,
                                 double *k_sum_dev, unsigned long long *counts_dev);
+
+/* The same P(k) summary for a grid that is slab-decomposed over GPUs: (1) every rank transforms its `planes` planes of the
+ * first axis along the last two axes (map [planes][n][n] -> complex work [planes][n][n/2 + 1]); (2) the caller transposes
+ * between the ranks (all_to_all) so that every rank holds all n planes of `ncols` columns of the MIDDLE axis, work
+ * [n][ncols][n/2 + 1]; (3) every rank transforms along the first axis and bins its modes (col0 = its first column): the
+ * three sums are partial and are added over the ranks by the caller. */
+int  bfgx_fft_slab_planes_device(int device, void *hip_stream, int32_t n_grid, int32_t planes, const double *map_dev, double *work_dev);
+int  bfgx_fft_slab_axis0_pk_device(int device, void *hip_stream, int32_t n_grid, int32_t ncols, int32_t col0, double *work_dev, double L,
+                                   int32_t nk, double *pk_sum_dev, double *k_sum_dev, unsigned long long *counts_dev);
 
 /* ---- particle-snapshot path ----------------------------------------------------------
  * Replaces BaryonifySnapshot.process, BaryonForge/Runners/SnapshotRunner.py:173-262: every particle within

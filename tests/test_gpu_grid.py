@@ -307,3 +307,89 @@ def test_config5_size_512_cubed(gpu):
     bfg.Runners.regrid_pixels_3D(grid, pos, val)
     ora = G.regrid_pixels(np.zeros((N, N, N)), pos, val)
     assert np.abs(grid - ora).max() <= 1e-12 * ora.max() and np.isclose(grid.sum(), val.sum(), rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------ slab decomposition (config 5 over N GPUs)
+@pytest.mark.parametrize('N,W', [(64, 2), (64, 4), (128, 8)])
+def test_slab_kernels_side_by_side_equal_the_full_grid(gpu, N, W, monkeypatch):
+    """The per-rank pieces of utils/GridSlabs on ONE GPU, the W ranks played one after the other and the exchanges done with
+    torch indexing: slab deposit, slab halo loop (cutouts clipped to the slab), slab regrid with aprons (added periodically to
+    the neighbours), plane FFTs -> transpose -> axis-0 FFT + partial P(k) sums == the single-GPU pipeline on the full grid."""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    from baryonification_amd.utils.GridSlabs import HipBackend
+    monkeypatch.setenv('BFGX_DEPOSIT', 'tiled')
+    dev = torch.device('cuda:0')
+    L, nh, eps, Nk = 120.0, 400, 5.0, 24
+    rng = np.random.default_rng(N * W)
+    bins = (np.arange(N) + 0.5) * (L / N)
+    edges = torch.from_numpy(np.linspace(0, L, N + 1)).to(dev)
+    M = (10 ** rng.uniform(13.0, 14.8, nh)).astype(np.float32).astype(np.float64)
+    pos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    pos[:4] = [[0.3, 60.0, 60.0], [L - 0.2, 10.0, 100.0], [L / W, 50.0, 50.0], [L / W - 0.01, 5.0, 5.0]]     # balls across slab faces / the box face
+    z, Mt, r = np.array([0.0, 0.01]), np.geomspace(0.99e12, 1.01e15, 10), np.geomspace(1e-3, 3e2, 500)
+    table = syn.displacement_table(z, Mt, r) * (180.0 * 64 / N)         # displacements of up to ~2 cells: aprons in use
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(Mt), np.log(r)], table, dict(syn.COSMO, w0=-1.0), eps, eps)
+    t = {k: torch.from_numpy(v.copy()).to(dev) for k, v in (('M', M), ('x', pos[:, 0]), ('y', pos[:, 1]), ('z', pos[:, 2]))}
+    lnM = torch.from_numpy(np.log(M.astype(np.float32)).astype(np.float64)).to(dev)
+    cat_dev = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
+    npart = 300_000
+    rows = torch.from_numpy(np.concatenate([rng.uniform(-0.01 * L, 1.01 * L, (npart, 3)), rng.uniform(0.5, 2.0, (npart, 1))], axis=1)).to(dev)
+    rows[0, :3] = 0.0
+    rows[1, :3] = L
+
+    be = HipBackend(model, keep, bins, 0.0, nh, device=0)
+    # ---- the full grid on one GPU
+    full_map = be.deposit(rows, edges, 0, N)
+    full_off = be.offsets(cat_dev, 0, N)
+    pairs_full = be.pairs
+    full_buf, full_sums, missed = be.regrid(full_map, full_off, 0, 0, N)
+    assert int(missed.item()) == 0 and pairs_full > 0
+    amax = float(torch.nan_to_num(full_off[..., 1], nan=0.0, posinf=0.0, neginf=0.0).abs().max().item())
+    assert 0.5 < amax < 8.0, amax
+    work = torch.empty((N, N, N // 2 + 1), dtype=torch.complex128, device=dev)
+    sums_full = torch.zeros((2, Nk), dtype=torch.float64, device=dev)
+    cnt_full = torch.zeros(Nk, dtype=torch.int64, device=dev)
+    engine.power_spectrum_device(full_buf.data_ptr(), N, L, Nk, work.data_ptr(), sums_full[0].data_ptr(), sums_full[1].data_ptr(), cnt_full.data_ptr())
+    torch.cuda.synchronize()
+
+    # ---- W slabs, one after the other
+    cnt = N // W
+    apron = min(int(np.ceil(amax)) + 1, (N - cnt) // 2)
+    new = torch.zeros_like(full_buf)
+    pairs = 0
+    s_in = s_out = 0.0
+    for rk in range(W):
+        lo = rk * cnt
+        slab = be.deposit(rows, edges, lo, cnt)                           # particles of other planes are dropped
+        assert (slab - full_map[lo:lo + cnt]).abs().max().item() <= 1e-13 * full_map.max().item()      # (order of the LDS additions)
+        off = be.offsets(cat_dev, lo, cnt)
+        pairs += be.pairs
+        a_, b_ = torch.nan_to_num(off, nan=-7.0), torch.nan_to_num(full_off[lo:lo + cnt], nan=-7.0)
+        assert (a_ - b_).abs().max().item() <= 1e-12 * b_.abs().max().item()                             # (order of the atomics)
+        buf, sums, missed = be.regrid(slab, off, apron, lo, cnt)
+        assert int(missed.item()) == 0
+        planes = (torch.arange(lo - apron, lo + cnt + apron, device=dev) % N)
+        new.index_add_(0, planes, buf)                                    # own planes + what exchange_aprons hands to the neighbours
+        s_in += sums[0].item(); s_out += sums[1].item()
+    assert pairs == pairs_full                                            # clipped cutouts: every contributing (halo, cell) pair exactly once
+    assert np.isclose(s_in, full_sums[0].item(), rtol=1e-13) and np.isclose(s_out, full_sums[1].item(), rtol=1e-12)
+    assert (new - full_buf).abs().max().item() <= 1e-12 * full_buf.abs().max().item()
+    # an apron that is too thin is reported, not silently dropped
+    if amax > 1.0:
+        _, _, missed = be.regrid(full_map[:cnt].contiguous(), full_off[:cnt].contiguous(), 0, 0, cnt)
+        assert int(missed.item()) == 1
+    # P(k): plane passes per slab, transpose, axis-0 pass + partial sums per column block
+    works = [be.fft_planes(full_buf[rk * cnt:(rk + 1) * cnt].contiguous()) for rk in range(W)]
+    allw = torch.cat(works, dim=0)                                        # [N][N][nz] after the plane passes
+    psum = torch.zeros((2, Nk), dtype=torch.float64, device=dev)
+    pcnt = torch.zeros(Nk, dtype=torch.int64, device=dev)
+    for rk in range(W):
+        cols = allw[:, rk * cnt:(rk + 1) * cnt, :].contiguous()           # what transpose_planes_to_columns delivers to rank rk
+        s2, c2 = be.fft_axis0_pk(cols, rk * cnt, L, Nk)
+        psum += s2; pcnt += c2
+    torch.cuda.synchronize()
+    assert torch.equal(pcnt, cnt_full) and int(pcnt.sum().item()) > 0
+    ok = cnt_full > 0
+    assert ((psum - sums_full).abs()[:, ok] <= 1e-11 * sums_full.abs()[:, ok]).all().item()
+    be.close()
