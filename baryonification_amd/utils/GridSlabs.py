@@ -52,29 +52,28 @@ def _allreduce(t, op):
     return t
 
 
-def route_particles(rows, edges, n, world):
-    """rows [m][3 or 4] (x, y, z[, mass]) held by this rank -> the rows whose first-axis bin lies in this rank's slab.
-    Bin rule of np.histogramdd: edges[b] <= x < edges[b + 1], the last edge inclusive, anything else dropped."""
+def route_particles(cols, edges, n, world):
+    """cols [w][m] (rows x, y, z[, mass]; columns = particles held by this rank) -> [w][m'] the particles whose first-axis bin
+    lies in this rank's slab.  Bin rule of np.histogramdd: edges[b] <= x < edges[b + 1], the last edge inclusive, anything
+    else dropped.  One all_to_all_single per coordinate (the blocks per destination are contiguous in a sorted column)."""
     import torch
-    import torch.distributed as dist
-    rank = dist.get_rank()
     cnt = n // world
-    x = rows[:, 0]
+    x = cols[0]
     b = torch.bucketize(x, edges, right=True) - 1
     b = torch.where(x == edges[-1], torch.full_like(b, n - 1), b)
     inside = (b >= 0) & (b < n)
-    owner = torch.where(inside, torch.div(b, cnt, rounding_mode='floor'), torch.full_like(b, world))      # `world` = dropped
-    order = torch.argsort(owner, stable=True)
-    counts = torch.bincount(owner, minlength=world + 1)[:world]
+    owner = torch.where(inside, torch.div(b, cnt, rounding_mode='floor'), torch.full_like(b, world)).to(torch.uint8 if world < 255 else torch.int32)
+    order = torch.argsort(owner, stable=True)                                                              # `world` = dropped: sorted last
+    counts = torch.bincount(owner.to(torch.int64), minlength=world + 1)[:world]
     ins = [int(c) for c in counts.tolist()]
-    send = rows[order][:sum(ins)].contiguous()
+    keep = order[:sum(ins)]
     t_in = counts.to(torch.int64).contiguous()
     t_out = torch.empty_like(t_in)
-    _a2a(t_out, t_in, None, None)                    # how many rows every rank sends me
+    _a2a(t_out, t_in, None, None)                    # how many particles every rank sends me
     outs = [int(c) for c in t_out.tolist()]
-    w = rows.shape[1]
-    recv = rows.new_empty((sum(outs), w))
-    _a2a(recv.view(-1), send.view(-1), [o * w for o in outs], [i * w for i in ins])
+    recv = cols.new_empty((cols.shape[0], sum(outs)))
+    for i in range(cols.shape[0]):
+        _a2a(recv[i], cols[i][keep].contiguous(), outs, ins)
     return recv
 
 
@@ -145,14 +144,13 @@ class HipBackend(object):
         self.stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.plan = engine.GridPlan(model, keep, bins, 3, redshift, max_halos, device=device, stream=self.stream)
 
-    def deposit(self, rows, edges, lo, cnt):
+    def deposit(self, cols, edges, lo, cnt):
         t = self.torch
-        cols = [rows[:, i].contiguous() for i in range(rows.shape[1])]
+        assert cols.is_contiguous()
         out = t.empty((cnt, self.n, self.n), dtype=t.float64, device=self.dev)
-        self.engine.deposit_particles_slab_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), cols[3].data_ptr() if len(cols) > 3 else 0,
-                                                  rows.shape[0], self.n, edges.data_ptr(), lo, cnt, out.data_ptr(), ndim=3, device=self.device,
+        self.engine.deposit_particles_slab_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), cols[3].data_ptr() if cols.shape[0] > 3 else 0,
+                                                  cols.shape[1], self.n, edges.data_ptr(), lo, cnt, out.data_ptr(), ndim=3, device=self.device,
                                                   stream=self.stream)
-        t.cuda.current_stream(self.dev).synchronize()            # `cols` are released on return
         return out
 
     def offsets(self, cat_dev, lo, cnt):
@@ -191,35 +189,55 @@ class HipBackend(object):
 
 
 def slab_step(backend, rows, cat, n, L, nk, timers=None):
-    """One pass of config 5 on this rank's slab (collective): particles `rows` [m][3|4] held by this rank, halo catalog `cat`
+    """One pass of config 5 on this rank's slab (collective): particles `rows` [3|4][m] (x, y, z[, mass] as rows) held by this rank, halo catalog `cat`
     (whatever the backend's offsets() takes: replicated on every rank).  Returns (new slab [cnt][n][n], k_cen, Pk, counts,
     [sum of the deposited map, sum of the regridded map] over all ranks)."""
+    import time
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, cnt = slab_bounds(n, world, rank)
+    t_last = [time.perf_counter()]
+
+    def lap(name):                                   # optional per-stage wall times (synchronising: diagnostics only)
+        if timers is not None:
+            if rows.is_cuda:
+                torch.cuda.synchronize()
+            now = time.perf_counter()
+            timers[name] = timers.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
     edges = torch.from_numpy(np.linspace(0, L, n + 1)).to(rows.device)                         # io.py:651 np.linspace(0, L, N_grid + 1)
     mine = route_particles(rows, edges, n, world)
+    lap('route')
     slab = backend.deposit(mine, edges, lo, cnt)                                               # ParticleSnapshot.make_map
+    lap('deposit')
     off = backend.offsets(cat, lo, cnt)                                                        # BaryonifyGrid halo loop
-    fin = torch.where(torch.isfinite(off[..., 1]), off[..., 1], torch.zeros_like(off[..., 1]))
-    amax = fin.abs().max().reshape(1) if fin.numel() else off.new_zeros(1)
+    lap('offsets')
+    o1 = off[..., 1]
+    amax = torch.nan_to_num(o1, nan=0.0, posinf=0.0, neginf=0.0).abs().max().reshape(1) if o1.numel() else off.new_zeros(1)
     _allreduce(amax, dist.ReduceOp.MAX)
     apron = min(int(np.ceil(float(amax.item()))) + 1, (n - cnt) // 2) if world > 1 else 0
+    lap('apron')
     buf, sums, missed = backend.regrid(slab, off, apron, lo, cnt)                              # Map2DRunner.py:577-605
     flag = missed.to(torch.int32).reshape(1).clone()
     _allreduce(flag, dist.ReduceOp.MAX)
     if int(flag.item()):
         raise RuntimeError("a regridded cell fell outside the slab + apron (%d planes): displacement larger than the slab allows" % apron)
+    lap('regrid')
     new = exchange_aprons(buf, apron, cnt, world)
     sums = sums.clone()
     _allreduce(sums, dist.ReduceOp.SUM)
+    lap('aprons')
     work = backend.fft_planes(new)                                                             # notebook 10, cells 12 + 15
+    lap('fft_planes')
     cols = transpose_planes_to_columns(work, n, world) if world > 1 else work
+    lap('transpose')
     psum, pcnt = backend.fft_axis0_pk(cols.contiguous(), lo, L, nk)
     psum, pcnt = psum.clone(), pcnt.clone()
     _allreduce(psum, dist.ReduceOp.SUM)
     _allreduce(pcnt, dist.ReduceOp.SUM)
+    lap('fft_axis0_pk')
     with np.errstate(divide='ignore', invalid='ignore'):
         c = pcnt.cpu().numpy()
         pk = psum[0].cpu().numpy() / c

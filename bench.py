@@ -126,8 +126,82 @@ def cpu_baseline_grid(args, cat, bins, zr, axes, table, eps, hmap_sample_pixels=
                       "grid; particle deposit and FFT not included" % (cat['M'].size, pairs, t1 - t0, ns, N ** 3, t2 - t1)}
 
 
+def main_grid_slabs(args):
+    """BASELINE config 5 as stated (N GPUs): the ONE 512^3 problem slab-decomposed over the ranks (utils/GridSlabs.py): particles
+    routed to the owner of their plane, halo loop clipped to the slab, regrid with apron exchange, P(k) through one all_to_all
+    transpose.  Strong scaling: the grid, the particle count and the halo catalog are those of the single-GPU line."""
+    import torch
+    import torch.distributed as dist
+    from baryonification_amd import _lib, engine, synthetic as syn
+    from baryonification_amd.utils import GridSlabs as GS
+
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count())
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libbfgx has no CPU fallback)"
+    backend = os.environ.get('BFGX_DIST_BACKEND', 'nccl')        # gloo: functional rehearsal with all ranks on one GPU
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+    N, nh, eps, zr, Nk = args.ngrid, args.grid_halos, 5.0, 0.0, 180
+    L = 205.0 / syn.COSMO['h']
+    npart = args.particles or N ** 3 // 2
+    bins = (np.arange(N) + 0.5) * (L / N)
+    rng = np.random.default_rng(syn.SEED_CATALOG)                 # the SAME halo catalog on every rank (replicated)
+    M = syn.make_catalog(nh, seed=syn.SEED_CATALOG)['M'].astype(np.float32).astype(np.float64)
+    pos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    z, Mt, r = np.array([0.0, 0.01]), np.geomspace(0.99e12, 1.01e15, 10), np.geomspace(1e-3, 3e2, 500)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(Mt), np.log(r)], syn.displacement_table(z, Mt, r), dict(syn.COSMO, w0=-1.0), eps, eps)
+    t = {k: torch.from_numpy(v.copy()).to(dev) for k, v in (('M', M), ('x', pos[:, 0]), ('y', pos[:, 1]), ('z', pos[:, 2]))}
+    lnM = torch.from_numpy(np.log(M.astype(np.float32)).astype(np.float64)).to(dev)
+    cat_dev = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
+    mine = npart // world + (1 if rank < npart % world else 0)   # this rank's share of the snapshot (as read from its file chunks)
+    torch.manual_seed(syn.SEED_MAP + rank)
+    rows = torch.rand((3, mine), dtype=torch.float64, device=dev) * L
+    be = GS.HipBackend(model, keep, bins, zr, nh, device=local_rank)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = GS.slab_step(be, rows, cat_dev, N, L, Nk)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = GS.slab_step(be, rows, cat_dev, N, L, Nk)
+    fence()
+    t1 = time.perf_counter()
+    stages = {}
+    GS.slab_step(be, rows, cat_dev, N, L, Nk, timers=stages)     # one more pass with synchronising stage timers (not in `value`)
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    new, kc, pk, cnt, sums = out
+    if rank == 0:
+        alg = N ** 3 * (3 * 8 + 8 + 8 * 8 + 8) + npart * (3 * 8 + 8) + N ** 3 * 8 + N ** 3 * 8 + 5 * N * N * (N // 2 + 1) * 16
+        ach = alg / (elapsed / args.steps) / 1e9
+        print(json.dumps({
+            "metric": "grid cells/sec for particle deposit + BaryonifyGrid + FFT P(k) on a %d^3 periodic grid" % N,
+            "value": N ** 3 / elapsed * args.steps, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: %d^3 grid of a %.1f Mpc box at z=0, %d uniform particles, %d halos (replicated catalog), "
+                                   "epsilon_max=%g, closed-form displacement table, P(k) in %d linear bins" % (N, L, npart, nh, eps, Nk),
+                       "ngrid": N, "particles": npart, "halos": nh,
+                       "parallelism": "slabs of %d planes x%d: particle routing (all_to_all), halo loop clipped per slab, regrid + apron exchange, "
+                                      "FFT with one all_to_all transpose, all_reduce of the bin sums (%s)" % (N // world, world, backend)},
+            "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),
+            "stage_ms_rank0": {k: round(v, 3) for k, v in stages.items()},
+            "roofline": {"kernel": "whole step (deposit + halo loop + regrid + FFT)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": ach / (HBM_PEAK_GBS * world), "traffic": None, "algorithmic_bytes_per_launch": alg}}), flush=True)
+    be.close()
+    dist.destroy_process_group()
+
+
 def main_grid(args):
-    """BASELINE config 5 on one GPU (or halo-sharded over N): ParticleSnapshot.make_map -> BaryonifyGrid -> P(k)."""
+    """BASELINE config 5 on one GPU: ParticleSnapshot.make_map -> BaryonifyGrid -> P(k) (N > 1: main_grid_slabs)."""
     import torch
     import torch.distributed as dist
     from baryonification_amd import _lib, engine, synthetic as syn
@@ -135,6 +209,8 @@ def main_grid(args):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if args.mode == 'grid3d' and (world > 1 or os.environ.get('BFGX_FORCE_SLABS') == '1'):
+        return main_grid_slabs(args)
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs a GPU (libbfgx has no CPU fallback)"
     torch.cuda.set_device(local_rank)

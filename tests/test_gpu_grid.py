@@ -334,9 +334,9 @@ def test_slab_kernels_side_by_side_equal_the_full_grid(gpu, N, W, monkeypatch):
     lnM = torch.from_numpy(np.log(M.astype(np.float32)).astype(np.float64)).to(dev)
     cat_dev = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
     npart = 300_000
-    rows = torch.from_numpy(np.concatenate([rng.uniform(-0.01 * L, 1.01 * L, (npart, 3)), rng.uniform(0.5, 2.0, (npart, 1))], axis=1)).to(dev)
-    rows[0, :3] = 0.0
-    rows[1, :3] = L
+    rows = torch.from_numpy(np.concatenate([rng.uniform(-0.01 * L, 1.01 * L, (3, npart)), rng.uniform(0.5, 2.0, (1, npart))], axis=0)).to(dev)
+    rows[:3, 0] = 0.0
+    rows[:3, 1] = L
 
     be = HipBackend(model, keep, bins, 0.0, nh, device=0)
     # ---- the full grid on one GPU
