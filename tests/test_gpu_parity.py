@@ -235,3 +235,24 @@ def test_multi_device_c_entry_on_one_gpu(gpu, name, ndev):
         r32 = product_runner(g)
         out32 = bfg.utils.SplitJoinParallel(r32, njobs=ndev, devices=[0] * ndev).process()
         assert np.abs(out32 - exp).max() <= 1e-6 * exp.mean()
+
+
+@pytest.mark.parametrize('scale', [30.0, 400.0])
+def test_multi_device_c_entry_large_displacements(gpu, scale):
+    """the same one-call multi-device entry with the displacement table scaled up so that pixels move by a good fraction of a
+    ring / by several rings: the devices pull 16 rings of apron, agree on the reach from the summed offsets and regrid with it;
+    result == the single-device call == the CPU oracle on the scaled table"""
+    import baryonification_amd as bfg
+    from helpers import oracle_run
+    g = dict(load_golden('lowz_baryonify'))
+    g['tab_values'] = g['tab_values'] * scale
+    ora = oracle_run(g)
+    one = product_runner(g, acc_f64=True).process()
+    assert np.abs(one - ora).max() <= 1e-10 * np.abs(ora).max()
+    pix = np.sqrt(4 * np.pi / one.size)
+    for ndev in (2, 3):
+        sj = bfg.utils.SplitJoinParallel(product_runner(g, acc_f64=True), njobs=ndev, devices=[0] * ndev)
+        out = sj.process()
+        assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
+        assert np.isclose(sj.last_stats['sum_out'], sj.last_stats['sum_in']) and np.isclose(out.sum(), g['map_in'].sum())
+    assert np.abs(one - g['map_in']).max() > 0 and pix > 0
