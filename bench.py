@@ -420,6 +420,7 @@ def main():
     slices = (world > 1 or force_x) and args.exchange == 'slices' and args.algo == 1
     d_fin = torch.zeros(npix if ((world > 1 or force_x) and rank == 0) else 0, dtype=torch.float64, device=dev)
     d_foreign = torch.zeros(1, dtype=torch.int64, device=dev)          # far deposits that belong to another rank's slice
+    route_far = [False]                # set (on every rank) when the untimed trial step finds such deposits
     if slices:
         from baryonification_amd.utils.Parallelize import _hip_reach, band_partition, gather_slices, halo_exchange, sliced_reduce
         first = plan.bands()
@@ -464,7 +465,18 @@ def main():
                 off_apron = halo_exchange(my_off, pb, needs, 3)
                 plan.regrid_bands(int(cuts[rank]), int(cuts[rank + 1]), d_map.data_ptr(), off_apron.data_ptr(), needs[rank][0], needs[rank][1],
                                   d_slice.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
-                plan.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
+                if route_far[0]:
+                    # far deposits (pole caps, moves beyond the reach) may belong to another rank's slice: every rank learns all
+                    # of them (host lists, a few KB) and adds those in its slice -- what distributed_process() always does
+                    fp, fv = plan.far_fetch()
+                    lists = [None] * world
+                    dist.all_gather_object(lists, (fp, fv))
+                    for qp, qv in lists:
+                        m = (qp >= p0) & (qp < p1)
+                        if m.any():
+                            d_slice.index_add_(0, torch.from_numpy(qp[m] - p0).to(dev), torch.from_numpy(qv[m]).to(dev))
+                else:
+                    plan.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
                 gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
                 return
             if args.algo == 0:
@@ -520,6 +532,16 @@ def main():
                 print("bench: falling back to --exchange reduce on every rank", file=sys.stderr, flush=True)
             slices = False
             step = run_steps(args.acc_f64)
+        elif not paint:
+            # did a far deposit land in another rank's slice?  then every step routes the lists (collective decision)
+            nf = d_foreign.clone() if backend == 'nccl' else d_foreign.cpu()
+            if dist.is_initialized():
+                dist.all_reduce(nf, op=dist.ReduceOp.MAX)
+            if int(nf.item()):
+                route_far[0] = True
+                d_foreign.zero_()
+                if rank == 0:
+                    print("bench: far deposits cross band boundaries: routing the far lists in every step", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     # the timed region proper: EXACTLY --steps passes, no per-kernel events (they cost ~0.05 ms per step); `value` comes from it
@@ -546,6 +568,11 @@ def main():
         # the drop-in call from numpy arrays (BaryonifyShell.process(): PCIe both ways, plan cache warm after the first call)
         extra["end_to_end"] = end_to_end(args, cat, hmap, z, M, r, table)
 
+    if slices and not paint and dist.is_initialized():
+        # a rank's sums are {its source pixels, the deposits that landed in ITS slice + the far ones it listed}: only the totals match
+        tot = d_sums.clone() if backend == 'nccl' else d_sums.cpu()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        d_sums.copy_(tot)
     if rank == 0:
         sums = d_sums.cpu().numpy()
         ms_step = elapsed / args.steps * 1e3
