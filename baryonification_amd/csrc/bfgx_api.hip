@@ -817,15 +817,15 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
         if (acc_f64) {
             const double *o = (const double *)offsets_dev - 3 * olo;
             if (p->band_reach == 1)
-                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
             else
-                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
         } else {
             const float *o = (const float *)offsets_dev - 3 * olo;
             if (p->band_reach == 1)
-                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
             else
-                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none);
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -904,7 +904,7 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
 // the gathering regrid (algo 1): [largest |offset|^2 per tile unless K1 left it], aprons, lean gather, gather with the ring
 // walk over the tiles that need it, far list / repair
 template <typename ACC, typename real>
-static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const ACC *o, double *map_out_dev, double *ts, bool from_k1)
+static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const ACC *o, double *map_out_dev, double *ts, bool from_k1, double *sums_dev)
 {
     const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real));
     FarList far = p->far;
@@ -916,11 +916,11 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
     hipLaunchKernelGGL(tile_apron_kernel, dim3((nt + 255) / 256), dim3(256), 0, p->stream, p->hpx, p->tiling, (const float *)p->tile_omax, 0,
                        reach.cap, 0, nt, p->tile_apron, p->regrid_todo);
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0>), dim3(nt), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
-                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo);
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2>), dim3(nwalk), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
-                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo);
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 1>), dim3(nfix), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
-                       map_out_dev, far, reach, (double *)nullptr, -1, nt, p->regrid_todo);
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, sums_dev);
 }
 
 namespace { void dep_release_all(); }
@@ -939,8 +939,8 @@ static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offse
         // the few deposits that need the generic route are listed and added afterwards
         HIP_TRY(hipMemsetAsync(p->far.count, 0, 4 * sizeof(int32_t), p->stream));      // entries, overflow, tiles left to the walking kernel
         double *ts = sums_dev ? p->tile_sums : nullptr;
-        if (acc_f64) launch_regrid_gather<double, double>(p, map_in_dev, (const double *)offsets_dev, map_out_dev, ts, from_k1);
-        else launch_regrid_gather<float, float>(p, map_in_dev, (const float *)offsets_dev, map_out_dev, ts, from_k1);
+        if (acc_f64) launch_regrid_gather<double, double>(p, map_in_dev, (const double *)offsets_dev, map_out_dev, ts, from_k1, sums_dev);
+        else launch_regrid_gather<float, float>(p, map_in_dev, (const float *)offsets_dev, map_out_dev, ts, from_k1, sums_dev);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
         if (acc_f64)
@@ -953,15 +953,14 @@ static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offse
     }
     HIP_TRY(hipGetLastError());
     if (sums_dev) {
-        KernelTimer kt(p, BFGX_K_SUM);
-        if (p->algo == 1)       // the tiled regrid left per-tile {sum of source values, sum of deposits}: no second pass over the maps
-            hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(256), 0, p->stream, p->tiling.ntiles, (const double *)p->tile_sums, sums_dev);
-        else {
+        // algo 1: the gather kernels left per-tile {sum of source values, sum of deposits} and the regrid's last launch added them up
+        if (p->algo != 1) {
+            KernelTimer kt(p, BFGX_K_SUM);
             HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
             hipLaunchKernelGGL(sum2_kernel, dim3(1024), dim3(256), 0, p->stream, p->hpx.npix, map_in_dev,
                                (const double *)map_out_dev, sums_dev);
+            HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;
 }

@@ -394,7 +394,7 @@ template <typename ACC, typename real, int PASS>
 __global__ void __launch_bounds__(256, 4)
 tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
                     double *__restrict__ map_out, FarList far, ReachArgs reach, double *__restrict__ tile_sums, int tile_off, int ntiles,
-                    int *__restrict__ todo)
+                    int *__restrict__ todo, double *__restrict__ sums_out)
 {
     // map_in, offsets and map_out are indexed by GLOBAL pixel number.  tile_off < 0: all tiles, heavy ones first; tile_off >= 0
     // (a rank that owns a range of bands): tiles tile_off + blockIdx.x, and the caller passes offsets / map_out pointers
@@ -406,6 +406,23 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     RegRowC<real> *rowc = reinterpret_cast<RegRowC<real> *>(rows + NTmax);
     const int tid = threadIdx.x;
     const int nl4 = (int)(4 * h.nside);
+    if (PASS == 1 && sums_out != nullptr && blockIdx.x == 0) {
+        // the two sums of the mass check from the per-tile totals the gather kernels left (the last launch of the regrid: all
+        // tiles are done); sums_out[0] = sum of the source values, [1] = sum of the deposits
+        double sa = 0.0, sb = 0.0;
+        for (int i = tid; i < ntiles; i += 256) { sa += tile_sums[2 * (int64_t)i]; sb += tile_sums[2 * (int64_t)i + 1]; }
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) { sa += __shfl_down(sa, sft, kWave); sb += __shfl_down(sb, sft, kWave); }
+        double *red = reinterpret_cast<double *>(smem);
+        if ((tid & (kWave - 1)) == 0) { red[2 * (tid / kWave)] = sa; red[2 * (tid / kWave) + 1] = sb; }
+        __syncthreads();
+        if (tid == 0) {
+            double ta = 0.0, tb = 0.0;
+            for (int w = 0; w < 256 / kWave; ++w) { ta += red[2 * w]; tb += red[2 * w + 1]; }
+            sums_out[0] = ta; sums_out[1] = tb;
+        }
+        __syncthreads();
+    }
     if (PASS == 1 && *far.overflow == 0) {                    // the usual case: add the listed far deposits to the stored map
         const unsigned long long n = *far.count;
         for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + tid; i < n; i += (unsigned long long)gridDim.x * 256)
