@@ -650,25 +650,6 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         r.fhi = (phq + dmax) * kInvTwoPi;
     }
 
-    // model-side radius and table coordinates (BaryonCorrection.py:364-370, Tabulate.py:279-283)
-    const double Rmod = (m.same_model ? R : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
-    r.rcut = m.tab.eps_model * Rmod;
-    r.inv_a = 1.0 / a;
-    const double x0 = lnz1 ? lnz1[j] : fast_log(1.0 / a), x1 = lnM ? lnM[j] : fast_log(M_j);
-    r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
-    double wv[NC];
-    int32_t ro[NC];
-    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
-    r.oob = oob ? 1 : 0;
-    if (NC == 4) {
-        for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
-    } else {
-        for (int c = 0; c < 4; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
-        RowSetX rx;
-        for (int c = 0; c < kNCmax; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
-        o.rowsx[j] = rx;
-    }
-
     // <4-pixel fallback (HealpixRunner.py:309-310): only discs of a few pixels can qualify -> exact census
     r.fb = 0; r._pad = 0;
     for (int q = 0; q < 4; ++q) { r.fb_ring[q] = 0; r.fb_k[q] = 0; }
@@ -693,6 +674,56 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         cls = kClsNarrow;
         if (r.fb) for (int q = 0; q < 4; ++q) if (r.fb_ring[q] < 16 || r.fb_ring[q] > (int)nl4 - 16) cls = kClsWide;
     }
+    // tile binning, pass 1: reserve one slot per touched tile.  Issued HERE, before the model-side arithmetic and the record
+    // stores, so that the returning atomics (the longest latency of this kernel) are in flight while the rest is computed;
+    // the TileRef that holds the slots is stored last.
+    TileRef ref;
+    ref.n = 0; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
+    for (int i = 0; i < kRefMax; ++i) { ref.few.tile[i] = 0; ref.few.slot[i] = 0; }
+    if (o.tref && !(BFGX_ABL0 & 2)) {
+        DiscSpan ds;
+        ds.fb = r.fb; ds.rfirst = r.rfirst; ds.rlast = r.rlast; ds.allphi = r.allphi; ds.flo = r.flo; ds.fhi = r.fhi;
+        for (int q = 0; q < 4; ++q) { ds.fb_ring[q] = r.fb_ring[q]; ds.fb_k[q] = r.fb_k[q]; }
+        int tl[kRefMax] = {0, 0, 0, 0};
+        int nt = 0;
+        if (cls != kClsNone) for_each_tile(h, T, ds, [&](int t) { if (nt < kRefMax) tl[nt] = t; ++nt; });
+        ref.n = nt; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
+        if (nt <= kRefMax) {
+            // narrow halos take their slot now (returning atomic); wide ones are placed by cursor after the scan
+            for (int i = 0; i < kRefMax; ++i) {
+                ref.few.tile[i] = (i < nt) ? tl[i] : 0;
+                ref.few.slot[i] = 0;
+                if (i < nt) {
+                    if (cls == kClsNarrow) ref.few.slot[i] = atomicAdd(o.cnt_a + tl[i], 1);
+                    else atomicAdd(o.cnt_w + tl[i], 1);
+                }
+            }
+        } else {
+            ref.many.rfirst = r.rfirst; ref.many.rlast = r.rlast; ref.many.allphi = r.allphi; ref.many._p = 0;
+            ref.many.flo = r.flo; ref.many.fhi = r.fhi;
+            int32_t *cnt = (cls == kClsNarrow) ? o.cnt_b : o.cnt_w;
+            for_each_tile(h, T, ds, [&](int t) { atomicAdd(cnt + t, 1); });
+        }
+    }
+    // model-side radius and table coordinates (BaryonCorrection.py:364-370, Tabulate.py:279-283)
+    const double Rmod = (m.same_model ? R : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
+    r.rcut = m.tab.eps_model * Rmod;
+    r.inv_a = 1.0 / a;
+    const double x0 = lnz1 ? lnz1[j] : fast_log(1.0 / a), x1 = lnM ? lnM[j] : fast_log(M_j);
+    r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
+    double wv[NC];
+    int32_t ro[NC];
+    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
+    r.oob = oob ? 1 : 0;
+    if (NC == 4) {
+        for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
+    } else {
+        for (int c = 0; c < 4; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
+        RowSetX rx;
+        for (int c = 0; c < kNCmax; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
+        o.rowsx[j] = rx;
+    }
+
     if (o.rec && (o.rec_all || cls == kClsWide)) o.rec[j] = r;
     if (cls == kClsNarrow && !(BFGX_ABL0 & 1)) {
         RowRec rr;
@@ -727,33 +758,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         }
     }
     if (BFGX_ABL0 & 1) { if (r.cosr == 1.2345 && wv[0] == 0.5) o.rowrec[j].z0 = r.lnoff + r.rcut; }      // keep the values alive
-    if (o.tref && !(BFGX_ABL0 & 2)) {           // tile binning, pass 1: reserve one slot per touched tile
-        DiscSpan ds;
-        ds.fb = r.fb; ds.rfirst = r.rfirst; ds.rlast = r.rlast; ds.allphi = r.allphi; ds.flo = r.flo; ds.fhi = r.fhi;
-        for (int q = 0; q < 4; ++q) { ds.fb_ring[q] = r.fb_ring[q]; ds.fb_k[q] = r.fb_k[q]; }
-        TileRef ref;
-        int tl[kRefMax] = {0, 0, 0, 0};
-        int nt = 0;
-        if (cls != kClsNone) for_each_tile(h, T, ds, [&](int t) { if (nt < kRefMax) tl[nt] = t; ++nt; });
-        ref.n = nt; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
-        if (nt <= kRefMax) {
-            // narrow halos take their slot now (returning atomic); wide ones are placed by cursor after the scan
-            for (int i = 0; i < kRefMax; ++i) {
-                ref.few.tile[i] = (i < nt) ? tl[i] : 0;
-                ref.few.slot[i] = 0;
-                if (i < nt) {
-                    if (cls == kClsNarrow) ref.few.slot[i] = atomicAdd(o.cnt_a + tl[i], 1);
-                    else atomicAdd(o.cnt_w + tl[i], 1);
-                }
-            }
-        } else {
-            ref.many.rfirst = r.rfirst; ref.many.rlast = r.rlast; ref.many.allphi = r.allphi; ref.many._p = 0;
-            ref.many.flo = r.flo; ref.many.fhi = r.fhi;
-            int32_t *cnt = (cls == kClsNarrow) ? o.cnt_b : o.cnt_w;
-            for_each_tile(h, T, ds, [&](int t) { atomicAdd(cnt + t, 1); });
-        }
-        o.tref[j] = ref;
-    }
+    if (o.tref && !(BFGX_ABL0 & 2)) o.tref[j] = ref;          // (the slots were reserved above, see there)
 }
 
 // exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total.  A tile's list is laid out as
