@@ -767,38 +767,48 @@ __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int ntiles, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, const int32_t *__restrict__ cnt_w,
                  int32_t *__restrict__ start, int32_t *__restrict__ wide_tiles)
 {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
-    const int per = (ntiles + 1023) / 1024;
-    const int lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
-    int32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += cnt_a[i] + cnt_b[i] + cnt_w[i];
-    part[tid] = s;
+    // both exclusive scans (entries per tile; tiles that have wide entries) in one pass: per-thread run of consecutive tiles,
+    // wave scan by shuffles, one barrier, the 16 wave totals scanned by every thread from LDS
+    constexpr int kPer = 8;                              // tiles per thread and round (8192 tiles per round)
+    __shared__ int32_t wtot[2][1024 / kWave];
+    __shared__ int32_t carry[2];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    if (tid < 2) carry[tid] = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int32_t v = (tid >= off) ? part[tid - off] : 0;
+    for (int base = 0; base < ntiles; base += 1024 * kPer) {
+        const int lo = min(base + tid * kPer, ntiles), hi = min(lo + kPer, ntiles);
+        int32_t c[kPer], wv[kPer], s = 0, nw = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int i = lo + q;
+            c[q] = 0; wv[q] = 0;
+            if (i < hi) { const int32_t w = cnt_w[i]; c[q] = cnt_a[i] + cnt_b[i] + w; wv[q] = w > 0 ? 1 : 0; }
+            s += c[q]; nw += wv[q];
+        }
+        int32_t is = s, iw = nw;                         // inclusive scans inside the wave
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int32_t us = __shfl_up(is, off, kWave), uw = __shfl_up(iw, off, kWave);
+            if (lane >= off) { is += us; iw += uw; }
+        }
+        if (lane == kWave - 1) { wtot[0][wid] = is; wtot[1][wid] = iw; }
         __syncthreads();
-        part[tid] += v;
+        int32_t ps = carry[0], pw = carry[1];
+        for (int w = 0; w < wid; ++w) { ps += wtot[0][w]; pw += wtot[1][w]; }
+        int32_t run = ps + is - s, pos = pw + iw - nw;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int i = lo + q;
+            if (i < hi) {
+                start[i] = run; run += c[q];
+                if (wv[q]) wide_tiles[1 + pos++] = i;    // the tiles that have wide entries: [0] = their number, [1..] = the tiles
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) { carry[0] = run; carry[1] = pos; }
         __syncthreads();
     }
-    int32_t run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) { start[i] = run; run += cnt_a[i] + cnt_b[i] + cnt_w[i]; }
-    if (tid == 1023) start[ntiles] = part[1023];
-    // the tiles that have wide entries: wide_tiles[0] = their number, wide_tiles[1..] = the tiles
-    __syncthreads();
-    int32_t nw = 0;
-    for (int i = lo; i < hi; ++i) nw += cnt_w[i] > 0 ? 1 : 0;
-    part[tid] = nw;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int32_t v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int32_t pos = part[tid] - nw;
-    for (int i = lo; i < hi; ++i) if (cnt_w[i] > 0) wide_tiles[1 + pos++] = i;
-    if (tid == 1023) wide_tiles[0] = part[1023];
+    if (tid == 0) { start[ntiles] = carry[0]; wide_tiles[0] = carry[1]; }
 }
 
 // tile binning, pass 2 (thread per halo): narrow halos with reserved slots are a plain scatter of halo indices; the others
