@@ -77,6 +77,7 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
     if (lds_edges) for (int i = tid; i <= g.nb; i += 256) sedge[i] = edges[i];
     __syncthreads();
     const double *e = lds_edges ? sedge : edges;
+    const double scale = (double)g.nb / (edges[g.nb] - edges[0]);
     const int64_t base = (int64_t)blockIdx.x * kDepChunk;
     // 8 particles per thread in flight: the loads of a batch are issued before any of the bin searches
     constexpr int kBatch = 8;
@@ -92,9 +93,9 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
         for (int q = 0; q < kBatch; ++q) {
             const int64_t p = base + (q0 + q) * 256 + tid;
             if (p >= n) continue;
-            int bx = histogram_bin(e, g.nb, vx[q]);
-            const int by = histogram_bin(e, g.nb, vy[q]);
-            const int bz = (DIM == 3) ? histogram_bin(e, g.nb, vz[q]) : 0;
+            int bx = histogram_bin(e, g.nb, vx[q], scale);
+            const int by = histogram_bin(e, g.nb, vy[q], scale);
+            const int bz = (DIM == 3) ? histogram_bin(e, g.nb, vz[q], scale) : 0;
             uint32_t key = kDepNoKey;
             bx = (bx >= g.plane_lo && bx < g.plane_lo + g.plane_n) ? bx - g.plane_lo : -1;
             if (bx >= 0 && by >= 0 && bz >= 0) {

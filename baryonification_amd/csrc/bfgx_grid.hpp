@@ -416,15 +416,19 @@ pixel_deposit_kernel(int N, int64_t n, const double *__restrict__ positions, con
 
 // np.histogramdd(coords, bins = (edges,) * DIM, weights = mass): bin b holds edges[b] <= v < edges[b + 1], the last
 // edge inclusive; anything else is dropped
-__device__ inline int histogram_bin(const double *__restrict__ e, int nb, double v)
+// `scale` = nb / (e[nb] - e[0]) only seeds the search (computed once per thread: an fp64 division per particle and axis is what
+// the deposit kernels would otherwise spend most of their arithmetic on); the two loops make the result exact whatever the seed
+__device__ inline int histogram_bin(const double *__restrict__ e, int nb, double v, double scale)
 {
-    if (!(v >= e[0]) || !(v <= e[nb])) return -1;
-    int b = (int)((v - e[0]) / (e[nb] - e[0]) * (double)nb);
+    const double e0 = e[0];
+    if (!(v >= e0) || !(v <= e[nb])) return -1;
+    int b = (int)((v - e0) * scale);
     b = max(0, min(b, nb - 1));
     while (b > 0 && e[b] > v) --b;
     while (b < nb - 1 && e[b + 1] <= v) ++b;
     return b;
 }
+__device__ inline int histogram_bin(const double *__restrict__ e, int nb, double v) { return histogram_bin(e, nb, v, (double)nb / (e[nb] - e[0])); }
 
 template <int DIM>
 __global__ void __launch_bounds__(256)
@@ -435,9 +439,10 @@ particle_deposit_kernel(int64_t n, const double *__restrict__ x, const double *_
     // out holds the planes [plane_lo, plane_lo + plane_n) of the first axis (the whole grid: 0, nb)
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    int bx = histogram_bin(edges, nb, x[p]);
-    const int by = histogram_bin(edges, nb, y[p]);
-    const int bz = (DIM == 3) ? histogram_bin(edges, nb, z[p]) : 0;
+    const double scale = (double)nb / (edges[nb] - edges[0]);
+    int bx = histogram_bin(edges, nb, x[p], scale);
+    const int by = histogram_bin(edges, nb, y[p], scale);
+    const int bz = (DIM == 3) ? histogram_bin(edges, nb, z[p], scale) : 0;
     bx = (bx >= plane_lo && bx < plane_lo + plane_n) ? bx - plane_lo : -1;
     if (bx < 0 || by < 0 || bz < 0) return;
     const int64_t flat = (DIM == 3) ? ((int64_t)bx * nb + by) * nb + bz : (int64_t)bx * nb + by;
