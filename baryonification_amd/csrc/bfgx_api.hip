@@ -1100,6 +1100,8 @@ struct CacheEntry {
     uint64_t key = 0, stamp = 0;
     bfgx_plan *plan = nullptr;
     PoolBuf cols[kCatCols], in, out, off, sums;
+    hipStream_t copy_stream = nullptr;       // the map travels to the device while K0 / K1 run on the plan's stream
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 std::mutex g_cache_mu;
@@ -1142,6 +1144,8 @@ void cache_drop(CacheEntry *e)
     if (e->plan) { (void)hipSetDevice(e->plan->device); bfgx_plan_destroy(e->plan); }
     for (auto &c : e->cols) c.release();
     e->in.release(); e->out.release(); e->off.release(); e->sums.release();
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     delete e;
 }
 
@@ -1264,28 +1268,39 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
     std::vector<double> hostlog;
     bfgx_catalog dcat;
-    Timer t;
-    t.start(p->stream);
+    if (!e->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (auto &v : e->ev) HIP_TRY(hipEventCreate(&v));
+    }
+    // phases: catalog -> device, K0 + K1 launched (enqueue-only), THEN the map -> device on a second stream (a copy from
+    // pageable memory occupies the host, the kernels run meanwhile), K2 after both, map -> host
+    HIP_TRY(hipEventRecord(e->ev[0], p->stream));
     if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog)) return rc;
     if (e->in.need(npix * sizeof(double)) || e->out.need(npix * sizeof(double)) || e->off.need(acc_bytes) || e->sums.need(2 * sizeof(double)))
         return fail(BFGX_ERR_HIP, "hipMalloc(map buffers) failed");
-    HIP_TRY(hipMemcpyAsync(e->in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    const double ms_h2d = t.stop(p->stream);
-
-    t.start(p->stream);
     if (o.algo == 0) {                                       // global-atomic kernels accumulate; the tiled ones store every element once
         HIP_TRY(hipMemsetAsync(e->off.p, 0, acc_bytes, p->stream));
         HIP_TRY(hipMemsetAsync(e->out.p, 0, npix * sizeof(double), p->stream));
     }
-    if (int rc = bfgx_baryonify_device(p, &dcat, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p)) return rc;
-    const double ms_k = t.stop(p->stream);
-
-    t.start(p->stream);
+    p->omax_from_k1 = (o.algo == 1);                         // K1's flush leaves the largest |offset|^2 of every tile for K2's aprons
+    const int rc_off = bfgx_offsets_device(p, &dcat, e->off.p, o.acc_offsets_f64);
+    p->omax_from_k1 = false;
+    if (rc_off) return rc_off;
+    HIP_TRY(hipMemcpyAsync(e->in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(e->ev[1], e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(p->stream, e->ev[1], 0));
+    if (int rc = regrid_impl(p, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p, o.algo == 1)) return rc;
+    HIP_TRY(hipEventRecord(e->ev[2], p->stream));
     double sums[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(sums, e->sums.p, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
-    const double ms_d2h = t.stop(p->stream);
+    HIP_TRY(hipEventRecord(e->ev[3], p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    float f_h2d = 0, f_k = 0, f_d2h = 0;
+    (void)hipEventElapsedTime(&f_h2d, e->ev[0], e->ev[1]);   // both uploads (K0 + K1 run underneath the second one)
+    (void)hipEventElapsedTime(&f_k, e->ev[1], e->ev[2]);     // what the kernels add after the last byte has arrived
+    (void)hipEventElapsedTime(&f_d2h, e->ev[2], e->ev[3]);
+    const double ms_h2d = f_h2d, ms_k = f_k, ms_d2h = f_d2h;
     if (int rc = bfgx_plan_status(p)) return rc;             // far-deposit list / entry list
 
     if (stats) {
