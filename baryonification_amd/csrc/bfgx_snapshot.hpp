@@ -205,6 +205,14 @@ __device__ inline double min_image(double dx, double L)
 }
 
 // flags: bit 1 = a particle lies outside [0, L] (scipy's periodic KDTree refuses such data)
+//
+// A workgroup takes 256 particles at a time.  Phase 1 (lane = particle): cell, occupancy bit, the cell's halo list, containment
+// test; a hit is only QUEUED in LDS.  Phase 2 (lane = queued hit): the fp64 read-out and the offset, added to the particle's
+// LDS accumulator -- with one thread per particle doing this inline a wave ran the read-out whenever ANY of its 64 unrelated
+// particles had a hit (~15 % lane utilisation, 0.9 of the kernel's 2.9 ms).  Phase 3 (lane = particle): displaced, re-wrapped
+// position, written once.
+constexpr int kSnapQueue = 768;                      // queued hits per 256 particles (3 per particle; more are done inline)
+
 template <int DIM>
 __global__ void __launch_bounds__(256)
 snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restrict__ px, const double *__restrict__ py,
@@ -212,56 +220,99 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
                      const int32_t *__restrict__ cell_start, const SnapEntry *__restrict__ entries, double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz,
                      int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total)
 {
+    __shared__ double spos[3][256], sacc[3][256];
+    __shared__ int qslot[kSnapQueue], qent[kSnapQueue];
+    __shared__ int qn;
+    const int tid = threadIdx.x;
     unsigned long long npairs = 0;
-    // grid-stride: a bounded number of workgroups, so that the pair census ends in a few thousand atomics on one
-    // address instead of one per wave (10^6 same-address atomics cost ~10 ms)
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
-        const double x = px[p], y = py[p], z = (DIM == 3) ? pz[p] : 0.0;
-        double tx = 0.0, ty = 0.0, tz = 0.0;
-        const bool inside = (x >= 0.0 && x <= g.L) && (y >= 0.0 && y <= g.L) && (DIM == 2 || (z >= 0.0 && z <= g.L));
-        if (!inside) atomicOr(flags, 2);
-        else {
-            const int64_t c = snap_cell_index(g, snap_cell(x, g), snap_cell(y, g), (DIM == 3) ? snap_cell(z, g) : 0);
-            int e0 = 0, e1 = 0;
-            if ((bitmap[c >> 5] >> (c & 31)) & 1u) { e0 = cell_start[c]; e1 = cell_start[c + 1]; }
-            for (int e = e0; e < e1; ++e) {
-                const SnapEntry &en = entries[e];
-                const double dx = min_image(x - en.pos[0], g.L), dy = min_image(y - en.pos[1], g.L);
-                const double dz = (DIM == 3) ? min_image(z - en.pos[2], g.L) : 0.0;
-                double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
-                if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
-                if (!(d2 <= en.Rq2)) continue;                                           // :225 / :237 query_ball_point
-                const SnapHaloRec &r = recs[en.idx];
-                // libm-free (bfgx_math.hpp): every lane of a wave pays for this block as soon as one lane has a hit
-                const double inv_d = (d2 > 0.0) ? fast_rsq(d2) : 0.0;
-                const double d = d2 * inv_d;                                             // :228 compute_distance
-                const double lnd = (d2 > 0.0) ? 0.5 * fast_log(d2) : -1.0e300;           // ln 0 -> below any table: NaN read-out
-                double disp = radial_readout<kNC>(pt, r.rowoff, r.w, lnd + r.lnoff);     // BaryonCorrection.py:356-379
-                if (!(d < r.rcut)) disp = 0.0;                                           // :381-382
-                double off = disp * g.a;                                                 // :240 displacement * a
-                if (!isfinite(off)) off = 0.0;                                           // :241
-                if (off == 0.0 && d > 0.0) continue;
-                ++npairs;
-                if (d2 > 0.0) {
-                    const double oi = off * inv_d;                                       // :242-244 offset * (dx / d)
-                    tx += oi * dx; ty += oi * dy;
-                    if (DIM == 3) tz += oi * dz;
-                } else {                                                                 // d = 0: 0 * (0 / 0) = NaN, as the reference
-                    tx = ty = tz = __builtin_nan("");
-                }
+
+    // read-out of one hit and its contribution to particle `slot` (SnapshotRunner.py:228-244)
+    auto hit = [&](int slot, const SnapEntry &en, double dx, double dy, double dz, double d2) {
+        const SnapHaloRec &r = recs[en.idx];
+        // libm-free (bfgx_math.hpp)
+        const double inv_d = (d2 > 0.0) ? fast_rsq(d2) : 0.0;
+        const double d = d2 * inv_d;                                             // :228 compute_distance
+        const double lnd = (d2 > 0.0) ? 0.5 * fast_log(d2) : -1.0e300;           // ln 0 -> below any table: NaN read-out
+        double disp = radial_readout<kNC>(pt, r.rowoff, r.w, lnd + r.lnoff);     // BaryonCorrection.py:356-379
+        if (!(d < r.rcut)) disp = 0.0;                                           // :381-382
+        double off = disp * g.a;                                                 // :240 displacement * a
+        if (!isfinite(off)) off = 0.0;                                           // :241
+        if (off == 0.0 && d > 0.0) return;
+        ++npairs;
+        if (d2 > 0.0) {
+            const double oi = off * inv_d;                                       // :242-244 offset * (dx / d)
+            atomicAdd(&sacc[0][slot], oi * dx); atomicAdd(&sacc[1][slot], oi * dy);
+            if (DIM == 3) atomicAdd(&sacc[2][slot], oi * dz);
+        } else {                                                                 // d = 0: 0 * (0 / 0) = NaN, as the reference
+            const double nan = __builtin_nan("");
+            atomicAdd(&sacc[0][slot], nan); atomicAdd(&sacc[1][slot], nan); atomicAdd(&sacc[2][slot], nan);
+        }
+    };
+
+    // containment test of particle `slot` against list entry e: a hit is queued for phase 2 (queuing the candidates too, so that
+    // this test runs one per lane, was measured: no gain -- the loop waits for the list entries, not for diverged lanes)
+    auto test = [&](int slot, int e) {
+        const SnapEntry &en = entries[e];
+        const double dx = min_image(spos[0][slot] - en.pos[0], g.L), dy = min_image(spos[1][slot] - en.pos[1], g.L);
+        const double dz = (DIM == 3) ? min_image(spos[2][slot] - en.pos[2], g.L) : 0.0;
+        double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
+        if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
+        if (!(d2 <= en.Rq2)) return;                                             // :225 / :237 query_ball_point
+        const int qi = atomicAdd(&qn, 1);
+        if (qi < kSnapQueue) { qslot[qi] = slot; qent[qi] = e; }
+        else hit(slot, en, dx, dy, dz, d2);                                      // hit queue full (a cluster core): done here
+    };
+
+    // grid-stride over blocks of 256 particles: a bounded number of workgroups, so that the pair census ends in a few thousand
+    // atomics on one address instead of one per wave (10^6 same-address atomics cost ~10 ms)
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < np; base += (int64_t)gridDim.x * 256) {
+        const int64_t p = base + tid;
+        const bool on = p < np;
+        const double x = on ? px[p] : 0.0, y = on ? py[p] : 0.0, z = (DIM == 3 && on) ? pz[p] : 0.0;
+        spos[0][tid] = x; spos[1][tid] = y; spos[2][tid] = z;
+        sacc[0][tid] = 0.0; sacc[1][tid] = 0.0; sacc[2][tid] = 0.0;
+        if (tid == 0) qn = 0;
+        __syncthreads();
+        // ---- phase 1
+        if (on) {
+            const bool inside = (x >= 0.0 && x <= g.L) && (y >= 0.0 && y <= g.L) && (DIM == 2 || (z >= 0.0 && z <= g.L));
+            if (!inside) atomicOr(flags, 2);
+            else {
+                const int64_t c = snap_cell_index(g, snap_cell(x, g), snap_cell(y, g), (DIM == 3) ? snap_cell(z, g) : 0);
+                int e0 = 0, e1 = 0;
+                if ((bitmap[c >> 5] >> (c & 31)) & 1u) { e0 = cell_start[c]; e1 = cell_start[c + 1]; }
+                for (int e = e0; e < e1; ++e) test(tid, e);
             }
         }
-        double nx = x + tx, ny = y + ty, nz = z + tz;                                    // :254-257
-        if (nx > g.L) nx -= g.L;                                                         // :259-262
-        if (nx < 0.0) nx += g.L;
-        if (ny > g.L) ny -= g.L;
-        if (ny < 0.0) ny += g.L;
-        ox[p] = nx; oy[p] = ny;
-        if (DIM == 3) {
-            if (nz > g.L) nz -= g.L;
-            if (nz < 0.0) nz += g.L;
-            oz[p] = nz;
+        __syncthreads();
+        // ---- phase 2: the queued hits, one per lane
+        const int nq = min(qn, kSnapQueue);
+        for (int i = tid; i < nq; i += 256) {
+            const int slot = qslot[i];
+            const SnapEntry &en = entries[qent[i]];
+            const double hx = spos[0][slot], hy = spos[1][slot], hz = spos[2][slot];
+            const double dx = min_image(hx - en.pos[0], g.L), dy = min_image(hy - en.pos[1], g.L);
+            const double dz = (DIM == 3) ? min_image(hz - en.pos[2], g.L) : 0.0;
+            double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
+            if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
+            hit(slot, en, dx, dy, dz, d2);
         }
+        __syncthreads();
+        // ---- phase 3
+        if (on) {
+            double nx = x + sacc[0][tid], ny = y + sacc[1][tid], nz = z + sacc[2][tid];  // :254-257
+            if (nx > g.L) nx -= g.L;                                                     // :259-262
+            if (nx < 0.0) nx += g.L;
+            if (ny > g.L) ny -= g.L;
+            if (ny < 0.0) ny += g.L;
+            ox[p] = nx; oy[p] = ny;
+            if (DIM == 3) {
+                if (nz > g.L) nz -= g.L;
+                if (nz < 0.0) nz += g.L;
+                oz[p] = nz;
+            }
+        }
+        __syncthreads();                                   // the LDS buffers are reused by the next block of particles
     }
     if (pair_total) {
         __shared__ unsigned long long wsum[256 / kWave];
