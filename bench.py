@@ -444,7 +444,13 @@ def main():
                 mine = sliced_reduce(d_out, pb, 1, recv=x_recv)
                 gather_slices(mine, pb, npix, 'root', out=d_fin if rank == 0 else None)
             elif world > 1:
-                dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318
+                if backend == 'nccl':
+                    dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)     # Parallelize.py:318
+                else:                                                    # gloo rehearsal: staged through the host
+                    h_out = d_out.cpu()
+                    dist.reduce(h_out, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        d_out.copy_(h_out)
 
         def step():
             if paint:
@@ -482,8 +488,13 @@ def main():
             if args.algo == 0:
                 d_out.zero_()                      # algo 1: the gathering regrid stores every pixel of the map exactly once
             if world > 1:
-                assert backend == 'nccl', "--exchange reduce needs RCCL"
-                dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)         # Parallelize.py:318 counterpart, before the regrid
+                if backend == 'nccl':
+                    dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)     # Parallelize.py:318 counterpart, before the regrid
+                else:                                                    # gloo rehearsal: staged through the host
+                    h_off = d_off.cpu()
+                    dist.reduce(h_off, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        d_off.copy_(h_off)
             if rank == 0:
                 plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
         return step
