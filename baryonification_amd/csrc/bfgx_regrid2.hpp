@@ -498,6 +498,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     // source pixels: the tile's rings +- R, its columns +- K (a tile that spans whole rings has no column apron)
     // (in a short ring the apron is what is left of the ring, split between the two sides, so that no pixel is visited twice)
     const int NR = T.BR + 2 * R;
+    const real reach_sp = (real)(0.999 * 2.0 / (3.0 * (double)h.nside));      // a lower bound of every ring spacing
     int maxspan = 0;
     for (int i = 1; i <= NR; ++i) maxspan = max(maxspan, rows[i].ke - rows[i].ks);
     const int LWs = maxspan + 2 * kap;
@@ -534,9 +535,19 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
         const double val = cur.val;
         const real o0 = (real)cur.o0, o1 = (real)cur.o1, o2 = (real)cur.o2;
-        const bool gathered = (double)fma_(o0, o0, fma_(o1, o1, o2 * o2)) < rows[cur.ti].lim2;
+        const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
+        const bool gathered = (double)osq < rows[cur.ti].lim2;
         if (gathered) {
             if (PASS == 1) continue;
+            if (PASS == 2) {
+                // an apron pixel d rings above / below the tile reaches it only by moving at least d - 1 ring spacings
+                // (>= 2 / (3 nside) each): most pixels of a deep apron are dismissed by this comparison
+                const int rt = cur.ti - (R + 1), dr = rt < 0 ? -rt : (rt >= i1 - i0 ? rt - (i1 - i0) + 1 : 0);
+                if (dr > 1) {
+                    const real need = (real)(dr - 1) * reach_sp;
+                    if (osq < need * need) continue;
+                }
+            }
             int tt[4], tk[4];
             real w[4];
             if (!regrid_gather_targets<real, PASS == 2>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) continue;
