@@ -1,0 +1,56 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (task contract): run at a small size, every mode."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_common(d, n_gpus=1):
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == n_gpus and d['higher_is_better'] is True and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert isinstance(d['config'].get('workload'), str) and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and r['peak'] > 0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert d['value'] > 0 and d['ms_per_step'] > 0
+
+
+def test_default_mode_line_small(gpu):
+    d = _run('--halos', '20000', '--nside', '128', '--steps', '5', '--warmup', '2', '--cpu-threads', '2')
+    _check_common(d)
+    assert d['unit'] == 'halos/s' and d['steps'] == 5 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['mass_conserved'] is True
+    assert abs(d['value'] - 20000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
+    assert 'value_acc_f64' in d and 'end_to_end' in d and d['end_to_end']['mass_conserved'] is True
+    assert set(d['kernel_ms']) >= {'prep', 'offsets', 'regrid'}
+
+
+def test_paint_and_grid_lines_small(gpu):
+    d = _run('--mode', 'paint', '--halos', '20000', '--nside', '128', '--steps', '3', '--warmup', '1', '--no-cpu-baseline')
+    _check_common(d)
+    assert 'PaintProfilesShell' in d['metric'] and d['dtype'] == 'f64'
+    d = _run('--mode', 'grid3d', '--ngrid', '64', '--grid-halos', '500', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
+    _check_common(d)
+    assert d['unit'] == 'cells/s' and d['mass_conserved'] is True and d['pk_finite_bins'] > 0
+    d = _run('--mode', 'snapshot', '--ngrid', '64', '--grid-halos', '500', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
+    _check_common(d)
+    assert d['unit'] == 'particles/s' and d['mass_conserved'] is True
