@@ -113,6 +113,7 @@ struct bfgx_plan {
     int32_t *regrid_todo = nullptr;  // [0] = count, then the tiles the lean gather kernel leaves to the one with the ring walk
     float *tile_omax = nullptr;      // largest |offset|^2 of every tile (K1's flush or tile_reach_kernel): the reach of the gathering regrid
     bool omax_from_k1 = false;       // set while a fused offsets + regrid call is in flight
+    int k1_tile_lo = 0, k1_tile_n = -1;   // tiles K1 / K3 process (-1: the whole sphere); set by the *_bands_device entries
     int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
     int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
     int32_t *wide_tiles = nullptr;   // [1 + ntiles]: number of tiles with wide entries, then those tiles (tile_scan_kernel)
@@ -336,14 +337,15 @@ static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out, bool wide_only)
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer kt(p, wide_only ? BFGX_K_WIDE : (MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT)));
     // wide pass: a small fixed grid walks the list of tiles that have wide entries (usually empty or a few polar tiles)
-    const int grid = wide_only ? std::min(p->tiling.ntiles, 512) : p->tiling.ntiles;
+    const int grid = wide_only ? std::min(p->tiling.ntiles, 512) : (p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kWavesPerBlock), lds, p->stream,
                        make_pair_table(p->model.tab), p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
                        (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total,
                        wide_only ? (const int32_t *)p->tile_count : (const int32_t *)nullptr,
                        wide_only ? (const int32_t *)p->tile_count_b : (const int32_t *)nullptr, wide_only ? 1 : 0,
                        wide_only ? (const int32_t *)p->wide_tiles : (const int32_t *)nullptr,
-                       (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr);
+                       (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
+                       p->k1_tile_lo, p->k1_tile_n);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -363,13 +365,14 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     // persistent grid: two 512-thread workgroups per CU (LDS and registers allow exactly that) draw tiles from a counter that the
     // binning step has reset (the sixth block of the counter array)
     unsigned int *tile_counter = (unsigned int *)(p->tile_count + 5 * ((size_t)p->tiling.ntiles + 1));
-    const int grid = std::min(p->tiling.ntiles, 2 * p->num_cus);
+    const int grid = std::min(p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1), 2 * p->num_cus);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
                        (const int32_t *)p->entries, p->capacity, out, p->pair_total, tile_counter,
-                       (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr);
+                       (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
+                       p->k1_tile_lo, p->k1_tile_n);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -879,6 +882,66 @@ int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev
     if (int rc = launch_prep(p, cat, 1, false, false, true)) return rc;
     if (acc_f64) return launch_scatter<MODE_OFFSETS, double>(p, cat->n, (double *)offsets_dev, nullptr);
     return launch_scatter<MODE_OFFSETS, float>(p, cat->n, (float *)offsets_dev, nullptr);
+}
+
+// K0 + K1 / K3 for the tiles of bands [band0, band1) only: out_slice_dev points at the first pixel of band0
+static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *out_slice_dev, int acc_f64, bool paint)
+{
+    if (int rc = check_catalog(p, cat)) return rc;
+    if (!out_slice_dev) return fail(BFGX_ERR_INVALID, "output pointer is NULL");
+    if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "band-restricted passes need the tiled algorithm (algo 1)");
+    if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
+    if ((p->model.tab.logv != 0) != paint) return fail(BFGX_ERR_INVALID, paint ? "profile painting needs a table with log_values = 1"
+                                                                               : "displacement read-out needs a table with log_values = 0");
+    if (band0 == band1) return BFGX_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * band0);
+    p->k1_tile_lo = p->band_tile0_host[band0];
+    p->k1_tile_n = p->band_tile0_host[band1] - p->k1_tile_lo;
+    struct Reset { bfgx_plan *p; ~Reset() { p->k1_tile_lo = 0; p->k1_tile_n = -1; } } reset{p};
+    if (int rc = launch_prep_and_bin(p, cat, paint ? 0 : 1, acc_f64 != 0)) return rc;
+    if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
+    // virtual base: the kernels index the output by global pixel number
+    if (paint) {
+        if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)out_slice_dev - p0);
+        return launch_tile_scatter<MODE_PAINT, float>(p, (float *)out_slice_dev - p0);
+    }
+    if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)out_slice_dev - 3 * p0);
+    return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)out_slice_dev - 3 * p0);
+}
+
+int bfgx_offsets_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *offsets_slice_dev, int acc_f64)
+{
+    return bands_scatter(p, cat, band0, band1, offsets_slice_dev, acc_f64, false);
+}
+
+int bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *map_slice_dev, int acc_f64)
+{
+    return bands_scatter(p, cat, band0, band1, map_slice_dev, acc_f64, true);
+}
+
+int bfgx_plan_tile_shape(bfgx_plan *p, int32_t *rings_per_band, int32_t *max_columns)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    if (rings_per_band) *rings_per_band = p->tiling.BR;
+    if (max_columns) *max_columns = p->tiling.W;
+    return BFGX_OK;
+}
+
+int bfgx_disc_rings_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t *rings_dev)
+{
+    // (uses none of the plan's per-halo workspace: the catalog may be larger than the plan's max_halos)
+    if (!p || !cat) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (cat->n < 0) return fail(BFGX_ERR_INVALID, "catalog size < 0");
+    if (cat->n > 0 && (!cat->M || !cat->z || !cat->dec)) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
+    if (cat->n > 0 && !rings_dev) return fail(BFGX_ERR_INVALID, "rings pointer is NULL");
+    HIP_TRY(hipSetDevice(p->device));
+    if (cat->n > 0) {
+        hipLaunchKernelGGL(disc_rings_kernel, dim3((unsigned)((cat->n + 255) / 256)), dim3(256), 0, p->stream, p->model, p->hpx, cat->n, cat->M, cat->z,
+                           cat->dec, rings_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
 }
 
 int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, int acc_f64)

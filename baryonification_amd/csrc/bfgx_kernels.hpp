@@ -761,6 +761,43 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     if (o.tref && !(BFGX_ABL0 & 2)) o.tref[j] = ref;          // (the slots were reserved above, see there)
 }
 
+// Ring range [first, last] (1-based, inclusive; first > last: nothing) that a halo's disc -- or its 4 fallback pixels -- can touch,
+// widened by 2 rings: what a rank that owns a range of bands needs to know to take the halos that matter to it (spatially
+// sharded multi-GPU runs).  Same arithmetic as halo_prep_kernel for a, R, D_A and the colatitude band of the disc.
+__global__ void __launch_bounds__(256)
+disc_rings_kernel(DevModel m, Hpx h, int64_t nhalo, const double *__restrict__ M, const double *__restrict__ z,
+                  const double *__restrict__ dec, int32_t *__restrict__ rings)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nhalo) return;
+    const double M_j = M[j], z_j = z[j];
+    const double a = 1.0 / (1.0 + z_j);
+    const double R = dev_radius(m.bg_runner, m.md_runner, M_j, a);
+    double D;
+    {
+        int i = (int)floor(z_j / m.da_step);
+        i = max(0, min(i, kDaKnots - 2));
+        const double t = z_j - (double)i * m.da_step;
+        const double *c = m.da_coef + 4 * i;
+        D = ((c[0] * t + c[1]) * t + c[2]) * t + c[3];
+    }
+    const double radius = R * m.eps_runner / D;
+    const double theta = kHalfPi - dec[j] * kDeg2Rad;
+    const int nl4 = (int)(4 * h.nside);
+    int first = 1, last = 0;
+    const bool bad = !(radius > 0.0) || !isfinite(radius) || !(theta >= 0.0) || !(theta <= kPi) || !(M_j > 0.0) || !isfinite(M_j) || !(z_j > -1.0);
+    if (!bad) {
+        if (radius >= kPi) { first = 1; last = nl4 - 1; }
+        else {
+            const double lo = fmax(theta - radius, 0.0), hi = fmin(theta + radius, kPi);
+            first = (int)ring_above(h, cos(lo)) - 1;              // ring_above: last ring with colatitude <= the argument's
+            last = (int)ring_above(h, cos(hi)) + 2;
+            first = max(1, first - 1); last = min(nl4 - 1, last + 1);
+        }
+    }
+    rings[2 * j] = first; rings[2 * j + 1] = last;
+}
+
 // exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total.  A tile's list is laid out as
 // [narrow, slots reserved by K0 | narrow, many-tile halos | wide]
 __global__ void __launch_bounds__(1024)
@@ -1163,7 +1200,7 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
                     const int32_t *__restrict__ tile_start, const int32_t *__restrict__ entries, int64_t capacity,
                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total,
                     const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, int addmode,
-                    const int32_t *__restrict__ wide_tiles, unsigned int *__restrict__ omax2)
+                    const int32_t *__restrict__ wide_tiles, unsigned int *__restrict__ omax2, int tile_lo, int tile_n)
 {
     // wide_tiles != nullptr ("wide pass"): only the wide-halo region of every tile's entry list is processed (the narrow
     // halos went through the fast kernel, bfgx_scatter2.hpp, which has stored the tile: addmode) and only the tiles that
@@ -1171,10 +1208,12 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
     // is small and fixed, so a catalog without wide halos costs a few microseconds
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
-    const int nvisit = wide_tiles ? wide_tiles[0] : T.ntiles;
+    // tile_n >= 0: only the tiles [tile_lo, tile_lo + tile_n) (a rank that owns a range of bands)
+    const int nvisit = wide_tiles ? wide_tiles[0] : (tile_n < 0 ? T.ntiles : tile_n);
     for (int bi = blockIdx.x; bi < nvisit; bi += gridDim.x) {
     // full pass: heavy (equatorial) tiles are dispatched first, the light polar ones fill the tail
-    const int tile = wide_tiles ? wide_tiles[1 + bi] : T.tile_order[bi];
+    const int tile = wide_tiles ? wide_tiles[1 + bi] : (tile_n < 0 ? T.tile_order[bi] : tile_lo + bi);
+    if (tile_n >= 0 && (tile < tile_lo || tile >= tile_lo + tile_n)) continue;       // (wide pass: the list covers the sphere)
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];

@@ -256,7 +256,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                      const int32_t *__restrict__ entries, int64_t capacity,
                      ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
-                     unsigned int *__restrict__ omax2)
+                     unsigned int *__restrict__ omax2, int tile_lo, int tile_n)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
@@ -267,8 +267,10 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     if (threadIdx.x == 0) s_tile = (int)atomicAdd(tile_counter, 1u);
     __syncthreads();
     const int tile_idx = s_tile;
-    if (tile_idx >= T.ntiles) break;
-    const int tile = T.tile_order[tile_idx];
+    // tile_n < 0: the whole sphere, heaviest tiles first; tile_n >= 0: the tiles [tile_lo, tile_lo + tile_n) only (a rank that owns a
+    // range of bands; `out` is then based so that only the pixels of those bands are touched)
+    if (tile_idx >= (tile_n < 0 ? T.ntiles : tile_n)) break;
+    const int tile = tile_n < 0 ? T.tile_order[tile_idx] : tile_lo + tile_idx;
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
     const int tj = tile - T.band_tile0[band];

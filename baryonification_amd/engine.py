@@ -50,6 +50,26 @@ class ShellPlan(object):
         _lib.check(_lib.load().bfgx_baryonify_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_work_ptr)),
                                                     int(acc_f64), C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None)))
 
+    def tile_shape(self):
+        """(rings per band, columns per tile): band b holds the rings [1 + b R, 1 + (b + 1) R)"""
+        br, w = C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.load().bfgx_plan_tile_shape(self._h, C.byref(br), C.byref(w)))
+        return int(br.value), int(w.value)
+
+    def disc_rings(self, cat_dev, rings_ptr):
+        """per halo the ring range [first, last] (1-based, inclusive, 2 rings of margin) its disc can touch -> int32 [n][2]"""
+        _lib.check(_lib.load().bfgx_disc_rings_device(self._h, C.byref(cat_dev), C.c_void_p(int(rings_ptr) or None)))
+
+    def offsets_bands(self, cat_dev, band0, band1, offsets_slice_ptr, acc_f64=False):
+        """K0 + K1 for the tiles of bands [band0, band1) only; the slice starts at the first pixel of band0 ([p1 - p0][3])"""
+        _lib.check(_lib.load().bfgx_offsets_bands_device(self._h, C.byref(cat_dev), int(band0), int(band1), C.c_void_p(int(offsets_slice_ptr)),
+                                                        int(acc_f64)))
+
+    def paint_bands(self, cat_dev, band0, band1, map_slice_ptr, acc_f64=True):
+        """K0 + K3 for the tiles of bands [band0, band1) only; the slice starts at the first pixel of band0"""
+        _lib.check(_lib.load().bfgx_paint_bands_device(self._h, C.byref(cat_dev), int(band0), int(band1), C.c_void_p(int(map_slice_ptr)),
+                                                      int(acc_f64)))
+
     def bands(self):
         """first RING pixel of every band of rings the tiling uses (+ npix): the unit of multi-GPU pixel ownership"""
         nb = C.c_int32(0)

@@ -43,7 +43,7 @@ import os
 import numpy as np
 
 __all__ = ['SplitJoinParallel', 'SimpleParallel', 'shard_slices', 'distributed_process', 'band_partition', 'sliced_reduce',
-           'halo_exchange', 'gather_slices']
+           'halo_exchange', 'gather_slices', 'route_halos', 'band_ring_bounds']
 
 
 def shard_slices(n, world):
@@ -81,6 +81,81 @@ def _hip_compute(runner, kind, cat_cols, device):
         plan.paint(cd, acc.data_ptr(), acc_f64=True)
     plan.status()            # blocking: the halo -> tile entry list did not overflow (a resident plan does not regrow it)
     return acc, plan
+
+
+def route_halos(cols, rings, ring_bounds):
+    """Spatial sharding of halos that start out scattered over the ranks (a catalog read in chunks): `cols` = list of 1-D tensors
+    (this rank's halos, one per column), `rings` int32 [n][2] = ring range [first, last] every disc can touch
+    (engine.ShellPlan.disc_rings), `ring_bounds[j]` = first ring owned by rank j (world + 1 entries).  A halo goes to EVERY rank
+    whose rings it can touch (first > last: to none).  Returns the list of received columns.  One all_to_all_single per column."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    first, last = rings[:, 0].long(), rings[:, 1].long()
+    idx, ins = [], []
+    for j in range(world):
+        m = (first < int(ring_bounds[j + 1])) & (last >= int(ring_bounds[j])) & (first <= last)
+        sel = torch.nonzero(m, as_tuple=False).reshape(-1)
+        idx.append(sel)
+        ins.append(int(sel.numel()))
+    order = torch.cat(idx) if idx else first.new_empty(0)
+    t_in = torch.tensor(ins, dtype=torch.int64, device=rings.device)
+    t_out = torch.empty_like(t_in)
+    _a2a(t_out, t_in, None, None)
+    outs = [int(c) for c in t_out.tolist()]
+    got = []
+    for c in cols:
+        recv = c.new_empty(sum(outs))
+        _a2a(recv, c[order].contiguous(), outs, ins)
+        got.append(recv)
+    return got
+
+
+def band_ring_bounds(cuts, rings_per_band, nside):
+    """first ring of every rank's run of bands (+ 4 nside for the end): band b = rings [1 + b R, 1 + (b + 1) R)"""
+    return np.minimum(1 + rings_per_band * np.asarray(cuts, dtype=np.int64), 4 * nside)
+
+
+def _hip_compute_spatial(runner, kind, cat_cols, device, world, rank):
+    """Spatial sharding: this rank takes, out of the FULL catalog every rank holds, the halos whose discs can touch its run of
+    ring bands and computes pix_offsets / the painted map for ITS pixels only (K0 + K1 / K3 on its tiles).  Nothing is summed
+    across ranks afterwards.  Returns (slice tensor on `device`, plan)."""
+    import torch
+    from .. import _lib, engine
+    from ..Runners._model import build_model
+    model, p_keys, keep = build_model(runner, 'displacement' if kind == 'baryonify' else 'projected')
+    nside = int(runner.LightconeShell.NSIDE)
+    dev = torch.device('cuda', device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n_all = cat_cols['M'].size
+    names = ['M', 'z', 'ra', 'dec'] + list(p_keys)
+    lnz, lnM = _lib.table_coords(cat_cols['M'], cat_cols['z'])        # numpy's np.log(1/a), np.log(M): table-edge halos as the reference
+    host = [np.ascontiguousarray(cat_cols[k], dtype=np.float64) for k in names] + [lnz, lnM]
+    probe = engine.ShellPlan(model, keep, nside, 16, device=device, stream=stream)      # bands + ring ranges need no per-halo workspace
+    first = probe.bands()
+    cuts = band_partition(first, world)
+    rb = band_ring_bounds(cuts, probe.tile_shape()[0], nside)
+    t_all = [torch.from_numpy(h).to(dev) for h in host]
+    cd_all = _lib.make_catalog_dev(n_all, t_all[0].data_ptr(), t_all[1].data_ptr(), t_all[2].data_ptr(), t_all[3].data_ptr())
+    rings = torch.empty((n_all, 2), dtype=torch.int32, device=dev)
+    probe.disc_rings(cd_all, rings.data_ptr())
+    mine = (rings[:, 0].long() < int(rb[rank + 1])) & (rings[:, 1].long() >= int(rb[rank])) & (rings[:, 0] <= rings[:, 1])
+    t = [c[mine].contiguous() for c in t_all]
+    probe.close()
+    n = int(t[0].numel())
+    plan = engine.ShellPlan(model, keep, nside, max(n, 1), device=device, stream=stream)
+    cd = _lib.make_catalog_dev(n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                               [t[4 + i].data_ptr() for i in range(len(p_keys))], ln1pz_ptr=t[-2].data_ptr(), lnM_ptr=t[-1].data_ptr())
+    p0, p1 = int(first[cuts[rank]]), int(first[cuts[rank + 1]])
+    if kind == 'baryonify':
+        sl = torch.zeros((p1 - p0) * 3, dtype=torch.float32, device=dev)
+        plan.offsets_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=False)
+    else:
+        sl = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
+        plan.paint_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=True)
+    plan.status()            # blocking: the halo -> tile entry list did not overflow
+    plan._spatial_keep = t   # the catalog columns live as long as the plan
+    return sl, plan
 
 
 def _hip_regrid(runner, plan, acc, device):
@@ -130,7 +205,7 @@ def sliced_reduce(acc, bounds, width, recv=None):
 def _a2a(recv, send, outs, ins):
     import torch.distributed as dist
     if send.is_cuda and dist.get_backend() == 'gloo':       # rehearsal on a box without RCCL peers: stage through the host
-        r = send.new_empty(sum(outs), device='cpu')
+        r = send.new_empty(recv.numel(), device='cpu')
         dist.all_to_all_single(r, send.cpu(), output_split_sizes=outs, input_split_sizes=ins)
         recv.copy_(r)
     else:
@@ -242,7 +317,7 @@ def _hip_regrid_slice(runner, plan, off_apron, olo, ohi, b0, b1, p0, p1, device)
 
 
 def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid=None, exchange='slices', bounds=None,
-                        regrid_slice=None, result='root', reach=None):
+                        regrid_slice=None, result='root', reach=None, compute_spatial=None):
     """Run `runner` (holding the FULL catalog on every rank) halo-sharded over the ranks of the default
     torch.distributed group.  Returns the final map on rank 0 (`result='root'`; None elsewhere) or on every rank
     (`result='all'`, exchange='slices').
@@ -251,17 +326,21 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
     device) -> ndarray on rank 0; exchange='slices': bounds(runner, ctx, world) -> (band cuts, pixel bounds, needs) and
     regrid_slice(runner, ctx, offsets_with_apron, olo, ohi, b0, b1, p0, p1, device) -> (slice tensor, far pixels, far
     values, sums); reach(runner, ctx, my_summed_offsets) (collective) fixes the apron before `bounds` is asked for the
-    ranges to exchange.  All default to the HIP engine."""
+    ranges to exchange.  exchange='spatial': no accumulator travels at all -- every rank takes the halos whose discs can touch
+    ITS run of ring bands and computes its own pixels only, compute_spatial(runner, kind, full_catalog_cols, device, world, rank)
+    -> (slice tensor, ctx); the regrid then proceeds as for 'slices'.  All default to the HIP engine."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     compute = compute or _hip_compute
     cat = runner.HaloLightConeCatalog.cat
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', rank))
+    if exchange == 'spatial':
+        return _distributed_spatial(runner, kind, cat, device, compute_spatial or _hip_compute_spatial, bounds, regrid_slice, reach, result)
     order = shuffled_order(cat.size, seed)
     mine = order[shard_slices(cat.size, world)[rank]]
     cols = {k: np.ascontiguousarray(cat[k][mine]) for k in cat.dtype.names}
-    if device is None:
-        device = int(os.environ.get('LOCAL_RANK', rank))
     # a failure on ONE rank (device out of memory, entry-list overflow) must not leave the others waiting in a collective:
     # the ranks agree on success before every exchange step and raise together
     err = None
@@ -288,6 +367,17 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
         full = gather_slices(mine_sum, pb, npix, result)
         return None if full is None else full.cpu().numpy().astype(np.float64)
     my_off = sliced_reduce(acc, pb, 3)
+    return _regrid_own_slices(runner, ctx, my_off, cuts, pb, needs, device, bounds, regrid_slice, reach, result)
+
+
+def _regrid_own_slices(runner, ctx, my_off, cuts, pb, needs, device, bounds, regrid_slice, reach, result):
+    """collective tail of BaryonifyShell over pixel slices: every rank holds the COMPLETE pix_offsets of its own pixels; agree on
+    the reach, exchange the apron rings, regrid the own bands, route the far deposits, gather the disjoint slices"""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nside = int(runner.LightconeShell.NSIDE)
+    npix = 12 * nside * nside
     if reach is None and bounds is None:
         reach = _hip_reach
     if reach is not None:
@@ -323,6 +413,26 @@ def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid
     old_sum = sum(float(g[2][0]) for g in gathered)
     assert np.isclose(new_sum, old_sum), "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (new_sum, old_sum)
     return new_map
+
+
+def _distributed_spatial(runner, kind, cat, device, compute_spatial, bounds, regrid_slice, reach, result):
+    """exchange='spatial' (see distributed_process)"""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cols = {k: np.ascontiguousarray(cat[k]) for k in cat.dtype.names}
+    err, mine, ctx = None, None, None
+    try:
+        mine, ctx = compute_spatial(runner, kind, cols, device, world, rank)
+    except Exception as e:        # noqa: BLE001
+        err = e
+    _agree(err, mine.device if mine is not None else None)
+    nside = int(runner.LightconeShell.NSIDE)
+    npix = 12 * nside * nside
+    cuts, pb, needs = (bounds or _hip_bounds)(runner, ctx, world)
+    if kind != 'baryonify':
+        full = gather_slices(mine, pb, npix, result)
+        return None if full is None else full.cpu().numpy().astype(np.float64)
+    return _regrid_own_slices(runner, ctx, mine, cuts, pb, needs, device, bounds, regrid_slice, reach, result)
 
 
 def _agree(err, device):

@@ -209,6 +209,15 @@ int  bfgx_plan_far_fetch(bfgx_plan *p, int64_t cap, int64_t *pix_host, double *v
 /* enqueue-only alternative: adds the listed deposits whose pixel lies in [p0, p1) to out_slice_dev (which starts at pixel
  * p0) and adds the number of the others to *foreign_dev (optional device counter the caller inspects later) */
 int  bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0, int64_t p1, unsigned long long *foreign_dev);
+/* Spatially sharded multi-GPU runs: a rank that owns the bands [band0, band1) (bfgx_plan_bands) takes every halo whose disc can
+ * touch them -- bfgx_disc_rings_device gives, per halo, the ring range [first, last] (1-based, inclusive, widened by 2 rings;
+ * first > last: nothing) -- and runs K0 + K1 (or K3) for ITS tiles only: offsets_slice_dev / map_slice_dev point at the first
+ * pixel of band0 ([p1 - p0][3] resp. [p1 - p0] elements, every one stored exactly once); halos that reach into other bands are
+ * clipped.  No accumulator travels between the ranks; the regrid then needs the neighbours' apron rings as above. */
+int  bfgx_plan_tile_shape(bfgx_plan *p, int32_t *rings_per_band, int32_t *max_columns);     /* band b = rings [1 + b R, 1 + (b + 1) R) */
+int  bfgx_disc_rings_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t *rings_dev /* [n][2]; n may exceed the plan's max_halos */);
+int  bfgx_offsets_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t band0, int32_t band1, void *offsets_slice_dev, int acc_f64);
+int  bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t band0, int32_t band1, void *map_slice_dev, int acc_f64);
 /* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */
 int  bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *map_out_dev, int acc_f64);
 /* optional per-kernel timing with HIP events recorded on the plan's stream around every launch.

@@ -418,3 +418,46 @@ def test_config4_share_nside2048(gpu):
     assert n0 == n1 > 2e8
     plan.status()
     plan.close()
+
+
+@pytest.mark.parametrize('paint', [False, True])
+def test_band_restricted_pass_with_selected_halos_equals_full_pass(gpu, paint):
+    """spatially sharded multi-GPU building block on one GPU: every "rank" takes the halos whose ring range (disc_rings) can touch
+    its run of bands and runs K0 + K1 (K3) for its tiles only; its slice must be the full-sky result on those pixels -- i.e. the
+    ring ranges miss no halo (polar caps, discs across band boundaries, 4-pixel fallbacks) and the kernels clip to the tile range"""
+    from baryonification_amd.utils.Parallelize import band_partition, band_ring_bounds
+    N, nside = 150_000, 512
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=paint)
+    cat = {k: v.copy() for k, v in cat.items()}
+    cat['dec'][:8] = [89.95, -89.9, 89.999, -89.7, 60.0, -60.0, 0.01, -0.01]
+    cat['M'][:4] *= 30.0                                                    # big discs on the pole caps
+    npix = 12 * nside * nside
+    width, dt = (1, torch.float64) if paint else (3, torch.float32)
+    cd, cols = _cat_dev(torch, _lib, dev, cat, coords=True)
+    full = torch.zeros(npix * width, dtype=dt, device=dev)
+    (plan.paint if paint else plan.offsets)(cd, full.data_ptr(), acc_f64=paint)
+    rings = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    plan.disc_rings(cd, rings.data_ptr())
+    torch.cuda.synchronize()
+    assert int((rings[:, 0] <= rings[:, 1]).sum().item()) == N and int(rings.min().item()) >= 1 and int(rings.max().item()) <= 4 * nside - 1
+    first = plan.bands()
+    BR = plan.tile_shape()[0]
+    for world in (3, 8):
+        cuts = band_partition(first, world)
+        rb = band_ring_bounds(cuts, BR, nside)
+        assert rb[0] == 1 and rb[-1] == 4 * nside
+        taken = 0
+        for rk in range(world):
+            sel = ((rings[:, 0].long() < int(rb[rk + 1])) & (rings[:, 1].long() >= int(rb[rk]))).cpu().numpy()
+            taken += int(sel.sum())
+            cdr, colsr = _cat_dev(torch, _lib, dev, cat, idx=np.nonzero(sel)[0], coords=True)
+            p0, p1 = int(first[cuts[rk]]), int(first[cuts[rk + 1]])
+            sl = torch.full(((p1 - p0) * width,), float('nan'), dtype=dt, device=dev)           # every element must be stored
+            (plan.paint_bands if paint else plan.offsets_bands)(cdr, int(cuts[rk]), int(cuts[rk + 1]), sl.data_ptr(), acc_f64=paint)
+            torch.cuda.synchronize()
+            plan.status()
+            ref = full[p0 * width:p1 * width]
+            assert torch.isfinite(sl).all().item()
+            assert (sl - ref).abs().max().item() <= (1e-12 if paint else 2e-6) * full.abs().max().item()
+        assert N <= taken <= 1.5 * N                                        # boundary halos go to two ranks, nothing is lost
+    plan.close()
