@@ -100,6 +100,10 @@ SYMBOLS = {
     'bfgx_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'bfgx_plan_bands': (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_void_p]),
     'bfgx_baryonify_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'bfgx_route_count_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_route_fill_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    'bfgx_max_offset2_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'bfgx_plan_tile_shape': (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
     'bfgx_disc_rings_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p]),
     'bfgx_offsets_bands_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int32, C.c_int32, C.c_void_p, C.c_int]),

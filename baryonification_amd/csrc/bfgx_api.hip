@@ -920,6 +920,79 @@ int bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0
     return bands_scatter(p, cat, band0, band1, map_slice_dev, acc_f64, true);
 }
 
+int bfgx_max_offset2_device(bfgx_plan *p, const void *offsets_dev, int64_t npixels, int acc_f64, float *out_dev)
+{
+    if (!p || !out_dev || (npixels > 0 && !offsets_dev)) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (npixels < 0) return fail(BFGX_ERR_INVALID, "npixels < 0");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), p->stream));
+    if (npixels > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((npixels + 255) / 256, 2048);
+        if (acc_f64) hipLaunchKernelGGL(max_offset_kernel<double>, dim3(grid), dim3(256), 0, p->stream, npixels, (const double *)offsets_dev, (unsigned *)out_dev);
+        else hipLaunchKernelGGL(max_offset_kernel<float>, dim3(grid), dim3(256), 0, p->stream, npixels, (const float *)offsets_dev, (unsigned *)out_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
+}
+
+// shared argument checks / set-up of the two routing passes
+static int route_args(bfgx_plan *p, const bfgx_catalog *cat, int32_t world, const int32_t *ring_bounds, int32_t ncols, const double *const *cols,
+                      RouteArgs &a)
+{
+    if (!p || !cat || !ring_bounds || !cols) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (world < 1 || world > kRouteMaxRanks) return fail(BFGX_ERR_INVALID, "routing supports 1 .. %d ranks", kRouteMaxRanks);
+    if (ncols < 1 || ncols > kRouteMaxCols) return fail(BFGX_ERR_INVALID, "routing packs 1 .. %d columns", kRouteMaxCols);
+    if (cat->n < 0) return fail(BFGX_ERR_INVALID, "catalog size < 0");
+    std::memset(&a, 0, sizeof(a));
+    a.world = world; a.ncols = ncols;
+    for (int j = 0; j <= world; ++j) {
+        if (j > 0 && ring_bounds[j] < ring_bounds[j - 1]) return fail(BFGX_ERR_INVALID, "ring bounds must ascend");
+        a.bounds[j] = ring_bounds[j];
+    }
+    for (int c = 0; c < ncols; ++c) { if (cat->n > 0 && !cols[c]) return fail(BFGX_ERR_INVALID, "column pointer is NULL"); a.col[c] = cols[c]; }
+    return BFGX_OK;
+}
+
+int bfgx_route_count_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, int32_t *counts_dev)
+{
+    bfgx_catalog c;
+    std::memset(&c, 0, sizeof(c));
+    c.n = n;
+    RouteArgs a;
+    const double *none[1] = {nullptr};
+    if (n < 0 || !counts_dev || (n > 0 && !rings_dev)) return fail(BFGX_ERR_INVALID, "NULL argument");
+    c.n = 0;                                                    // (no columns are read in the counting pass)
+    if (int rc = route_args(p, &c, world, ring_bounds, 1, none, a)) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * world, p->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(route_halos_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, a, n, rings_dev, counts_dev,
+                           (int32_t *)nullptr, (double *)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
+}
+
+int bfgx_route_fill_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, const int64_t *start,
+                           int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *rows_dev)
+{
+    bfgx_catalog c;
+    std::memset(&c, 0, sizeof(c));
+    c.n = n;
+    RouteArgs a;
+    if (n < 0 || !start || !cursor_dev || (n > 0 && (!rings_dev || !rows_dev))) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (int rc = route_args(p, &c, world, ring_bounds, ncols, cols_dev, a)) return rc;
+    for (int j = 0; j < world; ++j) a.start[j] = start[j];
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(int32_t) * world, p->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(route_halos_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, a, n, rings_dev, (int32_t *)nullptr,
+                           cursor_dev, rows_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
+}
+
 int bfgx_plan_tile_shape(bfgx_plan *p, int32_t *rings_per_band, int32_t *max_columns)
 {
     if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");

@@ -798,6 +798,53 @@ disc_rings_kernel(DevModel m, Hpx h, int64_t nhalo, const double *__restrict__ M
     rings[2 * j] = first; rings[2 * j + 1] = last;
 }
 
+// Routing of scattered halos to the ranks whose ring bands their discs can touch (spatially sharded multi-GPU runs): a halo with
+// ring range [first, last] goes to the contiguous run of ranks j with bounds[j] <= last and bounds[j + 1] > first.
+constexpr int kRouteMaxRanks = 64, kRouteMaxCols = 8;
+struct RouteArgs {
+    int32_t world, ncols;
+    int32_t bounds[kRouteMaxRanks + 1];          // first ring of every rank's run of bands, + one past the last ring
+    int64_t start[kRouteMaxRanks];               // fill pass: first row of every destination in the send buffer
+    const double *col[kRouteMaxCols];            // the catalog columns to pack into rows
+};
+
+__device__ inline void route_range(const RouteArgs &a, int first, int last, int &jlo, int &jhi)
+{
+    jlo = 0; jhi = -1;
+    if (first > last) return;
+    while (jlo < a.world - 1 && a.bounds[jlo + 1] <= first) ++jlo;
+    jhi = jlo;
+    while (jhi < a.world - 1 && a.bounds[jhi + 1] <= last) ++jhi;
+}
+
+// FILL = false: counts[j] += halos that go to rank j.  FILL = true: rows[start[j] + ...] = the packed rows (cursor zeroed by the
+// caller); the order of the rows inside a destination is arbitrary.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+route_halos_kernel(RouteArgs a, int64_t n, const int32_t *__restrict__ rings, int32_t *__restrict__ counts, int32_t *__restrict__ cursor,
+                   double *__restrict__ rows)
+{
+    __shared__ int hist[kRouteMaxRanks], base[kRouteMaxRanks], taken[kRouteMaxRanks];
+    const int tid = threadIdx.x;
+    if (tid < kRouteMaxRanks) { hist[tid] = 0; taken[tid] = 0; }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + tid;
+    int jlo = 0, jhi = -1;
+    if (j < n) route_range(a, rings[2 * j], rings[2 * j + 1], jlo, jhi);
+    for (int d = jlo; d <= jhi; ++d) atomicAdd(&hist[d], 1);
+    __syncthreads();
+    if (!FILL) {
+        if (tid < a.world && hist[tid]) atomicAdd(counts + tid, hist[tid]);
+        return;
+    }
+    if (tid < a.world) base[tid] = hist[tid] ? atomicAdd(cursor + tid, hist[tid]) : 0;       // one range per (workgroup, destination)
+    __syncthreads();
+    for (int d = jlo; d <= jhi; ++d) {
+        double *row = rows + (a.start[d] + base[d] + atomicAdd(&taken[d], 1)) * a.ncols;
+        for (int c = 0; c < a.ncols; ++c) row[c] = a.col[c][j];
+    }
+}
+
 // exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total.  A tile's list is laid out as
 // [narrow, slots reserved by K0 | narrow, many-tile halos | wide]
 __global__ void __launch_bounds__(1024)

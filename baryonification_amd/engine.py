@@ -50,6 +50,26 @@ class ShellPlan(object):
         _lib.check(_lib.load().bfgx_baryonify_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_work_ptr)),
                                                     int(acc_f64), C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None)))
 
+    def route_count(self, n, rings_ptr, ring_bounds, counts_ptr):
+        """routing pass 1 (enqueue-only): counts[world] (int32, device) = halos whose ring range touches each rank's rings"""
+        rb = np.ascontiguousarray(ring_bounds, dtype=np.int32)
+        _lib.check(_lib.load().bfgx_route_count_device(self._h, int(n), C.c_void_p(int(rings_ptr) or None), int(rb.size - 1), rb.ctypes.data,
+                                                      C.c_void_p(int(counts_ptr))))
+
+    def route_fill(self, n, rings_ptr, ring_bounds, start, col_ptrs, cursor_ptr, rows_ptr):
+        """routing pass 2 (enqueue-only): rows[start[j] ...] = packed rows (len(col_ptrs) doubles per halo) bound for rank j"""
+        rb = np.ascontiguousarray(ring_bounds, dtype=np.int32)
+        st = np.ascontiguousarray(start, dtype=np.int64)
+        cols = (C.c_void_p * len(col_ptrs))(*[int(c) for c in col_ptrs])
+        _lib.check(_lib.load().bfgx_route_fill_device(self._h, int(n), C.c_void_p(int(rings_ptr) or None), int(rb.size - 1), rb.ctypes.data,
+                                                     st.ctypes.data, len(col_ptrs), cols, C.c_void_p(int(cursor_ptr)),
+                                                     C.c_void_p(int(rows_ptr) or None)))
+
+    def max_offset2(self, offsets_ptr, npixels, out_ptr, acc_f64=False):
+        """enqueue-only: *out (float32, device) = largest |offset|^2 over npixels pixels of pix_offsets"""
+        _lib.check(_lib.load().bfgx_max_offset2_device(self._h, C.c_void_p(int(offsets_ptr) or None), int(npixels), int(acc_f64),
+                                                      C.c_void_p(int(out_ptr))))
+
     def tile_shape(self):
         """(rings per band, columns per tile): band b holds the rings [1 + b R, 1 + (b + 1) R)"""
         br, w = C.c_int32(0), C.c_int32(0)

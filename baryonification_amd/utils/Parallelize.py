@@ -7,8 +7,16 @@ worker processes and sums the returned maps (Parallelize.py:255-273, :312-318). 
 GPU: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI), each rank runs the
 per-halo kernels on its shard of halos; the partial accumulators are then summed.
 
+The default (`exchange='spatial'`) moves NO accumulator at all: the sphere's ring bands are dealt out to the ranks in
+contiguous pixel ranges and every rank takes, out of the catalog it holds (the reference's workers all hold the full catalog;
+a catalog read in chunks is routed with `route_halos`, 48 B per halo), the halos whose discs can touch ITS bands, computes
+pix_offsets / the painted map for its own pixels only (K0 + K1 / K3 on its tiles), exchanges the few apron rings the regrid
+needs with its two neighbours, regrids its bands and sends its slice of the map to rank 0.  The halo-sharded forms below remain
+(`exchange='slices' | 'reduce'`): they are what the reference's SplitJoinParallel does, at the price of summing full-sky
+accumulators across the ranks.
+
 xGMI is a point-to-point mesh (one link per peer), so a ring reduce of the whole accumulator to one rank
-(151 MB of pix_offsets at NSIDE 1024) is bound by ONE link.  The default exchange therefore works on pixel slices
+(151 MB of pix_offsets at NSIDE 1024) is bound by ONE link.  The halo-sharded exchange therefore works on pixel slices
 (`exchange='slices'`): the sphere's ring bands are dealt out to the ranks in contiguous pixel ranges,
   1. all_to_all: every rank sends slice j of its accumulator straight to rank j (all 7 links busy, 1/N of the
      data per link) and sums the N slices it receives -- a reduce-scatter;
@@ -83,32 +91,49 @@ def _hip_compute(runner, kind, cat_cols, device):
     return acc, plan
 
 
-def route_halos(cols, rings, ring_bounds):
-    """Spatial sharding of halos that start out scattered over the ranks (a catalog read in chunks): `cols` = list of 1-D tensors
-    (this rank's halos, one per column), `rings` int32 [n][2] = ring range [first, last] every disc can touch
-    (engine.ShellPlan.disc_rings), `ring_bounds[j]` = first ring owned by rank j (world + 1 entries).  A halo goes to EVERY rank
-    whose rings it can touch (first > last: to none).  Returns the list of received columns.  One all_to_all_single per column."""
+def route_halos(cols, rings, ring_bounds, plan=None):
+    """Spatial sharding of halos that start out scattered over the ranks (a catalog read in chunks): `cols` = list of 1-D float64
+    tensors (this rank's halos, one per catalog column), `rings` int32 [n][2] = ring range [first, last] every disc can touch
+    (engine.ShellPlan.disc_rings), `ring_bounds[j]` = first ring owned by rank j (world + 1 entries, ascending).  A halo goes to
+    EVERY rank whose rings it can touch -- a contiguous run of ranks, almost always one or two (first > last: to none).
+    Returns the received columns as one tensor [k][m].  With `plan` (a ShellPlan on the tensors' GPU) counting and packing are two
+    libbfgx kernels; either way ONE all_to_all_single of counts and one of packed rows."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    first, last = rings[:, 0].long(), rings[:, 1].long()
-    idx, ins = [], []
-    for j in range(world):
-        m = (first < int(ring_bounds[j + 1])) & (last >= int(ring_bounds[j])) & (first <= last)
-        sel = torch.nonzero(m, as_tuple=False).reshape(-1)
-        idx.append(sel)
-        ins.append(int(sel.numel()))
-    order = torch.cat(idx) if idx else first.new_empty(0)
-    t_in = torch.tensor(ins, dtype=torch.int64, device=rings.device)
+    n, k = int(rings.shape[0]), len(cols)
+    dev = rings.device
+    if plan is not None and rings.is_cuda:
+        counts = torch.empty(world, dtype=torch.int32, device=dev)
+        plan.route_count(n, rings.data_ptr(), ring_bounds, counts.data_ptr())
+        t_in = counts.to(torch.int64)
+    else:
+        rbt = torch.as_tensor(np.asarray(ring_bounds, dtype=np.int64), device=dev)
+        first, last = rings[:, 0].long(), rings[:, 1].long()
+        j_lo = (torch.bucketize(first, rbt, right=True) - 1).clamp_(0, world - 1)
+        j_hi = (torch.bucketize(last, rbt, right=True) - 1).clamp_(0, world - 1)
+        span = torch.where(first <= last, j_hi - j_lo + 1, torch.zeros_like(j_lo))
+        src, dst = [], []
+        for d in range(int(span.max().item()) if n else 0):                # d-th destination of the halos that have one
+            sel = torch.nonzero(span > d, as_tuple=False).reshape(-1)
+            src.append(sel); dst.append(j_lo[sel] + d)
+        src = torch.cat(src) if src else j_lo[:0]
+        dst = torch.cat(dst) if dst else j_lo[:0]
+        t_in = torch.bincount(dst, minlength=world)[:world].to(torch.int64)
     t_out = torch.empty_like(t_in)
     _a2a(t_out, t_in, None, None)
-    outs = [int(c) for c in t_out.tolist()]
-    got = []
-    for c in cols:
-        recv = c.new_empty(sum(outs))
-        _a2a(recv, c[order].contiguous(), outs, ins)
-        got.append(recv)
-    return got
+    ins, outs = [int(c) for c in t_in.tolist()], [int(c) for c in t_out.tolist()]
+    if plan is not None and rings.is_cuda:
+        rows = torch.empty((sum(ins), k), dtype=torch.float64, device=dev)
+        cursor = torch.empty(world, dtype=torch.int32, device=dev)
+        start = np.concatenate([[0], np.cumsum(ins)[:-1]]).astype(np.int64)
+        plan.route_fill(n, rings.data_ptr(), ring_bounds, start, [c.data_ptr() for c in cols], cursor.data_ptr(), rows.data_ptr())
+    else:
+        order = torch.argsort(dst, stable=True)
+        rows = torch.stack(cols, dim=1)[src[order]] if n else torch.zeros((0, k), dtype=torch.float64, device=dev)
+    recv = rows.new_empty((sum(outs), k))
+    _a2a(recv.view(-1), rows.contiguous().view(-1), [o * k for o in outs], [i * k for i in ins])
+    return recv.t().contiguous()
 
 
 def band_ring_bounds(cuts, rings_per_band, nside):
@@ -296,7 +321,11 @@ def _hip_reach(runner, plan, my_off):
     all ranks; every rank sets the same value on its plan"""
     import torch
     import torch.distributed as dist
-    m2 = my_off.view(-1, 3).float().square().sum(1).max().reshape(1) if my_off.numel() else my_off.new_zeros(1, dtype=torch.float32)
+    if my_off.is_cuda:
+        m2 = torch.empty(1, dtype=torch.float32, device=my_off.device)
+        plan.max_offset2(my_off.data_ptr(), my_off.numel() // 3, m2.data_ptr(), acc_f64=(my_off.dtype == torch.float64))
+    else:
+        m2 = my_off.view(-1, 3).float().square().sum(1).max().reshape(1) if my_off.numel() else my_off.new_zeros(1, dtype=torch.float32)
     if dist.get_backend() == 'gloo' and m2.is_cuda:
         m2 = m2.cpu()
     dist.all_reduce(m2, op=dist.ReduceOp.MAX)
@@ -316,7 +345,7 @@ def _hip_regrid_slice(runner, plan, off_apron, olo, ohi, b0, b1, p0, p1, device)
     return out, pix, val, sums.cpu().numpy()
 
 
-def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid=None, exchange='slices', bounds=None,
+def distributed_process(runner, kind, seed=42, device=None, compute=None, regrid=None, exchange='spatial', bounds=None,
                         regrid_slice=None, result='root', reach=None, compute_spatial=None):
     """Run `runner` (holding the FULL catalog on every rank) halo-sharded over the ranks of the default
     torch.distributed group.  Returns the final map on rank 0 (`result='root'`; None elsewhere) or on every rank

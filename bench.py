@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--table', choices=['closed-form', 's19'], default='closed-form',
                     help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
                          "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
-    ap.add_argument('--exchange', choices=['slices', 'reduce'], default='slices',
+    ap.add_argument('--exchange', choices=['spatial', 'slices', 'reduce'], default='spatial',
                     help="N > 1: 'slices' = all_to_all reduce-scatter by pixel slices + banded regrid + windows to rank 0 (default); "
                          "'reduce' = one reduce(sum) of the whole accumulator to rank 0")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -421,14 +421,24 @@ def main():
     d_fin = torch.zeros(npix if ((world > 1 or force_x) and rank == 0) else 0, dtype=torch.float64, device=dev)
     d_foreign = torch.zeros(1, dtype=torch.int64, device=dev)          # far deposits that belong to another rank's slice
     route_far = [False]                # set (on every rank) when the untimed trial step finds such deposits
-    if slices:
-        from baryonification_amd.utils.Parallelize import _hip_reach, band_partition, gather_slices, halo_exchange, sliced_reduce
+    spatial = (world > 1 or force_x) and args.exchange == 'spatial' and args.algo == 1
+    if slices or spatial:
+        from baryonification_amd.utils.Parallelize import (_hip_reach, band_partition, band_ring_bounds, gather_slices, halo_exchange,
+                                                           route_halos, sliced_reduce)
         first = plan.bands()
         cuts = band_partition(first, world)
         pb = first[cuts]
         needs = [plan.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
         p0, p1 = int(pb[rank]), int(pb[rank + 1])
         d_slice = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
+    if spatial:
+        # spatial sharding: the halos this rank holds (its chunk of the catalog) are routed to the ranks whose ring bands their discs
+        # can touch; every rank then computes ITS pixels only -- no accumulator crosses a link
+        rb = band_ring_bounds(cuts, plan.tile_shape()[0], nside)
+        cap = 2 * int(np.ceil(total_halos / world)) + 4096
+        plan_sp = engine.ShellPlan(model, keep, nside, cap, device=local_rank, stream=stream)
+        d_rings = torch.empty((nh, 2), dtype=torch.int32, device=dev)
+        cols_local = [t[k] for k in ('M', 'z', 'ra', 'dec', 'lnz', 'lnM')]
 
     def run_steps(acc_f64):
         """returns a closure doing one full pass of the hot path with the given accumulator type"""
@@ -452,7 +462,41 @@ def main():
                     if rank == 0:
                         d_out.copy_(h_out)
 
+        def step_spatial():
+            plan_sp.disc_rings(cat_dev, d_rings.data_ptr())
+            got = route_halos(cols_local, d_rings, rb, plan=plan_sp)           # [6][n]: the halos whose discs can touch my ring bands
+            n = int(got.shape[1])
+            assert n <= cap, "rank %d received %d halos, more than the plan holds (%d): a strongly clustered sky" % (rank, n, cap)
+            cd = _lib.make_catalog_dev(n, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
+                                       ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
+            b0, b1 = int(cuts[rank]), int(cuts[rank + 1])
+            if paint:
+                plan_sp.paint_bands(cd, b0, b1, d_slice.data_ptr(), acc_f64=True)
+                gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
+                return
+            my_off = d_off[:(p1 - p0) * 3]
+            plan_sp.offsets_bands(cd, b0, b1, my_off.data_ptr(), acc_f64=acc_f64)
+            if dist.is_initialized():
+                _hip_reach(None, plan_sp, my_off)          # collective: rings of apron from the largest |offset|
+            nd = [plan_sp.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
+            off_apron = halo_exchange(my_off, pb, nd, 3)
+            plan_sp.regrid_bands(b0, b1, d_map.data_ptr(), off_apron.data_ptr(), nd[rank][0], nd[rank][1], d_slice.data_ptr(), d_sums.data_ptr(),
+                                 acc_f64=acc_f64)
+            if route_far[0]:
+                fp, fv = plan_sp.far_fetch()
+                lists = [None] * world
+                dist.all_gather_object(lists, (fp, fv))
+                for qp, qv in lists:
+                    m = (qp >= p0) & (qp < p1)
+                    if m.any():
+                        d_slice.index_add_(0, torch.from_numpy(qp[m] - p0).to(dev), torch.from_numpy(qv[m]).to(dev))
+            else:
+                plan_sp.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
+            gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
+
         def step():
+            if spatial:
+                return step_spatial()
             if paint:
                 return step_paint()
             if args.algo == 0:
@@ -505,15 +549,16 @@ def main():
         torch.cuda.synchronize()
 
     def timed(step, steps, events):
-        plan.timing_enable(events)
+        tp = plan_sp if spatial else plan            # the plan whose kernels run in the step
+        tp.timing_enable(events)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         fence()
         el = time.perf_counter() - t0
-        kt = plan.timing_read() if events else None
-        plan.timing_enable(False)
+        kt = tp.timing_read() if events else None
+        tp.timing_enable(False)
         if world > 1:
             te = torch.tensor([el], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -521,7 +566,7 @@ def main():
         return el, kt
 
     step = run_steps(args.acc_f64)
-    if slices:
+    if slices or spatial:
         # one untimed trial of the slice exchange; the ranks AGREE on whether it worked (a failure on one rank only -- out of
         # memory, an overflowing entry list -- must not leave the others in a different collective)
         ok = 1
@@ -541,7 +586,7 @@ def main():
         if not ok:
             if rank == 0:
                 print("bench: falling back to --exchange reduce on every rank", file=sys.stderr, flush=True)
-            slices = False
+            slices = spatial = False
             step = run_steps(args.acc_f64)
         elif not paint:
             # did a far deposit land in another rank's slice?  then every step routes the lists (collective decision)
@@ -560,8 +605,8 @@ def main():
     # the same K steps again with HIP events around every kernel on the launch stream (bfgx_plan_timing_*): kernel_ms, roofline
     elapsed_ev, kt = timed(step, args.steps, True) if not args.no_kernel_events else (None, None)
     if os.environ.get('BFGX_BENCH_NOSTATUS') != '1':   # (timing-only ablation builds produce meaningless offsets)
-        plan.status()                          # entry-list capacity, far-deposit list
-    if slices and not paint:
+        (plan_sp if spatial else plan).status()   # entry-list capacity, far-deposit list
+    if (slices or spatial) and not paint:
         assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
 
     extra = {}
@@ -579,7 +624,7 @@ def main():
         # the drop-in call from numpy arrays (BaryonifyShell.process(): PCIe both ways, plan cache warm after the first call)
         extra["end_to_end"] = end_to_end(args, cat, hmap, z, M, r, table)
 
-    if slices and not paint and dist.is_initialized():
+    if (slices or spatial) and not paint and dist.is_initialized():
         # a rank's sums are {its source pixels, the deposits that landed in ITS slice + the far ones it listed}: only the totals match
         tot = d_sums.clone() if backend == 'nccl' else d_sums.cpu()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -605,7 +650,10 @@ def main():
                        "halos_per_gpu": nh, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
                        "parallelism": ("single GPU" if world == 1 else
-                                       "halo shards x%d + RCCL all_to_all reduce-scatter by pixel slices, one-ring halo exchange, banded gathering regrid on "
+                                       "spatial sharding x%d: halos routed (RCCL all_to_all of catalog columns) to the ranks whose ring bands their discs "
+                                       "touch, every rank computes and regrids its own pixels (apron rings exchanged), disjoint slices -> rank 0" % world
+                                       if spatial else
+                                       "halo shards x%d + RCCL all_to_all reduce-scatter by pixel slices, apron-ring exchange, banded gathering regrid on "
                                        "every rank, disjoint slices -> rank 0" % world
                                        if slices else "halo shards x%d + RCCL reduce(accumulator) -> rank 0" % world)},
             "map_pixels_per_s": npix / elapsed * args.steps,
@@ -621,6 +669,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
         print(json.dumps(out), flush=True)
     plan.close()
+    if 'plan_sp' in locals():
+        plan_sp.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

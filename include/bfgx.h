@@ -200,6 +200,8 @@ int  bfgx_baryonify_device(bfgx_plan *p, const bfgx_catalog *cat_dev, const doub
  * buffers: count only) so that the caller can add them to whichever rank's slice holds the pixel.  (bfgx_regrid_device
  * sizes its aprons tile by tile from the data, applies its own list, and repairs an overflowing list in-stream.) */
 int  bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel);
+/* *out_dev (float, device) = largest |offset|^2 of npixels pixels of pix_offsets (enqueue-only): what the ranks all-reduce (MAX) */
+int  bfgx_max_offset2_device(bfgx_plan *p, const void *offsets_dev, int64_t npixels, int acc_f64, float *out_dev);
 int  bfgx_plan_reach_rings(bfgx_plan *p, double max_offset, int32_t *rings);
 int  bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings);
 int  bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *olo, int64_t *ohi);
@@ -216,6 +218,14 @@ int  bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0,
  * clipped.  No accumulator travels between the ranks; the regrid then needs the neighbours' apron rings as above. */
 int  bfgx_plan_tile_shape(bfgx_plan *p, int32_t *rings_per_band, int32_t *max_columns);     /* band b = rings [1 + b R, 1 + (b + 1) R) */
 int  bfgx_disc_rings_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t *rings_dev /* [n][2]; n may exceed the plan's max_halos */);
+/* Routing of halos that start out scattered over the ranks: ring_bounds[j] (host, world + 1 ascending entries) = first ring of rank
+ * j's run of bands; a halo goes to every rank whose rings its range [first, last] (rings_dev, bfgx_disc_rings_device) touches.
+ * Pass 1 counts the halos per destination (counts_dev[world]); the caller forms the exclusive prefix `start` (host) and exchanges the
+ * counts; pass 2 packs the rows (ncols doubles per halo, from the ncols device columns cols_dev[]) into rows_dev, destination by
+ * destination, ready for ONE all_to_all.  cursor_dev: int32[world] scratch.  At most 64 ranks, 8 columns. */
+int  bfgx_route_count_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, int32_t *counts_dev);
+int  bfgx_route_fill_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, const int64_t *start,
+                            int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *rows_dev);
 int  bfgx_offsets_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t band0, int32_t band1, void *offsets_slice_dev, int acc_f64);
 int  bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t band0, int32_t band1, void *map_slice_dev, int acc_f64);
 /* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */

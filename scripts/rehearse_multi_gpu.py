@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Functional rehearsal of the N > 1 product path on a ONE-GPU box: every rank uses device 0, the process group is
 gloo and utils/Parallelize stages its all_to_all steps through the host.  Checks that
-distributed_process(runner, ...) with the HIP engine (halo shards -> sliced reduce-scatter -> one-ring halo exchange -> banded gathering regrid -> disjoint slices to
-rank 0) returns what a single-process runner.process() returns.  Launch:
+distributed_process(runner, ...) with the HIP engine -- exchange='slices' (halo shards -> sliced reduce-scatter -> apron exchange -> banded
+gathering regrid -> disjoint slices to rank 0) and exchange='spatial' (every rank takes the halos of its ring bands, no accumulator travels) --
+returns what a single-process runner.process() returns.  Launch:
 
     GLOO_SOCKET_IFNAME=lo python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29577 scripts/rehearse_multi_gpu.py
 """
@@ -41,16 +42,17 @@ def main():
             model = bfg.utils.TabulatedProfile(None, cosmo)
             model.set_table(z, M, r, syn.paint_table(z, M, r))
             runner = bfg.Runners.PaintProfilesShell(Catalog, Shell, 10.0, model, verbose=False)
-        out = distributed_process(runner, kind, device=0, exchange='slices')
-        if rank == 0:
-            ref = runner.process()
-            tol = 1e-6 * ref.mean() if kind == 'baryonify' else 1e-10 * np.abs(ref).max()     # f32 pix_offsets / f64 painting
-            err = np.abs(out - ref).max()
-            print("rehearsal %-9s world=%d nside=%d halos=%d  max|distributed - single| = %.3e (tol %.1e)  %s" % (
-                kind, world, nside, nh, err, tol, 'OK' if err <= tol else 'FAIL'), flush=True)
-            ok = ok and err <= tol
-        else:
-            assert out is None
+        ref = runner.process() if rank == 0 else None
+        for exchange in ('slices', 'spatial'):
+            out = distributed_process(runner, kind, device=0, exchange=exchange)
+            if rank == 0:
+                tol = 1e-6 * ref.mean() if kind == 'baryonify' else 1e-10 * np.abs(ref).max()     # f32 pix_offsets / f64 painting
+                err = np.abs(out - ref).max()
+                print("rehearsal %-9s %-7s world=%d nside=%d halos=%d  max|distributed - single| = %.3e (tol %.1e)  %s" % (
+                    kind, exchange, world, nside, nh, err, tol, 'OK' if err <= tol else 'FAIL'), flush=True)
+                ok = ok and err <= tol
+            else:
+                assert out is None
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

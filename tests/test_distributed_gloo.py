@@ -92,6 +92,15 @@ def _oracle_regrid_slice(runner, ctx, off_apron, olo, ohi, b0, b1, p0, p1, devic
     return torch.from_numpy(sl), np.zeros(0, dtype=np.int64), np.zeros(0), np.array([g['map_in'][p0:p1].sum(), sl.sum()])
 
 
+def _oracle_compute_spatial(runner, kind, cols, device, world, rank):
+    """exchange='spatial' with the oracle: the rank's own pixels of the full-catalog result (which halos a rank takes is the HIP
+    side's business, tests/test_gpu_fullsize.py::test_band_restricted_pass_with_selected_halos_equals_full_pass)"""
+    acc, _ = _oracle_compute(runner, kind, cols, device)
+    cuts, pb, _ = _oracle_bounds(runner, None, world)
+    w = 3 if kind == 'baryonify' else 1
+    return acc[int(pb[rank]) * w:int(pb[rank + 1]) * w].clone(), None
+
+
 def _worker(rank, world, port, name, out_path, exchange='slices', result='root'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -102,7 +111,8 @@ def _worker(rank, world, port, name, out_path, exchange='slices', result='root')
         runner._golden = g
         kind = 'baryonify' if g['kind'] == 'baryonify' else 'paint'
         out = distributed_process(runner, kind, seed=42, device=rank, compute=_oracle_compute, regrid=_oracle_regrid, exchange=exchange,
-                                  bounds=_oracle_bounds, regrid_slice=_oracle_regrid_slice, result=result)
+                                  bounds=_oracle_bounds, regrid_slice=_oracle_regrid_slice, result=result,
+                                  compute_spatial=_oracle_compute_spatial)
         if result == 'all':
             np.save(out_path + '.%d.npy' % rank, out)            # every rank holds the map
         elif rank == 0:
@@ -119,7 +129,13 @@ def _failing_compute(runner, kind, cols, device):
     return _oracle_compute(runner, kind, cols, device)
 
 
-def _worker_one_rank_fails(rank, world, port, name, out_path):
+def _failing_compute_spatial(runner, kind, cols, device, world, rank):
+    if rank == 1:
+        raise MemoryError("rank 1 ran out of device memory")
+    return _oracle_compute_spatial(runner, kind, cols, device, world, rank)
+
+
+def _worker_one_rank_fails(rank, world, port, name, out_path, exchange='slices'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -128,8 +144,8 @@ def _worker_one_rank_fails(rank, world, port, name, out_path):
         runner = product_runner(g)
         runner._golden = g
         try:
-            distributed_process(runner, 'baryonify', seed=42, device=rank, compute=_failing_compute, bounds=_oracle_bounds,
-                                regrid_slice=_oracle_regrid_slice)
+            distributed_process(runner, 'baryonify', seed=42, device=rank, compute=_failing_compute, bounds=_oracle_bounds, exchange=exchange,
+                                regrid_slice=_oracle_regrid_slice, compute_spatial=_failing_compute_spatial)
             raised = 'none'
         except MemoryError:
             raised = 'own'
@@ -162,7 +178,7 @@ def test_band_partition_balances_pixels():
         assert abs(share.sum() - 1) < 1e-15 and np.all(np.abs(share - 1 / world) < 0.35 / world + 8 * 4 * nside / first[-1])
 
 
-@pytest.mark.parametrize('world,exchange', [(2, 'slices'), (3, 'slices'), (2, 'reduce')])
+@pytest.mark.parametrize('world,exchange', [(2, 'slices'), (3, 'slices'), (2, 'reduce'), (2, 'spatial'), (4, 'spatial')])
 @pytest.mark.parametrize('name', ['lowz_baryonify', 'lowz_paint'])
 def test_multi_rank_gloo_equals_single_process(tmp_path, name, world, exchange):
     with socket.socket() as s:
@@ -202,12 +218,67 @@ def test_eight_rank_slice_exchange_both_runners(tmp_path, name):
         assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
-def test_one_failing_rank_raises_on_every_rank(tmp_path):
+@pytest.mark.parametrize('exchange', ['slices', 'spatial'])
+def test_one_failing_rank_raises_on_every_rank(tmp_path, exchange):
     """a rank that fails before a collective must not leave its peers blocked in it: all ranks raise"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     out_path = str(tmp_path / 'flag')
-    mp.spawn(_worker_one_rank_fails, args=(3, port, 'lowz_baryonify', out_path), nprocs=3, join=True)
+    mp.spawn(_worker_one_rank_fails, args=(3, port, 'lowz_baryonify', out_path, exchange), nprocs=3, join=True)
     got = [open(out_path + '.%d.txt' % r).read() for r in range(3)]
     assert got == ['peer', 'own', 'peer']
+
+
+def _worker_route(rank, world, port, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from baryonification_amd.utils.Parallelize import route_halos
+        rng = np.random.default_rng(100 + rank)
+        n = 5000 + 100 * rank
+        first = rng.integers(1, 400, n)
+        last = np.minimum(first + rng.integers(0, 30, n), 399)
+        first[:5], last[:5] = 1, 399                                    # every rank
+        first[5:9], last[5:9] = 50, 49                                  # nobody
+        ident = (rank * 1_000_000 + np.arange(n)).astype(np.float64)
+        cols = [torch.from_numpy(ident), torch.from_numpy(rng.normal(size=n)), torch.from_numpy(first.astype(np.float64)), torch.from_numpy(last.astype(np.float64))]
+        bounds = np.linspace(1, 400, world + 1).astype(np.int64)
+        got = route_halos(cols, torch.from_numpy(np.stack([first, last], axis=1).astype(np.int32)), bounds)
+        np.save(out_path + '.%d.npy' % rank, got.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_route_halos_gloo_every_halo_reaches_every_rank_it_touches(tmp_path):
+    """spatial sharding of scattered halos (torch path of route_halos): rank j receives exactly the halos, from all ranks, whose
+    ring range touches its rings"""
+    world = 3
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / 'route')
+    mp.spawn(_worker_route, args=(world, port, out_path), nprocs=world, join=True)
+    bounds = np.linspace(1, 400, world + 1).astype(np.int64)
+    got = [np.load(out_path + '.%d.npy' % r) for r in range(world)]
+    total = 0
+    for j in range(world):
+        g = got[j]
+        assert g.shape[0] == 4
+        first, last = g[2], g[3]
+        assert np.all((first < bounds[j + 1]) & (last >= bounds[j]) & (first <= last))         # only halos that touch my rings
+        assert np.unique(g[0]).size == g.shape[1]                                               # each once
+        total += g.shape[1]
+    # nothing is lost: regenerate the inputs and count the (halo, rank) incidences
+    want = 0
+    for rank in range(world):
+        rng = np.random.default_rng(100 + rank)
+        n = 5000 + 100 * rank
+        first = rng.integers(1, 400, n)
+        last = np.minimum(first + rng.integers(0, 30, n), 399)
+        first[:5], last[:5] = 1, 399
+        first[5:9], last[5:9] = 50, 49
+        for j in range(world):
+            want += int(((first < bounds[j + 1]) & (last >= bounds[j]) & (first <= last)).sum())
+    assert total == want

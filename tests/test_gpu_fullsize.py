@@ -461,3 +461,43 @@ def test_band_restricted_pass_with_selected_halos_equals_full_pass(gpu, paint):
             assert (sl - ref).abs().max().item() <= (1e-12 if paint else 2e-6) * full.abs().max().item()
         assert N <= taken <= 1.5 * N                                        # boundary halos go to two ranks, nothing is lost
     plan.close()
+
+
+def test_route_kernels_pack_every_halo_for_every_rank_it_touches(gpu):
+    """bfgx_route_count_device / bfgx_route_fill_device (spatial sharding of scattered halos): per destination rank the packed rows
+    are exactly the halos whose ring range touches that rank's rings -- incl. halos that go to several ranks and to none"""
+    import torch
+    from baryonification_amd import engine, synthetic as syn
+    dev = torch.device('cuda:0')
+    n, world, nside = 300_000, 5, 512
+    rng = np.random.default_rng(3)
+    first = rng.integers(1, 4 * nside, n)
+    last = np.minimum(first + rng.integers(0, 40, n), 4 * nside - 1)
+    last[:50] = 4 * nside - 1; first[:50] = 1                              # discs over the whole sky: every rank
+    first[50:80] = 100; last[50:80] = 99                                    # touch nothing
+    bounds = np.array([1, 300, 700, 1024, 1500, 4 * nside], dtype=np.int64)
+    cols = [torch.from_numpy(rng.normal(size=n)).to(dev) for _ in range(6)]
+    cols[0] = torch.arange(n, dtype=torch.float64, device=dev)             # column 0 = halo number: identifies the row
+    rings = torch.from_numpy(np.stack([first, last], axis=1).astype(np.int32)).to(dev)
+    cat = syn.make_catalog(1000)
+    z, M, r = syn.table_grid(cat)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
+    plan = engine.ShellPlan(model, keep, nside, 1000, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    plan.route_count(n, rings.data_ptr(), bounds, counts.data_ptr())
+    c = counts.cpu().numpy().astype(np.int64)
+    want = [np.nonzero((first < bounds[j + 1]) & (last >= bounds[j]) & (first <= last))[0] for j in range(world)]
+    assert np.array_equal(c, [w.size for w in want]) and c.sum() > n
+    start = np.concatenate([[0], np.cumsum(c)[:-1]])
+    rows = torch.full((int(c.sum()), 6), float('nan'), dtype=torch.float64, device=dev)
+    cursor = torch.empty(world, dtype=torch.int32, device=dev)
+    plan.route_fill(n, rings.data_ptr(), bounds, start, [x.data_ptr() for x in cols], cursor.data_ptr(), rows.data_ptr())
+    got = rows.cpu().numpy()
+    host = np.stack([x.cpu().numpy() for x in cols], axis=1)
+    assert np.isfinite(got).all()
+    for j in range(world):
+        blk = got[start[j]:start[j] + c[j]]
+        ids = blk[:, 0].astype(np.int64)
+        assert np.array_equal(np.sort(ids), want[j])                       # the right halos, each once
+        assert np.array_equal(blk, host[ids])                               # whole rows travel together
+    plan.close()
