@@ -11,7 +11,12 @@ out = sys.argv[1]
 
 def short(name):
     """kernel name as the summaries print it"""
-    tags = (('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
+    tags = (('grid_regrid_kernel', 'grid_regrid'), ('grid_scatter_kernel', 'grid_scatter'), ('grid_prep_kernel', 'grid_prep'),
+            ('snap_displace_kernel', 'snap_displace'), ('snap_halo_prep_kernel', 'snap_halo_prep'),
+            ('deposit_keys_kernel', 'deposit_keys'), ('deposit_split_kernel<1', 'deposit_split<1>'), ('deposit_split_kernel<2', 'deposit_split<2>'),
+            ('deposit_count_kernel', 'deposit_count'), ('deposit_tiles_kernel', 'deposit_tiles'), ('fft_c2c_strided_kernel', 'fft_c2c_strided'),
+            ('fft_r2c_lines_kernel', 'fft_r2c_lines'), ('pk_bin_kernel', 'pk_bin'),
+            ('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
             ('halo_prep_kernel', 'halo_prep'), ('halo_scatter_kernel', 'halo_scatter'), ('regrid_far_kernel', 'regrid_far'),
             ('regrid_kernel', 'regrid(algo0)'), ('sum2_kernel', 'sum2'), ('sum_tiles_kernel', 'sum_tiles'), ('tile_scan_kernel', 'tile_scan'),
             ('tile_place_kernel', 'tile_place'), ('tile_reach_kernel', 'tile_reach'), ('tile_apron_kernel', 'tile_apron'))
