@@ -39,6 +39,7 @@ template <typename T> static inline hipError_t bfgx_counted_malloc(T **p, size_t
 #include "bfgx_fft.hpp"
 #include "bfgx_snapshot.hpp"
 #include "bfgx_deposit.hpp"
+#include "bfgx_grid_gather.hpp"
 #include "bfgx_fftlog.hpp"
 
 using namespace bfgx;

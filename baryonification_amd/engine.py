@@ -225,6 +225,15 @@ class GridPlan(object):
         _lib.check(_lib.load().bfgx_grid_regrid_device(self._h, C.c_void_p(int(map_in_ptr)), C.c_void_p(int(offsets_ptr)),
                                                       C.c_void_p(int(map_out_ptr)), C.c_void_p(int(sums_ptr) or None)))
 
+    def baryonify(self, cat_dev, map_in_ptr, map_out_ptr, sums_ptr=0):
+        """BaryonifyGrid.process() on device arrays as one cell-owned pass (no pix_offsets array): halos listed per block of cells,
+        every cell sums its offsets in registers and is regridded at once.  Same map_out as offsets() + regrid() up to the order
+        of fp64 sums.  Returns the number of contributing (halo, pixel) pairs."""
+        n = C.c_int64(0)
+        _lib.check(_lib.load().bfgx_grid_baryonify_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_in_ptr)), C.c_void_p(int(map_out_ptr)),
+                                                         C.c_void_p(int(sums_ptr) or None), C.byref(n)))
+        return int(n.value)
+
     def set_slab(self, plane_lo, plane_n):
         """slab decomposition over GPUs: this plan owns the planes [plane_lo, plane_lo + plane_n) of the first array axis;
         offsets() / paint() then fill plane_n x npix (x npix) cells (pass the whole catalog), regrid_slab() regrids them"""

@@ -279,11 +279,15 @@ def main_grid(args):
         if rank == 0:
             timed('deposit', lambda: engine.deposit_particles_device(part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), 0, npart, N,
                                                                      d_edges.data_ptr(), d_map.data_ptr(), 3, local_rank, stream))
-        pairs[0] = plan.offsets(cat_dev, d_off.data_ptr())
-        if world > 1:
+        if world == 1:
+            # halo loop + regrid as one cell-owned pass: no pix_offsets array
+            pairs[0] = plan.baryonify(cat_dev, d_map.data_ptr(), d_out.data_ptr(), d_sums.data_ptr())
+        else:
+            pairs[0] = plan.offsets(cat_dev, d_off.data_ptr())
             dist.reduce(d_off, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr())
         if rank == 0:
-            plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr())
             timed('pk', lambda: engine.power_spectrum_device(d_out.data_ptr(), N, L, Nk, d_work.data_ptr(), d_pk.data_ptr(),
                                                              d_ks.data_ptr(), d_cnt.data_ptr(), local_rank, stream))
 

@@ -353,6 +353,12 @@ int  bfgx_grid_regrid_device(bfgx_grid_plan *p, const double *map_in_dev, const 
 int  bfgx_grid_plan_set_slab(bfgx_grid_plan *p, int32_t plane_lo, int32_t plane_n);
 int  bfgx_grid_regrid_slab_device(bfgx_grid_plan *p, const double *map_in_dev, const double *offsets_dev, int32_t apron,
                                   double *map_out_dev, double *sums_dev, int32_t *missed_dev);
+/* BaryonifyGrid.process() on device arrays, single GPU: the halo loop (Map2DRunner.py:476-575) and the regrid (:577-605) as ONE
+ * cell-owned pass -- halos are listed per block of cells, every cell sums its offsets in registers and is regridded at once, so no
+ * pix_offsets array exists.  map_out [npix^ndim] is zeroed by the call; sums_dev [2] (optional, zeroed by the caller) receives
+ * {sum(map_in), sum(map_out)}.  Same result as bfgx_grid_offsets_device + bfgx_grid_regrid_device up to the order of fp64 sums. */
+int  bfgx_grid_baryonify_device(bfgx_grid_plan *p, const bfgx_grid_catalog *cat_dev, const double *map_in_dev, double *map_out_dev,
+                                double *sums_dev, int64_t *n_pairs_host);
 int  bfgx_grid_plan_timing_enable(bfgx_grid_plan *p, int on);
 int  bfgx_grid_plan_timing_read(bfgx_grid_plan *p, double *ms_sum, int64_t *launches);
 /* device-resident variants of the two deposit kernels and the P(k) summary (all pointers device) */

@@ -240,6 +240,65 @@ def test_grid_plan_resident_path(gpu):
     plan.close()
 
 
+@pytest.mark.parametrize('ndim,N,nh', [(3, 64, 800), (3, 64, 12), (2, 128, 300), (2, 250, 9), (3, 61, 500), (3, 32, 0)])
+def test_grid_cell_owned_pass(gpu, ndim, N, nh):
+    """bfgx_grid_baryonify_device (halos listed per block of cells, offsets summed in registers, no pix_offsets array)
+    == bfgx_grid_offsets_device + bfgx_grid_regrid_device; grids that are not a multiple of the block size; list regrowth"""
+    import torch
+    from baryonification_amd import _lib, engine
+    c = _big_case(ndim, N, max(nh, 1), 17)
+    cat = {k: v[:nh] for k, v in c['cat'].items()}
+    cos = dict(c['cosmo'], w0=-1.0)
+    m, keep = engine.model_from_tables([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], c['d'], cos, 6.0, 8.0)
+    dev = torch.device('cuda:0')
+    t = {k: torch.tensor(cat[k], dtype=torch.float64, device=dev) for k in ('M', 'x', 'y', 'z')}
+    lnM = torch.tensor(np.log(cat['M'].astype(np.float32)).astype(np.float64), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = engine.GridPlan(m, keep, c['bins'], ndim, c['redshift'], max(nh, 1), 0, stream)
+    dcat = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr() if ndim == 3 else 0,
+                                      lnM.data_ptr())
+    off = torch.empty((N ** ndim, ndim), dtype=torch.float64, device=dev)
+    m_in = torch.tensor(c['map'], device=dev)
+    ref, out = torch.empty_like(m_in), torch.full_like(m_in, float('nan'))
+    s_ref, s_out = (torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(2))
+    n_ref = plan.offsets(dcat, off.data_ptr())
+    plan.regrid(m_in.data_ptr(), off.data_ptr(), ref.data_ptr(), s_ref.data_ptr())
+    n_out = plan.baryonify(dcat, m_in.data_ptr(), out.data_ptr(), s_out.data_ptr())
+    torch.cuda.synchronize()
+    a, b = ref.cpu().numpy(), out.cpu().numpy()
+    assert n_out == n_ref and (n_ref > 0) == (nh > 0)
+    assert np.isfinite(b).all() and np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    assert np.allclose(s_out.cpu().numpy(), s_ref.cpu().numpy(), rtol=1e-12, atol=0)
+    if nh:
+        assert not np.array_equal(a, c['map'])
+        os.environ['BFGX_GRID_ITEM_CAP'] = '5'                           # block lists start too small and are regrown
+        try:
+            small = engine.GridPlan(m, keep, c['bins'], ndim, c['redshift'], nh, 0, stream)
+            out.fill_(float('nan'))
+            assert small.baryonify(dcat, m_in.data_ptr(), out.data_ptr()) == n_ref
+            torch.cuda.synchronize()
+            assert np.abs(a - out.cpu().numpy()).max() <= 1e-12 * np.abs(a).max()
+            small.close()
+        finally:
+            del os.environ['BFGX_GRID_ITEM_CAP']
+    plan.close()
+
+
+def test_grid_one_shot_scatter_path(gpu):
+    """BFGX_GRID_PATH=scatter: the one-shot API through the halo-owned kernels (pix_offsets array + regrid, what the slab and
+    multi-GPU entry points run) == the default cell-owned pass == the committed golden"""
+    for name in ('grid3d_baryonify', 'grid2d_baryonify'):
+        c = H.load_grid_golden(name)
+        base = H.grid_product_runner(c).process()
+        os.environ['BFGX_GRID_PATH'] = 'scatter'
+        try:
+            again = H.grid_product_runner(c).process()
+        finally:
+            del os.environ['BFGX_GRID_PATH']
+        assert np.abs(again - base).max() <= 1e-12 * np.abs(base).max()
+        assert np.abs(again - c['expected']).max() <= 1e-10 * np.abs(c['expected']).max()
+
+
 def test_grid_edge_cases(gpu):
     """empty catalog, a single halo whose cutout is clipped to half the box, an all-zero map"""
     import baryonification_amd as bfg
