@@ -2,12 +2,14 @@
 // cells 12 + 15: np.fft.fftn -> |F|^2 -> np.bincount in linear k-bins) for gfx950.
 //
 // The map is real, so only the kz <= N/2 half of the spectrum is computed (r2c along the contiguous axis, then two
-// in-place c2c passes along the strided axes); the mirrored half enters the bin sums through a weight of 2.
+// complex passes along the strided axes); the mirrored half enters the bin sums through a weight of 2.
 // Every 1-D transform runs in LDS: decimation in time, bit-reversed on the way in, two radix-2 stages fused per
-// barrier (radix-4 data movement), twiddles from a host-built fp64 table; the r2c pass packs two real lines into one
-// complex transform.  The strided passes move tiles of kFftTile lines that
-// are adjacent in memory, so that global accesses stay contiguous (tile * 16 B) and LDS accesses conflict-free
-// (line index fastest).  N must be a power of two, 8 <= N <= 1024.
+// barrier (radix-4 data movement), twiddles from a host-built fp64 table (copied to LDS in the strided passes); the r2c
+// pass packs two real lines into one complex transform.  Rows of the half spectrum are padded to whole 128-byte lines
+// (fft_pitch); the strided passes move tiles of 4 (or 8) lines that are adjacent in memory, so that global accesses stay
+// contiguous and LDS accesses conflict-free (line index fastest).  The LAST pass writes nothing back: the transformed tile is
+// binned from LDS (|F|^2, |k|, counts per linear k-bin), so the spectrum crosses HBM 5 times instead of 8.
+// N must be a power of two, 8 <= N <= 1024.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,7 +18,7 @@
 namespace bfgx {
 
 constexpr int kFftBlock = 256;
-constexpr int kFftTile = 4;           // lines per workgroup in the strided passes (measured best of 1..16 at 512^3; BFGX_FFT_TILE overrides)
+constexpr int kFftTileLog2 = 2;       // 1 << this = lines per workgroup in the strided passes (BFGX_FFT_TILE = 4 | 8 overrides)
 
 __device__ inline int bit_reverse(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
 
@@ -70,7 +72,7 @@ __device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2
 // lines a, b as the single complex sequence a + i b and separates the spectra afterwards:
 //   A_k = (Z_k + conj(Z_{N-k})) / 2,   B_k = (Z_k - conj(Z_{N-k})) / (2i).
 __global__ void __launch_bounds__(kFftBlock)
-fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, int N, int log2n, const double2 *__restrict__ tw)
+fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, int N, int log2n, const double2 *__restrict__ tw, int pitch)
 {
     extern __shared__ double2 fbuf[];
     const int64_t line = 2 * (int64_t)blockIdx.x;
@@ -78,7 +80,7 @@ fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, 
     for (int i = threadIdx.x; i < N; i += kFftBlock) fbuf[bit_reverse(i, log2n)] = make_double2(sa[i], sb[i]);
     lds_fft_stages(fbuf, N, 1, tw);
     const int nz = (N >> 1) + 1;
-    double2 *da = out + line * nz, *db = da + nz;
+    double2 *da = out + line * pitch, *db = da + pitch;                  // rows of `pitch` >= nz complex values
     for (int k = threadIdx.x; k < nz; k += kFftBlock) {
         const double2 z = fbuf[k], zc = fbuf[(N - k) & (N - 1)];    // Z_{N-k}, with Z_N = Z_0
         da[k] = make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
@@ -86,60 +88,124 @@ fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, 
     }
 }
 
-// passes 2 and 3: in-place complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
-// data[o * outer_stride + i * stride + kz0 + l]; blockIdx.x = kz tile, blockIdx.y = o.
-__global__ void __launch_bounds__(kFftBlock)
-fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
-                       const double2 *__restrict__ tw, int tile)
+// what the fused last pass needs to bin |F|^2 (pk_bin_kernel's arguments)
+struct PkBins {
+    const double *klin;
+    double kb0, dk;
+    int nk, b0;
+    double *pk_sum, *k_sum;
+    unsigned long long *counts;
+};
+
+// one |F|^2 sample into the LDS histogram: k = sqrt(klin[a]^2 + klin[c]^2 + klin[b]^2) (the notebook's summation order),
+// bin = floor((k - kb0) / dk); the c-mirrored half of the spectrum counts through a weight of 2
+__device__ inline void pk_bin_sample(const PkBins &pb, int N, int a, int b, int c, double2 f, double *hp, double *hk, unsigned long long *hc)
 {
-    extern __shared__ double2 fbuf[];
-    const int kz0 = blockIdx.x * tile;
-    const int nl = min(tile, nz - kz0);
-    double2 *base = data + (int64_t)blockIdx.y * outer_stride + kz0;
-    for (int t = threadIdx.x; t < N * nl; t += kFftBlock) {
-        const int l = t % nl, i = t / nl;
-        fbuf[bit_reverse(i, log2n) * nl + l] = base[(int64_t)i * stride + l];
-    }
-    lds_fft_stages(fbuf, N, nl, tw);
-    for (int t = threadIdx.x; t < N * nl; t += kFftBlock) {
-        const int l = t % nl, i = t / nl;
-        base[(int64_t)i * stride + l] = fbuf[i * nl + l];
-    }
+    const double ka = pb.klin[a], kb = pb.klin[b], kc = pb.klin[c];
+    const double k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
+    const double u = floor((k - pb.kb0) / pb.dk);
+    if (!(u >= 0.0) || !(u < (double)pb.nk)) return;
+    const int bin = (int)u;
+    const double p = f.x * f.x + f.y * f.y;
+    const int mult = (c > 0 && c < (N >> 1)) ? 2 : 1;
+    atomicAdd(hp + bin, mult * p);
+    atomicAdd(hk + bin, mult * k);
+    atomicAdd(hc + bin, (unsigned long long)mult);
 }
 
-// |F|^2, |k| and mode counts per linear k-bin.  F[a][b][c], c <= N/2; k = sqrt(klin[a]^2 + klin[c]^2 + klin[b]^2)
-// (the notebook's summation order); bin = floor((k - kb0) / dk); the c-mirrored half counts through a weight of 2.
-// F may hold only the columns b0 <= b < b0 + nb of the middle axis (slab decomposition after the transpose: [N][nb][nz]).
-__global__ void __launch_bounds__(256)
-pk_bin_kernel(const double2 *__restrict__ F, int N, const double *__restrict__ klin, double kb0, double dk, int nk,
-              double *__restrict__ pk_sum, double *__restrict__ k_sum, unsigned long long *__restrict__ counts, int nb, int b0)
+// passes 2 and 3: complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
+// data[o * outer_stride + i * stride + kz0 + l]; the workgroups stride over the nzt * nouter tiles (kz tile fastest).
+// BIN = false: in place.  BIN = true (last pass of the power spectrum): nothing is written back -- the transformed tile goes
+// straight from LDS into the workgroup's k-bin histogram (the spectrum itself is not an output), which is flushed once at the
+// end; the line index i is then the FIRST array axis and o the column b0 + o of the middle axis.
+// the butterflies of lds_fft_stages for a compile-time number of interleaved lines (1 << LT) and twiddles held in LDS: the index
+// arithmetic is shifts and masks (with a run-time line count it was three quarters of the strided passes' instructions)
+template <int LT>
+__device__ inline void lds_fft_stages_t(double2 *buf, int N, const double2 *tw)
 {
-    extern __shared__ double hist[];                       // [nk] power, [nk] k, then [nk] counts (u64)
-    double *hp = hist, *hk = hist + nk;
-    unsigned long long *hc = reinterpret_cast<unsigned long long *>(hist + 2 * nk);
-    for (int i = threadIdx.x; i < nk; i += blockDim.x) { hp[i] = 0.0; hk[i] = 0.0; hc[i] = 0ull; }
-    __syncthreads();
-    const int nz = (N >> 1) + 1;
-    const int64_t total = (int64_t)N * nb * nz;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(t % nz);
-        const int64_t q = t / nz;
-        const int b = b0 + (int)(q % nb), a = (int)(q / nb);
-        const double ka = klin[a], kb = klin[b], kc = klin[c];
-        const double k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
-        const double u = floor((k - kb0) / dk);
-        if (!(u >= 0.0) || !(u < (double)nk)) continue;
-        const int bin = (int)u;
-        const double2 f = F[t];
-        const double p = f.x * f.x + f.y * f.y;
-        const int mult = (c > 0 && c < (N >> 1)) ? 2 : 1;
-        atomicAdd(hp + bin, mult * p);
-        atomicAdd(hk + bin, mult * k);
-        atomicAdd(hc + bin, (unsigned long long)mult);
+    constexpr int NL = 1 << LT;
+    int m = 1;
+    const int nq = (N >> 2) << LT;
+    for (; 4 * m <= N; m <<= 2) {
+        __syncthreads();
+        const int ts1 = (N >> 1) / m, ts2 = (N >> 2) / m;
+        for (int t = threadIdx.x; t < nq; t += kFftBlock) {
+            const int l = t & (NL - 1), b = t >> LT;
+            const int pos = b & (m - 1);
+            const int p = ((b - pos) << 2) + pos;
+            const double2 w1 = tw[pos * ts1], w2 = tw[pos * ts2];
+            const double2 w3 = make_double2(w2.y, -w2.x);
+            double2 *q = buf + (p << LT) + l;
+            const double2 a0 = q[0], a1 = q[m << LT], a2 = q[(2 * m) << LT], a3 = q[(3 * m) << LT];
+            const double2 t1 = cmul(w1, a1), t3 = cmul(w1, a3);
+            const double2 b0 = make_double2(a0.x + t1.x, a0.y + t1.y), b1 = make_double2(a0.x - t1.x, a0.y - t1.y);
+            const double2 b2 = make_double2(a2.x + t3.x, a2.y + t3.y), b3 = make_double2(a2.x - t3.x, a2.y - t3.y);
+            const double2 u2 = cmul(w2, b2), u3 = cmul(w3, b3);
+            q[0] = make_double2(b0.x + u2.x, b0.y + u2.y);
+            q[(2 * m) << LT] = make_double2(b0.x - u2.x, b0.y - u2.y);
+            q[m << LT] = make_double2(b1.x + u3.x, b1.y + u3.y);
+            q[(3 * m) << LT] = make_double2(b1.x - u3.x, b1.y - u3.y);
+        }
+    }
+    if (m < N) {
+        __syncthreads();
+        const int nb = (N >> 1) << LT;
+        const int tstep = (N >> 1) / m;
+        for (int t = threadIdx.x; t < nb; t += kFftBlock) {
+            const int l = t & (NL - 1), b = t >> LT;
+            const int pos = b & (m - 1);
+            double2 *q = buf + ((((b - pos) << 1) + pos) << LT) + l;
+            const double2 u = q[0], v = cmul(tw[pos * tstep], q[m << LT]);
+            q[0] = make_double2(u.x + v.x, u.y + v.y);
+            q[m << LT] = make_double2(u.x - v.x, u.y - v.y);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nk; i += blockDim.x) {
-        if (hc[i]) { atomicAdd(pk_sum + i, hp[i]); atomicAdd(k_sum + i, hk[i]); atomicAdd(counts + i, hc[i]); }
+}
+
+// LDS of one workgroup of the strided passes: the tile, the twiddles, (BIN) the histogram
+__host__ __device__ inline size_t fft_c2c_lds_bytes(int N, int lt, int nk) { return sizeof(double2) * (((size_t)N << lt) + (size_t)(N >> 1)) + sizeof(double) * 3 * (size_t)nk; }
+
+template <bool BIN, int LT>
+__global__ void __launch_bounds__(kFftBlock)
+fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
+                       const double2 *__restrict__ tw, int nzt, int nouter, PkBins pb)
+{
+    // a tile = the (1 << LT) adjacent lines kz0 .. kz0 + (1 << LT) of one `o`; rows are padded (fft_pitch), so the last tile of
+    // a row reads up to 7 pad columns: lines of their own, transformed like the others and never binned or looked at
+    constexpr int NL = 1 << LT;
+    extern __shared__ double2 fbuf[];
+    double2 *twl = fbuf + ((size_t)N << LT);
+    double *hp = reinterpret_cast<double *>(twl + (N >> 1)), *hk = hp + pb.nk;
+    unsigned long long *hc = reinterpret_cast<unsigned long long *>(hk + pb.nk);
+    for (int i = threadIdx.x; i < (N >> 1); i += kFftBlock) twl[i] = tw[i];
+    if (BIN) {
+        for (int i = threadIdx.x; i < pb.nk; i += kFftBlock) { hp[i] = 0.0; hk[i] = 0.0; hc[i] = 0ull; }
+    }
+    const int64_t ntiles = (int64_t)nzt * nouter;
+    for (int64_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int kz0 = (int)(tl % nzt) << LT, o = (int)(tl / nzt);
+        double2 *base = data + (int64_t)o * outer_stride + kz0;
+        __syncthreads();                                             // (the previous tile's readers are done with fbuf)
+        for (int t = threadIdx.x; t < (N << LT); t += kFftBlock) {
+            const int l = t & (NL - 1), i = t >> LT;
+            fbuf[(bit_reverse(i, log2n) << LT) + l] = base[(int64_t)i * stride + l];
+        }
+        lds_fft_stages_t<LT>(fbuf, N, twl);
+        for (int t = threadIdx.x; t < (N << LT); t += kFftBlock) {
+            const int l = t & (NL - 1), i = t >> LT;
+            if (BIN) {
+                // neighbouring lanes take rows 37 apart (an odd multiplier permutes the rows): rows next to each other have
+                // almost the same |k| and would serialise on one histogram cell
+                const int a = (i * 37) & (N - 1);
+                if (kz0 + l < nz) pk_bin_sample(pb, N, a, pb.b0 + o, kz0 + l, fbuf[(a << LT) + l], hp, hk, hc);
+            } else base[(int64_t)i * stride + l] = fbuf[t];
+        }
+    }
+    if (BIN) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < pb.nk; i += kFftBlock)
+            if (hc[i]) { atomicAdd(pb.pk_sum + i, hp[i]); atomicAdd(pb.k_sum + i, hk[i]); atomicAdd(pb.counts + i, hc[i]); }
     }
 }
 

@@ -285,8 +285,18 @@ def deposit_particles_device(x_ptr, y_ptr, z_ptr, mass_ptr, n, n_grid, edges_ptr
                                                         int(n_grid), C.c_void_p(int(edges_ptr)), C.c_void_p(int(map_out_ptr))))
 
 
+def fft_pitch(n_grid):
+    """complex values per row of the half-spectrum work arrays: n/2 + 1 rounded up to whole 128-byte lines"""
+    return int(_lib.load().bfgx_fft_pitch(int(n_grid)))
+
+
+def power_spectrum_work_doubles(n_grid):
+    """doubles of scratch power_spectrum_device needs (half spectrum, rows padded to whole 128-byte lines)"""
+    return int(_lib.load().bfgx_power_spectrum_work_doubles(int(n_grid)))
+
+
 def power_spectrum_device(map_ptr, n_grid, L, nk, work_ptr, pk_sum_ptr, k_sum_ptr, counts_ptr, device=0, stream=0):
-    """FFT + |F|^2 + linear k-bins on a device-resident map; work = complex128 [n][n][n/2+1]"""
+    """FFT + |F|^2 + linear k-bins on a device-resident map; work = power_spectrum_work_doubles(n_grid) doubles of scratch"""
     _lib.check(_lib.load().bfgx_power_spectrum_device(int(device), C.c_void_p(int(stream) or None), int(n_grid),
                                                      C.c_void_p(int(map_ptr)), float(L), int(nk), C.c_void_p(int(work_ptr)),
                                                      C.c_void_p(int(pk_sum_ptr)), C.c_void_p(int(k_sum_ptr)),

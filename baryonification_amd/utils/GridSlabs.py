@@ -172,7 +172,7 @@ class HipBackend(object):
     def fft_planes(self, slab):
         t = self.torch
         cnt = slab.shape[0]
-        work = t.empty((cnt, self.n, self.n // 2 + 1), dtype=t.complex128, device=self.dev)
+        work = t.zeros((cnt, self.n, self.engine.fft_pitch(self.n)), dtype=t.complex128, device=self.dev)     # rows padded to 128-byte lines
         self.engine.fft_slab_planes_device(slab.data_ptr(), self.n, cnt, work.data_ptr(), device=self.device, stream=self.stream)
         return work
 

@@ -245,7 +245,7 @@ def main_grid(args):
     d_map = torch.empty(N ** 3, dtype=torch.float64, device=dev)
     d_off = torch.empty(N ** 3 * 3, dtype=torch.float64, device=dev)
     d_out = torch.empty(N ** 3, dtype=torch.float64, device=dev)
-    d_work = torch.empty(N * N * (N // 2 + 1) * 2, dtype=torch.float64, device=dev)
+    d_work = torch.empty(engine.power_spectrum_work_doubles(N), dtype=torch.float64, device=dev)
     d_sums = torch.zeros(2, dtype=torch.float64, device=dev)
     d_pk, d_ks = torch.zeros(Nk, dtype=torch.float64, device=dev), torch.zeros(Nk, dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(Nk, dtype=torch.int64, device=dev)

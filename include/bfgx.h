@@ -370,15 +370,19 @@ int  bfgx_deposit_particles_device(int device, void *hip_stream, int32_t ndim, i
 int  bfgx_deposit_particles_slab_device(int device, void *hip_stream, int32_t ndim, int64_t n, const double *x, const double *y,
                                         const double *z, const double *mass, int32_t n_grid, const double *edges_dev,
                                         int32_t plane_lo, int32_t plane_n, double *map_out_dev);
+/* work_dev: scratch of bfgx_power_spectrum_work_doubles(n_grid) doubles (the half spectrum, complex [n_grid][n_grid][pitch] with
+ * rows padded to whole 128-byte lines; its content is undefined afterwards: the last FFT pass bins |F|^2 straight from LDS) */
+int64_t bfgx_power_spectrum_work_doubles(int32_t n_grid);
+/* complex values per row of the half spectrum in every work array below: n_grid/2 + 1 rounded up to a multiple of 8 */
+int32_t bfgx_fft_pitch(int32_t n_grid);
 int  bfgx_power_spectrum_device(int device, void *hip_stream, int32_t n_grid, const double *map_dev, double L, int32_t nk,
-                                double *work_dev /* complex [n_grid][n_grid][n_grid/2+1] */, double *pk_sum_dev,
-                                double *k_sum_dev, unsigned long long *counts_dev);
+                                double *work_dev, double *pk_sum_dev, double *k_sum_dev, unsigned long long *counts_dev);
 
 /* The same P(k) summary for a grid that is slab-decomposed over GPUs: (1) every rank transforms its `planes` planes of the
- * first axis along the last two axes (map [planes][n][n] -> complex work [planes][n][n/2 + 1]); (2) the caller transposes
- * between the ranks (all_to_all) so that every rank holds all n planes of `ncols` columns of the MIDDLE axis, work
- * [n][ncols][n/2 + 1]; (3) every rank transforms along the first axis and bins its modes (col0 = its first column): the
- * three sums are partial and are added over the ranks by the caller. */
+ * first axis along the last two axes (map [planes][n][n] -> complex work [planes][n][pitch], pitch = bfgx_fft_pitch(n): the pad
+ * columns hold nothing and are never looked at); (2) the caller transposes between the ranks (all_to_all) so that every rank holds
+ * all n planes of `ncols` columns of the MIDDLE axis, work [n][ncols][pitch]; (3) every rank transforms along the first axis and bins its modes (col0 = its first column; work is
+ * scratch afterwards): the three sums are partial and are added over the ranks by the caller. */
 int  bfgx_fft_slab_planes_device(int device, void *hip_stream, int32_t n_grid, int32_t planes, const double *map_dev, double *work_dev);
 int  bfgx_fft_slab_axis0_pk_device(int device, void *hip_stream, int32_t n_grid, int32_t ncols, int32_t col0, double *work_dev, double L,
                                    int32_t nk, double *pk_sum_dev, double *k_sum_dev, unsigned long long *counts_dev);

@@ -406,7 +406,7 @@ def test_slab_kernels_side_by_side_equal_the_full_grid(gpu, N, W, monkeypatch):
     assert int(missed.item()) == 0 and pairs_full > 0
     amax = float(torch.nan_to_num(full_off[..., 1], nan=0.0, posinf=0.0, neginf=0.0).abs().max().item())
     assert 0.5 < amax < 8.0, amax
-    work = torch.empty((N, N, N // 2 + 1), dtype=torch.complex128, device=dev)
+    work = torch.empty(engine.power_spectrum_work_doubles(N), dtype=torch.float64, device=dev)
     sums_full = torch.zeros((2, Nk), dtype=torch.float64, device=dev)
     cnt_full = torch.zeros(Nk, dtype=torch.int64, device=dev)
     engine.power_spectrum_device(full_buf.data_ptr(), N, L, Nk, work.data_ptr(), sums_full[0].data_ptr(), sums_full[1].data_ptr(), cnt_full.data_ptr())
