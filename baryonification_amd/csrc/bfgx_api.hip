@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -1060,7 +1061,7 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, sums_dev);
 }
 
-namespace { void dep_release_all(); }
+namespace { void dep_release_all(); void fft_release_all(); }
 
 extern "C" {
 
@@ -1368,6 +1369,7 @@ void bfgx_cache_clear(void)
         g_cache.clear();
     }
     dep_release_all();           // workspace of the tiled particle deposit (bfgx_grid_api.inc)
+    fft_release_all();           // twiddle / wavenumber tables of the power spectrum
 }
 
 long long bfgx_debug_alloc_count(void) { return (long long)g_bfgx_allocs.load(); }

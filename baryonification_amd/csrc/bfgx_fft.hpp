@@ -91,7 +91,7 @@ fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, 
 // what the fused last pass needs to bin |F|^2 (pk_bin_kernel's arguments)
 struct PkBins {
     const double *klin;
-    double kb0, dk;
+    double kb0, dk, inv_dk;
     int nk, b0;
     double *pk_sum, *k_sum;
     unsigned long long *counts;
@@ -103,7 +103,10 @@ __device__ inline void pk_bin_sample(const PkBins &pb, int N, int a, int b, int 
 {
     const double ka = pb.klin[a], kb = pb.klin[b], kc = pb.klin[c];
     const double k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
-    const double u = floor((k - pb.kb0) / pb.dk);
+    // floor((k - kb0) / dk): the quotient through the reciprocal, the division itself only where that could change the floor
+    const double ue = (k - pb.kb0) * pb.inv_dk;
+    double u = floor(ue);
+    if (fabs(ue - rint(ue)) < 1e-6 * (fabs(ue) + 1.0)) u = floor((k - pb.kb0) / pb.dk);
     if (!(u >= 0.0) || !(u < (double)pb.nk)) return;
     const int bin = (int)u;
     const double p = f.x * f.x + f.y * f.y;

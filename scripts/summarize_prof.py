@@ -11,10 +11,12 @@ out = sys.argv[1]
 
 def short(name):
     """kernel name as the summaries print it"""
-    tags = (('grid_regrid_kernel', 'grid_regrid'), ('grid_scatter_kernel', 'grid_scatter'), ('grid_prep_kernel', 'grid_prep'),
+    tags = (('grid_gather_regrid_kernel', 'grid_gather_regrid'), ('grid_block_lists_kernel', 'grid_block_lists'), ('gather_sums_kernel', 'gather_sums'),
+            ('grid_regrid_kernel', 'grid_regrid'), ('grid_scatter_kernel', 'grid_scatter'), ('grid_prep_kernel', 'grid_prep'),
             ('snap_displace_kernel', 'snap_displace'), ('snap_halo_prep_kernel', 'snap_halo_prep'),
             ('deposit_keys_kernel', 'deposit_keys'), ('deposit_split_kernel<1', 'deposit_split<1>'), ('deposit_split_kernel<2', 'deposit_split<2>'),
-            ('deposit_count_kernel', 'deposit_count'), ('deposit_tiles_kernel', 'deposit_tiles'), ('fft_c2c_strided_kernel', 'fft_c2c_strided'),
+            ('deposit_count_kernel', 'deposit_count'), ('deposit_tiles_kernel', 'deposit_tiles'), ('fft_c2c_strided_kernel<true', 'fft_c2c_strided+pk_bins'),
+            ('fft_c2c_strided_kernel', 'fft_c2c_strided'),
             ('fft_r2c_lines_kernel', 'fft_r2c_lines'), ('pk_bin_kernel', 'pk_bin'),
             ('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
             ('halo_prep_kernel', 'halo_prep'), ('halo_scatter_kernel', 'halo_scatter'), ('regrid_far_kernel', 'regrid_far'),
