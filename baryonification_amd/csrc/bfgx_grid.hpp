@@ -256,7 +256,11 @@ grid_scatter_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restrict__ re
 // Python's float % for a positive modulus (CPython float_rem)
 __device__ inline double py_mod_pos(double x, double n)
 {
-    double m = fmod(x, n);
+    // a displaced pixel lies within one box length of the grid: there fmod(x, n) is x itself (|x| < n) or x - n (exact), and the
+    // ~100-instruction fmod is left to the positions further out
+    double m;
+    if (x > -n && x < 2.0 * n) m = (x >= n) ? x - n : x;
+    else m = fmod(x, n);
     if (m != 0.0) { if (m < 0.0) m += n; }
     else m = 0.0;
     return m;

@@ -95,10 +95,10 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
     __shared__ uint16_t queue[kGatherBatch * Blk::cells];                // (halo of the batch << 12) | cell: cannot overflow
     __shared__ int qn;
     const int N = g.npix, nbk = gather_blocks_per_axis(N, S), tid = threadIdx.x, lane = tid & (kWave - 1);
-    const int64_t blk = blockIdx.x;
-    int c0, c1, c2 = 0;                                  // first cell of the block along the array axes
-    if (DIM == 3) { c2 = (int)(blk % nbk) << S; const int64_t q = blk / nbk; c1 = (int)(q % nbk) << S; c0 = (int)(q / nbk) << S; }
-    else { c1 = (int)(blk % nbk) << S; c0 = (int)(blk / nbk) << S; }
+    const unsigned blk = blockIdx.x;
+    int c0, c1, c2 = 0;                                  // first cell of the block along the array axes (32-bit divisions)
+    if (DIM == 3) { c2 = (int)(blk % (unsigned)nbk) << S; const unsigned q = blk / (unsigned)nbk; c1 = (int)(q % (unsigned)nbk) << S; c0 = (int)(q / (unsigned)nbk) << S; }
+    else { c1 = (int)(blk % (unsigned)nbk) << S; c0 = (int)(blk / (unsigned)nbk) << S; }
     auto cell_pixel = [&](int cell, int pc[3]) {
         if (DIM == 3) { pc[2] = c2 + (cell & (Blk::B - 1)); pc[1] = c1 + ((cell >> S) & (Blk::B - 1)); pc[0] = c0 + (cell >> (2 * S)); }
         else { pc[2] = 0; pc[1] = c1 + (cell & (Blk::B - 1)); pc[0] = c0 + (cell >> S); }
@@ -236,7 +236,7 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
         unsigned long long tn = 0;
         for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; tn += sn[w]; }
         // (no atomic on one pair counter here: 2.6e5 workgroups adding to the same address serialise -- 1.2 ms on a 512^3 grid)
-        block_sums[3 * blk] = ta; block_sums[3 * blk + 1] = tb; block_sums[3 * blk + 2] = (double)tn;
+        block_sums[3 * (size_t)blk] = ta; block_sums[3 * (size_t)blk + 1] = tb; block_sums[3 * (size_t)blk + 2] = (double)tn;
     }
 }
 
