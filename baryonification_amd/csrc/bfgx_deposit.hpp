@@ -34,31 +34,33 @@ struct DepGeom {
     int32_t sx, sy, sz;               // tile shape in cells
     int32_t ntx, nty, ntz;            // tiles per axis
     int32_t T, B1, B2;                // tiles; level-1 buckets; tiles per level-1 bucket (B1 * B2 >= T)
+    int32_t lsx, lsy, lsz, lB2;       // log2 of the tile shape and of B2 (all powers of two: the per-particle index arithmetic is shifts,
+                                      // seven integer divisions per particle were most of deposit_keys' instructions)
 };
 
 __host__ inline DepGeom dep_geom(int dim, int nb, int plane_lo, int plane_n)
 {
     DepGeom g;
     g.dim = dim; g.nb = nb; g.plane_lo = plane_lo; g.plane_n = plane_n;
-    if (dim == 3) { g.sx = 16; g.sy = 16; g.sz = 32; }
-    else { g.sx = 64; g.sy = 128; g.sz = 1; }
+    if (dim == 3) { g.sx = 16; g.sy = 16; g.sz = 32; g.lsx = 4; g.lsy = 4; g.lsz = 5; }
+    else { g.sx = 64; g.sy = 128; g.sz = 1; g.lsx = 6; g.lsy = 7; g.lsz = 0; }
     g.ntx = (plane_n + g.sx - 1) / g.sx;
     g.nty = (nb + g.sy - 1) / g.sy;
     g.ntz = (dim == 3) ? (nb + g.sz - 1) / g.sz : 1;
     g.T = g.ntx * g.nty * g.ntz;
-    int b = 1;
-    while ((int64_t)b * b < g.T) b <<= 1;
-    g.B2 = b; g.B1 = (g.T + b - 1) / b;
+    int b = 1, lb = 0;
+    while ((int64_t)b * b < g.T) { b <<= 1; ++lb; }
+    g.B2 = b; g.lB2 = lb; g.B1 = (g.T + b - 1) / b;
     return g;
 }
 
 // key of a cell: tile << 13 | index in tile (the last grid axis runs fastest inside the tile, as in memory)
 __device__ inline uint32_t dep_key(const DepGeom &g, int bx, int by, int bz)
 {
-    const int tx = bx / g.sx, ty = by / g.sy, tz = (g.dim == 3) ? bz / g.sz : 0;
-    const int lx = bx - tx * g.sx, ly = by - ty * g.sy, lz = (g.dim == 3) ? bz - tz * g.sz : 0;
+    const int tx = bx >> g.lsx, ty = by >> g.lsy, tz = (g.dim == 3) ? bz >> g.lsz : 0;
+    const int lx = bx & (g.sx - 1), ly = by & (g.sy - 1), lz = (g.dim == 3) ? bz & (g.sz - 1) : 0;
     const uint32_t tile = (uint32_t)((tx * g.nty + ty) * g.ntz + tz);
-    const uint32_t local = (uint32_t)((lx * g.sy + ly) * g.sz + lz);
+    const uint32_t local = (uint32_t)((((lx << g.lsy) + ly) << g.lsz) + lz);
     return (tile << kDepLocalBits) | local;
 }
 
@@ -100,7 +102,7 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
             bx = (bx >= g.plane_lo && bx < g.plane_lo + g.plane_n) ? bx - g.plane_lo : -1;
             if (bx >= 0 && by >= 0 && bz >= 0) {
                 key = dep_key(g, bx, by, bz);
-                atomicAdd(hist + (int)((key >> kDepLocalBits) / (uint32_t)g.B2), 1);
+                atomicAdd(hist + (int)((key >> kDepLocalBits) >> g.lB2), 1);
             }
             keys[p] = key;
         }
@@ -116,7 +118,7 @@ template <int LEVEL>
 __device__ inline int dep_bucket(const DepGeom &g, uint32_t key)
 {
     const uint32_t tile = key >> kDepLocalBits;
-    return LEVEL == 1 ? (int)(tile / (uint32_t)g.B2) : (int)tile;
+    return LEVEL == 1 ? (int)(tile >> g.lB2) : (int)tile;
 }
 
 // level-2 counts: keys sorted by level-1 bucket -> particles per tile.  A chunk of consecutive keys spans few level-1
@@ -131,7 +133,7 @@ deposit_count_kernel(DepGeom g, const int32_t *__restrict__ nvalid, const uint32
     const int64_t n = *nvalid, base = (int64_t)blockIdx.x * kDepChunk;
     if (base >= n) return;
     for (int i = tid; i < kDepHist; i += 256) hist[i] = 0;
-    if (tid == 0) bmin_s = (int)(((keys[base] >> kDepLocalBits) / (uint32_t)g.B2) * (uint32_t)g.B2);
+    if (tid == 0) bmin_s = (int)(((keys[base] >> kDepLocalBits) >> g.lB2) << g.lB2);
     __syncthreads();
     const int bmin = bmin_s;
 #pragma unroll 4
@@ -164,7 +166,7 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     const int64_t n = n_dev ? (int64_t)*n_dev : n_host, base = (int64_t)blockIdx.x * kDepChunk;
     if (base >= n) return;
     for (int i = tid; i < kDepHist; i += 256) hist[i] = 0;
-    if (tid == 0) bmin_s = (LEVEL == 1) ? 0 : (int)(((keys_in[base] >> kDepLocalBits) / (uint32_t)g.B2) * (uint32_t)g.B2);
+    if (tid == 0) bmin_s = (LEVEL == 1) ? 0 : (int)(((keys_in[base] >> kDepLocalBits) >> g.lB2) << g.lB2);
     __syncthreads();
     const int bmin = bmin_s;
     uint32_t key[kDepPer];
@@ -247,7 +249,7 @@ deposit_tiles_kernel(DepGeom g, const int32_t *__restrict__ start2, const uint32
     const int tz = tile % g.ntz, ty = (tile / g.ntz) % g.nty, tx = tile / (g.ntz * g.nty);
     const int x0 = tx * g.sx, y0 = ty * g.sy, z0 = tz * g.sz;
     for (int l = tid; l < g.sx * g.sy * g.sz; l += kDepTileThreads) {
-        const int lz = l % g.sz, ly = (l / g.sz) % g.sy, lx = l / (g.sz * g.sy);
+        const int lz = l & (g.sz - 1), ly = (l >> g.lsz) & (g.sy - 1), lx = l >> (g.lsz + g.lsy);
         const int bx = x0 + lx, by = y0 + ly, bz = z0 + lz;
         if (bx >= g.plane_n || by >= g.nb || (g.dim == 3 && bz >= g.nb)) continue;
         const int64_t flat = (g.dim == 3) ? ((int64_t)bx * g.nb + by) * g.nb + bz : (int64_t)bx * g.nb + by;
