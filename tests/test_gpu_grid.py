@@ -284,6 +284,37 @@ def test_grid_cell_owned_pass(gpu, ndim, N, nh):
     plan.close()
 
 
+def test_grid_cell_owned_pass_refuses_what_it_cannot_do(gpu):
+    """a plan that owns a slab, a plan holding a profile (log) table and a catalog larger than the plan fail loudly"""
+    import torch
+    from baryonification_amd import _lib, engine
+    c = _big_case(3, 32, 20, 3)
+    cat = c['cat']
+    cos = dict(c['cosmo'], w0=-1.0)
+    axes = [np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])]
+    m, keep = engine.model_from_tables(axes, c['d'], cos, 6.0, 8.0)
+    dev = torch.device('cuda:0')
+    t = {k: torch.tensor(cat[k], dtype=torch.float64, device=dev) for k in ('M', 'x', 'y', 'z')}
+    dcat = _lib.make_grid_catalog_dev(20, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), 0)
+    m_in = torch.tensor(c['map'], device=dev)
+    m_out = torch.empty_like(m_in)
+    plan = engine.GridPlan(m, keep, c['bins'], 3, c['redshift'], 20, 0, torch.cuda.current_stream().cuda_stream)
+    assert plan.baryonify(dcat, m_in.data_ptr(), m_out.data_ptr()) > 0
+    plan.set_slab(8, 8)
+    with pytest.raises(ValueError, match='slab'):
+        plan.baryonify(dcat, m_in.data_ptr(), m_out.data_ptr())
+    plan.close()
+    small = engine.GridPlan(m, keep, c['bins'], 3, c['redshift'], 10, 0, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(ValueError, match='max_halos'):
+        small.baryonify(dcat, m_in.data_ptr(), m_out.data_ptr())
+    small.close()
+    mp, keep_p = engine.model_from_tables(axes, np.log(c['P']), cos, 6.0, 8.0, log_values=True)
+    paint = engine.GridPlan(mp, keep_p, c['bins'], 3, c['redshift'], 20, 0, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(ValueError, match='paint'):
+        paint.baryonify(dcat, m_in.data_ptr(), m_out.data_ptr())
+    paint.close()
+
+
 def test_grid_one_shot_scatter_path(gpu):
     """BFGX_GRID_PATH=scatter: the one-shot API through the halo-owned kernels (pix_offsets array + regrid, what the slab and
     multi-GPU entry points run) == the default cell-owned pass == the committed golden"""
