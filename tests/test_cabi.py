@@ -67,3 +67,22 @@ def test_invalid_arguments_map_to_python_exceptions():
         engine.ShellPlan(model, keep, 0, 10)
     with pytest.raises(ValueError):
         _lib.make_table(axes, np.zeros((3, 3, 7)))
+
+
+def test_power_spectrum_work_size_is_host_arithmetic():
+    """rows of the half spectrum are padded to whole 128-byte lines (8 complex values): pure host functions, no GPU needed"""
+    from baryonification_amd import engine
+    for n in (8, 16, 64, 128, 512, 1024):
+        pitch = engine.fft_pitch(n)
+        assert pitch % 8 == 0 and n // 2 + 1 <= pitch < n // 2 + 1 + 8
+        assert engine.power_spectrum_work_doubles(n) == 2 * n * n * pitch
+    assert engine.fft_pitch(512) == 264
+
+
+def test_null_arguments_are_refused_before_any_device_call():
+    import ctypes as C
+    L = _lib.load()
+    n = C.c_int64(0)
+    assert L.bfgx_grid_baryonify_device(None, None, None, None, None, C.byref(n)) == _lib.ERR_INVALID
+    assert b'NULL' in L.bfgx_last_error()
+    assert L.bfgx_power_spectrum_device(0, None, 64, None, 100.0, 10, None, None, None, None) == _lib.ERR_INVALID
