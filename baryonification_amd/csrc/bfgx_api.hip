@@ -908,6 +908,10 @@ static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, i
         if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)out_slice_dev - p0);
         return launch_tile_scatter<MODE_PAINT, float>(p, (float *)out_slice_dev - p0);
     }
+    // K1's flush leaves the largest |offset|^2 of every tile it stores (bfgx_bands_max_offset2_device reduces them: the reach of the
+    // regrid then needs no second pass over the slice)
+    p->omax_from_k1 = true;
+    struct ResetO { bfgx_plan *p; ~ResetO() { p->omax_from_k1 = false; } } reseto{p};
     if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)out_slice_dev - 3 * p0);
     return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)out_slice_dev - 3 * p0);
 }
@@ -920,6 +924,21 @@ int bfgx_offsets_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t ban
 int bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *map_slice_dev, int acc_f64)
 {
     return bands_scatter(p, cat, band0, band1, map_slice_dev, acc_f64, true);
+}
+
+int bfgx_bands_max_offset2_device(bfgx_plan *p, int32_t band0, int32_t band1, float *out_dev)
+{
+    if (!p || !out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "band-restricted passes need the tiled algorithm (algo 1)");
+    if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), p->stream));
+    const int t0 = p->band_tile0_host[band0], nt = p->band_tile0_host[band1] - t0;
+    if (nt > 0) {
+        hipLaunchKernelGGL(max_bits_kernel, dim3(1), dim3(1024), 0, p->stream, nt, (const unsigned *)p->tile_omax + t0, (unsigned *)out_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
 }
 
 int bfgx_max_offset2_device(bfgx_plan *p, const void *offsets_dev, int64_t npixels, int acc_f64, float *out_dev)
@@ -968,7 +987,7 @@ int bfgx_route_count_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, i
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * world, p->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(route_halos_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, a, n, rings_dev, counts_dev,
+        hipLaunchKernelGGL(route_halos_kernel<false>, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRouteGrid)), dim3(256), 0, p->stream, a, n, rings_dev, counts_dev,
                            (int32_t *)nullptr, (double *)nullptr);
         HIP_TRY(hipGetLastError());
     }
@@ -988,7 +1007,7 @@ int bfgx_route_fill_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, in
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(int32_t) * world, p->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(route_halos_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, a, n, rings_dev, (int32_t *)nullptr,
+        hipLaunchKernelGGL(route_halos_kernel<true>, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRouteGrid)), dim3(256), 0, p->stream, a, n, rings_dev, (int32_t *)nullptr,
                            cursor_dev, rows_dev);
         HIP_TRY(hipGetLastError());
     }

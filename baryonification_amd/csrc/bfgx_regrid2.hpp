@@ -295,6 +295,17 @@ max_offset_kernel(int64_t n, const ACC *__restrict__ offsets, unsigned *__restri
     if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, __float_as_uint(m2));
 }
 
+// largest of n non-negative floats given as their bit patterns (the per-tile maxima K1 leaves): one workgroup
+__global__ void __launch_bounds__(1024)
+max_bits_kernel(int n, const unsigned *__restrict__ v, unsigned *__restrict__ out)
+{
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < n; i += 1024) m = max(m, v[i]);
+#pragma unroll
+    for (int sft = kWave >> 1; sft > 0; sft >>= 1) m = max(m, (unsigned)__shfl_down((int)m, sft, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicMax(out, m);
+}
+
 // One source pixel of the gathering regrid: the 4 targets of its displaced position, (ring index in the tile's ring tables,
 // column) + weight.  The pixel must be a gathered one (see above).  Returns false
 // when the move leaves the ring tables (then no target lies in the tile).  x = column of the pixel relative to the tile's

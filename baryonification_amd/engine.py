@@ -65,6 +65,11 @@ class ShellPlan(object):
                                                      st.ctypes.data, len(col_ptrs), cols, C.c_void_p(int(cursor_ptr)),
                                                      C.c_void_p(int(rows_ptr) or None)))
 
+    def bands_max_offset2(self, band0, band1, out_ptr):
+        """largest |offset|^2 (float32, device) of the slice offsets_bands() has just written for the bands [band0, band1): reduced
+        from the per-tile maxima K1 leaves, no pass over the slice"""
+        _lib.check(_lib.load().bfgx_bands_max_offset2_device(self._h, int(band0), int(band1), C.c_void_p(int(out_ptr))))
+
     def max_offset2(self, offsets_ptr, npixels, out_ptr, acc_f64=False):
         """enqueue-only: *out (float32, device) = largest |offset|^2 over npixels pixels of pix_offsets"""
         _lib.check(_lib.load().bfgx_max_offset2_device(self._h, C.c_void_p(int(offsets_ptr) or None), int(npixels), int(acc_f64),

@@ -122,7 +122,7 @@ def route_halos(cols, rings, ring_bounds, plan=None):
         t_in = torch.bincount(dst, minlength=world)[:world].to(torch.int64)
     t_out = torch.empty_like(t_in)
     _a2a(t_out, t_in, None, None)
-    ins, outs = [int(c) for c in t_in.tolist()], [int(c) for c in t_out.tolist()]
+    ins, outs = [[int(c) for c in row] for row in torch.stack([t_in, t_out]).tolist()]      # one read-back for both
     if plan is not None and rings.is_cuda:
         rows = torch.empty((sum(ins), k), dtype=torch.float64, device=dev)
         cursor = torch.empty(world, dtype=torch.int32, device=dev)
@@ -316,12 +316,17 @@ def _hip_bounds(runner, plan, world):
     return cuts, first[cuts], needs
 
 
-def _hip_reach(runner, plan, my_off):
+def _hip_reach(runner, plan, my_off, bands=None):
     """collective: the rings of apron the gathering regrid needs follow the largest |offset| of the SUMMED pix_offsets over
-    all ranks; every rank sets the same value on its plan"""
+    all ranks; every rank sets the same value on its plan.  `bands` = (b0, b1): `my_off` is the slice plan.offsets_bands() has
+    just written for those bands (spatial sharding, nothing added since) -- the maximum then comes from the per-tile maxima K1
+    left behind instead of a pass over the slice."""
     import torch
     import torch.distributed as dist
-    if my_off.is_cuda:
+    if my_off.is_cuda and bands is not None:
+        m2 = torch.empty(1, dtype=torch.float32, device=my_off.device)
+        plan.bands_max_offset2(int(bands[0]), int(bands[1]), m2.data_ptr())
+    elif my_off.is_cuda:
         m2 = torch.empty(1, dtype=torch.float32, device=my_off.device)
         plan.max_offset2(my_off.data_ptr(), my_off.numel() // 3, m2.data_ptr(), acc_f64=(my_off.dtype == torch.float64))
     else:
@@ -461,6 +466,9 @@ def _distributed_spatial(runner, kind, cat, device, compute_spatial, bounds, reg
     if kind != 'baryonify':
         full = gather_slices(mine, pb, npix, result)
         return None if full is None else full.cpu().numpy().astype(np.float64)
+    if reach is None and bounds is None:
+        import functools
+        reach = functools.partial(_hip_reach, bands=(int(cuts[rank]), int(cuts[rank + 1])))     # K1's per-tile maxima: no pass over the slice
     return _regrid_own_slices(runner, ctx, mine, cuts, pb, needs, device, bounds, regrid_slice, reach, result)
 
 

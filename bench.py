@@ -490,7 +490,7 @@ def main():
             my_off = d_off[:(p1 - p0) * 3]
             plan_sp.offsets_bands(cd, b0, b1, my_off.data_ptr(), acc_f64=acc_f64)
             if dist.is_initialized():
-                _hip_reach(None, plan_sp, my_off)          # collective: rings of apron from the largest |offset|
+                _hip_reach(None, plan_sp, my_off, bands=(b0, b1))          # collective: rings of apron from the largest |offset| (K1's per-tile maxima)
             nd = [plan_sp.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
             off_apron = halo_exchange(my_off, pb, nd, 3)
             plan_sp.regrid_bands(b0, b1, d_map.data_ptr(), off_apron.data_ptr(), nd[rank][0], nd[rank][1], d_slice.data_ptr(), d_sums.data_ptr(),

@@ -200,6 +200,10 @@ int  bfgx_baryonify_device(bfgx_plan *p, const bfgx_catalog *cat_dev, const doub
  * buffers: count only) so that the caller can add them to whichever rank's slice holds the pixel.  (bfgx_regrid_device
  * sizes its aprons tile by tile from the data, applies its own list, and repairs an overflowing list in-stream.) */
 int  bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel);
+/* the same maximum for the slice bfgx_offsets_bands_device has JUST written for the bands [band0, band1): reduced from the per-tile
+ * maxima K1's flush leaves behind (a few thousand values) instead of a second pass over the slice.  Valid only while nothing
+ * else has been added to that slice (spatial sharding: every rank computes its own pixels). */
+int  bfgx_bands_max_offset2_device(bfgx_plan *p, int32_t band0, int32_t band1, float *out_dev);
 /* *out_dev (float, device) = largest |offset|^2 of npixels pixels of pix_offsets (enqueue-only): what the ranks all-reduce (MAX) */
 int  bfgx_max_offset2_device(bfgx_plan *p, const void *offsets_dev, int64_t npixels, int acc_f64, float *out_dev);
 int  bfgx_plan_reach_rings(bfgx_plan *p, double max_offset, int32_t *rings);
