@@ -948,7 +948,7 @@ int bfgx_max_offset2_device(bfgx_plan *p, const void *offsets_dev, int64_t npixe
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), p->stream));
     if (npixels > 0) {
-        const unsigned grid = (unsigned)std::min<int64_t>((npixels + 255) / 256, 2048);
+        const unsigned grid = (unsigned)std::min<int64_t>((npixels + 255) / 256, 1024);
         if (acc_f64) hipLaunchKernelGGL(max_offset_kernel<double>, dim3(grid), dim3(256), 0, p->stream, npixels, (const double *)offsets_dev, (unsigned *)out_dev);
         else hipLaunchKernelGGL(max_offset_kernel<float>, dim3(grid), dim3(256), 0, p->stream, npixels, (const float *)offsets_dev, (unsigned *)out_dev);
         HIP_TRY(hipGetLastError());

@@ -292,7 +292,15 @@ max_offset_kernel(int64_t n, const ACC *__restrict__ offsets, unsigned *__restri
     }
 #pragma unroll
     for (int sft = kWave >> 1; sft > 0; sft >>= 1) m2 = fmaxf(m2, __shfl_down(m2, sft, kWave));
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, __float_as_uint(m2));
+    // one atomic per workgroup (the counter is ONE address: atomics on it serialise)
+    __shared__ float wm[256 / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) wm[threadIdx.x / kWave] = m2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.0f;
+        for (int w = 0; w < 256 / kWave; ++w) m = fmaxf(m, wm[w]);
+        if (m > 0.0f) atomicMax(out, __float_as_uint(m));
+    }
 }
 
 // largest of n non-negative floats given as their bit patterns (the per-tile maxima K1 leaves): one workgroup
