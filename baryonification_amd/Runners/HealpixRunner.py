@@ -111,7 +111,9 @@ class PaintProfilesShell(DefaultRunner):
         cat, cols = self._catalog(p_keys)
         nside = int(self.LightconeShell.NSIDE)
         new_map = _lib.pinned_empty(self.LightconeShell.map.size)
-        acc64 = 1 if self.acc_f64 is None else int(bool(self.acc_f64))
+        # acc_f64: None / True = fp64 throughout (1e-10 parity); 2 or 'mixed' = fp32 pair math accumulated in fp64 (2.3x faster,
+        # 5e-5 of the pixel value); False = fp32 map
+        acc64 = 1 if self.acc_f64 is None else (2 if self.acc_f64 in (2, 'mixed') else int(bool(self.acc_f64)))
         opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0, int(self.algo), 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data,

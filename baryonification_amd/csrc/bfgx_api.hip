@@ -115,6 +115,7 @@ struct bfgx_plan {
     int32_t *regrid_todo = nullptr;  // [0] = count, then the tiles the lean gather kernel leaves to the one with the ring walk
     float *tile_omax = nullptr;      // largest |offset|^2 of every tile (K1's flush or tile_reach_kernel): the reach of the gathering regrid
     bool omax_from_k1 = false;       // set while a fused offsets + regrid call is in flight
+    bool paint_pair_f32 = false;     // set while a paint call with acc_f64 = 2 is in flight: f32 pair math into the f64 map
     int k1_tile_lo = 0, k1_tile_n = -1;   // tiles K1 / K3 process (-1: the whole sphere); set by the *_bands_device entries
     int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
     int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
@@ -385,6 +386,13 @@ static int launch_tile_scatter(bfgx_plan *p, ACC *out)
 {
     if (use_fast(p)) {
         using real = typename std::conditional<sizeof(ACC) == 8, double, float>::type;
+        if constexpr (MODE == MODE_PAINT && sizeof(ACC) == 8) {
+            // acc_f64 = 2: the pair phase in fp32 (K0 wrote fp32 pair records), LDS accumulation and the stored map in fp64
+            if (p->paint_pair_f32) {
+                if (int rc = launch_tile_scatter2<MODE, ACC, float>(p, out)) return rc;
+                return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);
+            }
+        }
         if (int rc = launch_tile_scatter2<MODE, ACC, real>(p, out)) return rc;
         return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);
     }
@@ -901,8 +909,12 @@ static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, i
     p->k1_tile_lo = p->band_tile0_host[band0];
     p->k1_tile_n = p->band_tile0_host[band1] - p->k1_tile_lo;
     struct Reset { bfgx_plan *p; ~Reset() { p->k1_tile_lo = 0; p->k1_tile_n = -1; } } reset{p};
-    if (int rc = launch_prep_and_bin(p, cat, paint ? 0 : 1, acc_f64 != 0)) return rc;
+    if (acc_f64 < 0 || acc_f64 > (paint ? 2 : 1)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
+    const bool mixed = paint && acc_f64 == 2 && use_fast(p);
+    if (int rc = launch_prep_and_bin(p, cat, paint ? 0 : 1, acc_f64 != 0 && !mixed)) return rc;
     if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
+    p->paint_pair_f32 = mixed;
+    struct ResetP { bfgx_plan *p; ~ResetP() { p->paint_pair_f32 = false; } } resetp{p};
     // virtual base: the kernels index the output by global pixel number
     if (paint) {
         if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)out_slice_dev - p0);
@@ -1044,9 +1056,13 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
     if (!map_out_dev) return fail(BFGX_ERR_INVALID, "map pointer is NULL");
     if (!p->model.tab.logv) return fail(BFGX_ERR_INVALID, "profile painting needs a table with log_values = 1");
     HIP_TRY(hipSetDevice(p->device));
+    if (acc_f64 < 0 || acc_f64 > 2) return fail(BFGX_ERR_INVALID, "acc_f64 must be 0, 1 or 2");
     if (p->algo == 1) {
-        if (int rc = launch_prep_and_bin(p, cat, 0, acc_f64 != 0)) return rc;
+        const bool mixed = acc_f64 == 2 && use_fast(p);          // (tables the fast kernel cannot take: fp64 throughout)
+        if (int rc = launch_prep_and_bin(p, cat, 0, acc_f64 != 0 && !mixed)) return rc;
         if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
+        p->paint_pair_f32 = mixed;
+        struct Reset { bfgx_plan *p; ~Reset() { p->paint_pair_f32 = false; } } reset{p};
         if (acc_f64) return launch_tile_scatter<MODE_PAINT, double>(p, (double *)map_out_dev);
         return launch_tile_scatter<MODE_PAINT, float>(p, (float *)map_out_dev);
     }

@@ -143,7 +143,8 @@ class ShellPlan(object):
         return pix, val
 
     def paint(self, cat_dev, map_out_ptr, acc_f64=True):
-        """K0 + K3 (HealpixRunner.py:418-445)"""
+        """K0 + K3 (HealpixRunner.py:418-445).  acc_f64: True / 1 = fp64 throughout (double map), False / 0 = fp32 (float map),
+        2 = fp32 pair math accumulated in fp64 into a double map"""
         _lib.check(_lib.load().bfgx_paint_device(self._h, C.byref(cat_dev), C.c_void_p(int(map_out_ptr)), int(acc_f64)))
 
     def count_pairs(self, cat_dev, fallback4=True, counts_ptr=0):

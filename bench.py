@@ -462,7 +462,7 @@ def main():
         def step_paint():
             if args.algo == 0:
                 d_out.zero_()
-            plan.paint(cat_dev, d_out.data_ptr(), acc_f64=True)
+            plan.paint(cat_dev, d_out.data_ptr(), acc_f64=(1 if acc_f64 else 2))    # 2: f32 pair math, f64 accumulation and map
             if slices:
                 mine = sliced_reduce(d_out, pb, 1, recv=x_recv)
                 gather_slices(mine, pb, npix, 'root', out=d_fin if rank == 0 else None)
@@ -484,7 +484,7 @@ def main():
                                        ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
             b0, b1 = int(cuts[rank]), int(cuts[rank + 1])
             if paint:
-                plan_sp.paint_bands(cd, b0, b1, d_slice.data_ptr(), acc_f64=True)
+                plan_sp.paint_bands(cd, b0, b1, d_slice.data_ptr(), acc_f64=(1 if acc_f64 else 2))
                 gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
                 return
             my_off = d_off[:(p1 - p0) * 3]
@@ -623,6 +623,15 @@ def main():
         assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
 
     extra = {}
+    if world == 1 and paint and not args.acc_f64 and args.algo == 1 and not args.no_extras:
+        step64 = run_steps(True)                 # fp64 pair math too (the 1e-10 parity path)
+        for _ in range(3):
+            step64()
+        n64 = max(20, args.steps // 4)
+        el64, _ = timed(step64, n64, False)
+        extra["value_acc_f64"] = {"value": total_halos / el64 * n64, "unit": "halos/s", "ms_per_step": el64 / n64 * 1e3, "steps": n64,
+                                  "dtype": "f64 throughout (fp64 pair math, fp64 LDS accumulation, fp64 map)"}
+        del step64
     if world == 1 and not paint and not args.acc_f64 and args.algo == 1 and not args.no_extras:
         # the same step with fp64 pix_offsets accumulators and fp64 pair math (1e-10 parity path)
         step64 = run_steps(True)
@@ -651,7 +660,8 @@ def main():
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": ("f64" if (args.acc_f64 or paint) else
+            "dtype": ("f64" if args.acc_f64 else
+                      "f64 ring-row geometry + f64 LDS accumulation + f64 map; f32 pair math (chord, ln r, read-out, exp)" if paint else
                       "f64 ring-row geometry + f64 LDS accumulation / map; f32 pair math, f32 pix_offsets, f32 regrid geometry"),
             "data": "synthetic",
             "config": {"workload": "BASELINE config %d: %d-halo synthetic catalog %s (SURVEY 8d seeds), %s, "
@@ -696,10 +706,10 @@ def roofline(args, kernels, n_pairs, nh, npix, paint):
     # K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo; K2 60 B per map pixel (3 acc + 8 + 4 x 8 + 8); K3 8 B/pair
     alg = {'offsets': n_pairs * 3 * acc_b + nh * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8), 'paint': n_pairs * 8 + nh * 32 + npix * 8}
     dom = 'paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
-    real = 'double' if (args.acc_f64 or paint) else 'float'
+    real = 'double' if args.acc_f64 else 'float'
     names = {"offsets": ("tile_scatter2_kernel<OFFSETS, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
              "regrid": ("tile_regrid3_kernel<%s, %s, 0>" % (real, real)) if args.algo == 1 else "regrid_kernel",
-             "paint": "tile_scatter2_kernel<PAINT, double>" if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
+             "paint": ("tile_scatter2_kernel<PAINT, double, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
     ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
     traffic = valu = None
     try:

@@ -47,7 +47,10 @@ def test_default_mode_line_small(gpu):
 def test_paint_and_grid_lines_small(gpu):
     d = _run('--mode', 'paint', '--halos', '20000', '--nside', '128', '--steps', '3', '--warmup', '1', '--no-cpu-baseline')
     _check_common(d)
-    assert 'PaintProfilesShell' in d['metric'] and d['dtype'] == 'f64'
+    assert 'PaintProfilesShell' in d['metric'] and 'f32 pair math' in d['dtype'] and 'f64 map' in d['dtype']
+    assert d['value_acc_f64']['value'] > 0 and d['roofline']['kernel'].endswith('float>')
+    d = _run('--mode', 'paint', '--halos', '20000', '--nside', '128', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--acc-f64')
+    assert d['dtype'] == 'f64' and 'value_acc_f64' not in d
     d = _run('--mode', 'grid3d', '--ngrid', '64', '--grid-halos', '500', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
     _check_common(d)
     assert d['unit'] == 'cells/s' and d['mass_conserved'] is True and d['pk_finite_bins'] > 0

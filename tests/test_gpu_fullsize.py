@@ -115,6 +115,13 @@ def test_config3_paint_full_size_properties(gpu):
     assert (paint(cdA, 1) + paint(cdB, 1) - full).abs().max().item() <= 1e-11 * scale       # linearity (Parallelize.py:318)
     f32 = paint(cd, 1, acc_f64=False)
     assert (f32.double() - full).abs().max().item() <= 1e-5 * scale                         # stated fp32 tolerance
+    # acc_f64 = 2: fp32 pair math accumulated in fp64 into the double map (what bench.py --mode paint times by default).  Stated
+    # fp64 -> fp32 tolerance: 5e-5 of the pixel's value (ln r and the read-out of ln P in fp32, then exp)
+    mixed = paint(cd, 1, acc_f64=2)
+    assert mixed.dtype == torch.float64 and torch.isfinite(mixed).all().item()
+    assert ((mixed - full).abs() <= 5e-5 * full + 1e-12 * scale).all().item()
+    assert (mixed - full).abs().max().item() <= 1e-5 * scale
+    assert abs(mixed.sum().item() / full.sum().item() - 1.0) <= 1e-6
     # oracle on a 20 000-halo sample of the same catalog
     from oracle import oracle as O
     sub = {k: v[:20000] for k, v in cat.items()}
