@@ -466,6 +466,14 @@ def test_band_restricted_pass_with_selected_halos_equals_full_pass(gpu, paint):
             ref = full[p0 * width:p1 * width]
             assert torch.isfinite(sl).all().item()
             assert (sl - ref).abs().max().item() <= (1e-12 if paint else 2e-6) * full.abs().max().item()
+            if not paint:
+                # the reach of the regrid: the per-tile maxima K1 left behind == a pass over the slice (up to K1's 1e-6 safety factor)
+                m_k1, m_pass = torch.empty(1, dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
+                plan.bands_max_offset2(int(cuts[rk]), int(cuts[rk + 1]), m_k1.data_ptr())
+                plan.max_offset2(sl.data_ptr(), p1 - p0, m_pass.data_ptr(), acc_f64=False)
+                torch.cuda.synchronize()
+                a, b = float(m_k1.item()), float(m_pass.item())
+                assert b > 0 and b <= a <= b * (1 + 3e-6), (a, b)
         assert N <= taken <= 1.5 * N                                        # boundary halos go to two ranks, nothing is lost
     plan.close()
 
