@@ -318,7 +318,11 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     int64_t ne64 = (int64_t)cnt_a[tile] + cnt_b[tile];            // the narrow-halo region of the tile's entry list
     if (e0 + ne64 > capacity) ne64 = capacity > e0 ? capacity - e0 : 0;
     const int ne = (int)ne64;
-    const int nchunks = (BFGX_ABL2 == 1) ? 0 : (ne + kChunk2 - 1) / kChunk2;
+    // entries per chunk: at most kChunk2, fewer when the tile's list is short, so that every wave of the workgroup gets a chunk (a
+    // large-NSIDE tile lists ~20 halos with hundreds of pixels each: in chunks of 16 entries two of the eight waves did all the
+    // work).  One chunk per wave measured best (NSIDE 2048: K1 1.91 -> 1.56 ms, 8192: 56.8 -> 24.0 ms; 16 or 32 chunks per tile pack worse)
+    const int csz = max(1, min(kChunk2, (ne + kW2 - 1) / kW2));
+    const int nchunks = (BFGX_ABL2 == 1) ? 0 : (ne + csz - 1) / csz;
     WaveLds &L = wl[wid];
     unsigned long long npairs = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -334,8 +338,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         int nrows = 0;
         EntC2 en;
         en.hidx = 0; en.prefix = 0; en.ring_lo = 0; en.fb = 0;
-        if (lane < kChunk2 && c * kChunk2 + lane < ne) {
-            en.hidx = entries[e0 + c * kChunk2 + lane];
+        if (lane < csz && c * csz + lane < ne) {
+            en.hidx = entries[e0 + c * csz + lane];
             const RowRec &rr = rowrecs[en.hidx];
             en.fb = rr.fb;
             if (en.fb) nrows = 4;
