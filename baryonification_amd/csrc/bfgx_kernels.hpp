@@ -1313,7 +1313,8 @@ tile_scatter_kernel(PairTable pt, Hpx h, Tiling T, const HaloRec *__restrict__ r
     const int ne = (int)(e1 > e0 ? e1 - e0 : 0);
     // entries a wave takes at a time: the wide pass visits a few polar tiles with a handful of entries each (and thousands of
     // pixels per entry), so small chunks keep all four waves of the tile busy
-    const int chunk = wide_tiles ? 2 : kChunk;
+    // (full pass: one chunk per wave when the tile's list is short, as in the fast kernel)
+    const int chunk = wide_tiles ? 2 : max(1, min(kChunk, (ne + kWavesPerBlock - 1) / kWavesPerBlock));
     const int nchunks = (ne + chunk - 1) / chunk;
     TileWaveLds &L = wl[wid];
     unsigned long long npairs = 0;
