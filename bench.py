@@ -8,11 +8,15 @@ NSIDE=1024 HEALPix shell (BASELINE.json configs[1]), inputs resident in HBM.
     ... bench.py --gpus N --scaling strong            # ONE 1e6-halo catalog split over the N GPUs (north_star's wording)
     ... bench.py --gpus 8 --config 4                  # BASELINE config 4: 1e7 halos, NSIDE 2048, over the GPUs given
 
-One step = one full pass of the hot path: K0 halo_prep (per-halo scalars, halo -> tile binning) -> K1 tile_scatter2
-(pix_offsets; tile-owned LDS accumulation, no global atomics) -> [N>1: RCCL all_to_all reduce-scatter by pixel slices +
-one-ring halo exchange] -> K2 tile_regrid3 (gathering regrid: every output pixel stored once) -> the two sums of the
-mass-conservation check [-> N>1: disjoint slices to rank 0].  N>1 is weak scaling by default (every rank owns its own
-1e6-halo shard of an N x 1e6 catalog on the same shell); value = all halos / max-over-ranks time.
+One step = one full pass of the hot path: [N>1, default --exchange spatial: every halo's catalog row is routed (RCCL
+all_to_all) to the ranks whose ring bands its disc touches ->] K0 halo_prep (per-halo scalars, halo -> tile binning) -> K1
+tile_scatter2 (pix_offsets; tile-owned LDS accumulation, no global atomics) -> [N>1: all_reduce(MAX) of the largest
+|offset|, exchange of that many apron rings ->] K2 tile_regrid3 (gathering regrid: every output pixel stored once) -> the
+two sums of the mass-conservation check [-> N>1: disjoint slices to rank 0].  --exchange slices / reduce keep the halo
+shards where they are and exchange pix_offsets instead.  N>1 is weak scaling by default (every rank owns its own 1e6-halo
+shard of an N x 1e6 catalog on the same shell); value = all halos / max-over-ranks time.
+--mode paint (BASELINE config 3 with --nside 2048): K0 -> K3, the pair phase in fp32 accumulated in fp64 into the fp64 map
+(--acc-f64: fp64 throughout; `value_acc_f64` carries that number on the default line).  --mode grid3d / snapshot: config 5.
 
 Prints ONE JSON line (rank 0).  `value` / `ms_per_step` come from a timed region of exactly --steps steps between
 barrier + synchronize fences WITHOUT per-kernel events; the same K steps are then repeated with HIP events around every
