@@ -167,6 +167,9 @@ SYMBOLS = {
     'bfgx_grid_plan_timing_read': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_deposit_particles_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_route_particles_count_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'bfgx_route_particles_fill_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                                   C.c_void_p, C.c_void_p]),
     'bfgx_power_spectrum_work_doubles': (C.c_int64, [C.c_int32]),
     'bfgx_fft_pitch': (C.c_int32, [C.c_int32]),
     'bfgx_power_spectrum_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,

@@ -257,4 +257,69 @@ deposit_tiles_kernel(DepGeom g, const int32_t *__restrict__ start2, const uint32
     }
 }
 
+// ---- routing of particles to the ranks that own their planes (slab decomposition over GPUs, utils/GridSlabs.py) -----------------
+// owner[j] = rank whose planes [r cnt, (r + 1) cnt) hold the particle's first-axis bin (np.histogramdd's rule), kRouteDropped for a
+// particle outside the edges.  A few hundred workgroups, each owning a contiguous run of particles and touching the `world`
+// counters once (same-address atomics serialise).
+constexpr int kPartRouteGrid = 1024;
+constexpr int kPartRouteMaxRanks = 255;
+constexpr uint8_t kRouteDropped = 255;
+
+__global__ void __launch_bounds__(256)
+route_particles_count_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ edges, int nb, int cnt, int world,
+                             uint8_t *__restrict__ owner, int32_t *__restrict__ counts)
+{
+    __shared__ int hist[256];
+    __shared__ double sedge[kDepEdgesLds];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    const bool lds_edges = nb + 1 <= kDepEdgesLds;
+    if (lds_edges) for (int i = tid; i <= nb; i += 256) sedge[i] = edges[i];
+    __syncthreads();
+    const double *e = lds_edges ? sedge : edges;
+    const double scale = (double)nb / (edges[nb] - edges[0]);
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t j0 = (int64_t)blockIdx.x * per, j1 = min(n, j0 + per);
+    for (int64_t j = j0 + tid; j < j1; j += 256) {
+        const int b = histogram_bin(e, nb, x[j], scale);
+        const int d = (b >= 0) ? min(b / cnt, world - 1) : (int)kRouteDropped;
+        owner[j] = (uint8_t)d;
+        if (b >= 0) atomicAdd(&hist[d], 1);
+    }
+    __syncthreads();
+    if (tid < world && hist[tid]) atomicAdd(counts + tid, hist[tid]);
+}
+
+// cols_out[c][start[d] + ...] = column c of the particles bound for rank d (any order inside a destination); `total` = particles kept
+struct PartRouteArgs {
+    int32_t world, ncols;
+    int64_t start[kPartRouteMaxRanks];
+    const double *col[4];
+};
+
+__global__ void __launch_bounds__(256)
+route_particles_fill_kernel(PartRouteArgs a, int64_t n, int64_t total, const uint8_t *__restrict__ owner, int32_t *__restrict__ cursor,
+                            double *__restrict__ cols_out)
+{
+    __shared__ int hist[256], base[256], taken[256];
+    const int tid = threadIdx.x;
+    hist[tid] = 0; taken[tid] = 0;
+    __syncthreads();
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t j0 = (int64_t)blockIdx.x * per, j1 = min(n, j0 + per);
+    for (int64_t j = j0 + tid; j < j1; j += 256) {
+        const int d = owner[j];
+        if (d != kRouteDropped) atomicAdd(&hist[d], 1);
+    }
+    __syncthreads();
+    if (tid < a.world) base[tid] = hist[tid] ? atomicAdd(cursor + tid, hist[tid]) : 0;       // one range per (workgroup, destination)
+    __syncthreads();
+    for (int64_t j = j0 + tid; j < j1; j += 256) {
+        const int d = owner[j];
+        if (d == kRouteDropped) continue;
+        const int64_t pos = a.start[d] + base[d] + atomicAdd(&taken[d], 1);
+        for (int c = 0; c < a.ncols; ++c) cols_out[(int64_t)c * total + pos] = a.col[c][j];
+    }
+}
+
 }  // namespace bfgx

@@ -291,6 +291,20 @@ def deposit_particles_device(x_ptr, y_ptr, z_ptr, mass_ptr, n, n_grid, edges_ptr
                                                         int(n_grid), C.c_void_p(int(edges_ptr)), C.c_void_p(int(map_out_ptr))))
 
 
+def route_particles_count_device(x_ptr, n, n_grid, edges_ptr, world, owner_ptr, counts_ptr, device=0, stream=0):
+    """pass 1 of the particle routing of a slab-decomposed grid (enqueue-only): owner[n] uint8, counts[world] int32"""
+    _lib.check(_lib.load().bfgx_route_particles_count_device(int(device), C.c_void_p(int(stream) or None), int(n), C.c_void_p(int(x_ptr) or None), int(n_grid),
+                                                            C.c_void_p(int(edges_ptr)), int(world), C.c_void_p(int(owner_ptr) or None), C.c_void_p(int(counts_ptr))))
+
+
+def route_particles_fill_device(col_ptrs, n, owner_ptr, world, start, total, cursor_ptr, cols_out_ptr, device=0, stream=0):
+    """pass 2: cols_out[c][start[d] + ...] = column c of the particles bound for rank d (len(col_ptrs) <= 4 columns)"""
+    st = np.ascontiguousarray(start, dtype=np.int64)
+    cp = (C.c_void_p * len(col_ptrs))(*[int(q) for q in col_ptrs])
+    _lib.check(_lib.load().bfgx_route_particles_fill_device(int(device), C.c_void_p(int(stream) or None), int(n), len(col_ptrs), cp, C.c_void_p(int(owner_ptr) or None),
+                                                           int(world), st.ctypes.data, int(total), C.c_void_p(int(cursor_ptr)), C.c_void_p(int(cols_out_ptr) or None)))
+
+
 def fft_pitch(n_grid):
     """complex values per row of the half-spectrum work arrays: n/2 + 1 rounded up to whole 128-byte lines"""
     return int(_lib.load().bfgx_fft_pitch(int(n_grid)))

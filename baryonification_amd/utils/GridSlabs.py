@@ -52,11 +52,40 @@ def _allreduce(t, op):
     return t
 
 
-def route_particles(cols, edges, n, world):
+def _route_particles_hip(cols, edges, n, world, backend):
+    """route_particles through libbfgx (two kernels: owners + counts, then the columns packed by destination)"""
+    import torch
+    eng, dev = backend.engine, cols.device
+    w, m = int(cols.shape[0]), int(cols.shape[1])
+    owner = torch.empty(max(m, 1), dtype=torch.uint8, device=dev)
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    eng.route_particles_count_device(cols[0].data_ptr(), m, n, edges.data_ptr(), world, owner.data_ptr(), counts.data_ptr(),
+                                     device=backend.device, stream=backend.stream)
+    t_in = counts.to(torch.int64)
+    t_out = torch.empty_like(t_in)
+    _a2a(t_out, t_in, None, None)                    # how many particles every rank sends me
+    ins, outs = [[int(c) for c in row] for row in torch.stack([t_in, t_out]).tolist()]
+    total = sum(ins)
+    packed = cols.new_empty((w, total))
+    cursor = torch.empty(world, dtype=torch.int32, device=dev)
+    start = np.concatenate([[0], np.cumsum(ins)[:-1]]).astype(np.int64)
+    eng.route_particles_fill_device([cols[i].data_ptr() for i in range(w)], m, owner.data_ptr(), world, start, total, cursor.data_ptr(),
+                                    packed.data_ptr(), device=backend.device, stream=backend.stream)
+    recv = cols.new_empty((w, sum(outs)))
+    for i in range(w):
+        _a2a(recv[i], packed[i], outs, ins)
+    return recv
+
+
+def route_particles(cols, edges, n, world, backend=None):
     """cols [w][m] (rows x, y, z[, mass]; columns = particles held by this rank) -> [w][m'] the particles whose first-axis bin
     lies in this rank's slab.  Bin rule of np.histogramdd: edges[b] <= x < edges[b + 1], the last edge inclusive, anything
-    else dropped.  One all_to_all_single per coordinate (the blocks per destination are contiguous in a sorted column)."""
+    else dropped.  One all_to_all_single per coordinate (the blocks per destination are contiguous in a sorted column).
+    With a HipBackend and columns on its GPU the owners, counts and the packing are libbfgx kernels instead of a torch sort."""
     import torch
+    if backend is not None and getattr(backend, 'engine', None) is not None and cols.is_cuda and cols.is_contiguous() and world <= 255 \
+            and cols.shape[0] <= 4 and cols.dtype == torch.float64:
+        return _route_particles_hip(cols, edges, n, world, backend)
     cnt = n // world
     x = cols[0]
     b = torch.bucketize(x, edges, right=True) - 1
@@ -208,7 +237,7 @@ def slab_step(backend, rows, cat, n, L, nk, timers=None):
             t_last[0] = now
 
     edges = torch.from_numpy(np.linspace(0, L, n + 1)).to(rows.device)                         # io.py:651 np.linspace(0, L, N_grid + 1)
-    mine = route_particles(rows, edges, n, world)
+    mine = route_particles(rows, edges, n, world, backend)
     lap('route')
     slab = backend.deposit(mine, edges, lo, cnt)                                               # ParticleSnapshot.make_map
     lap('deposit')

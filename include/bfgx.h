@@ -382,6 +382,16 @@ int  bfgx_deposit_particles_slab_device(int device, void *hip_stream, int32_t nd
 int64_t bfgx_power_spectrum_work_doubles(int32_t n_grid);
 /* complex values per row of the half spectrum in every work array below: n_grid/2 + 1 rounded up to a multiple of 8 */
 int32_t bfgx_fft_pitch(int32_t n_grid);
+/* routing of particles to the ranks that own their planes (slab decomposition: rank r owns the planes [r n/world, (r + 1) n/world) of
+ * the first axis; bin rule of np.histogramdd on x, particles outside the edges are dropped).  Pass 1 (enqueue-only): owner_dev[n]
+ * (uint8 scratch) and counts_dev[world] (int32) = particles bound for every rank.  Pass 2, after the caller has read the counts:
+ * cols_out_dev[c][start[d] + ...] = column c of the particles bound for rank d (ncols <= 4 columns of `total` = sum(counts) kept
+ * particles each, any order inside a destination); cursor_dev[world] int32 scratch. */
+int  bfgx_route_particles_count_device(int device, void *hip_stream, int64_t n, const double *x_dev, int32_t n_grid, const double *edges_dev,
+                                       int32_t world, uint8_t *owner_dev, int32_t *counts_dev);
+int  bfgx_route_particles_fill_device(int device, void *hip_stream, int64_t n, int32_t ncols, const double *const *cols_dev,
+                                      const uint8_t *owner_dev, int32_t world, const int64_t *start_host, int64_t total,
+                                      int32_t *cursor_dev, double *cols_out_dev);
 int  bfgx_power_spectrum_device(int device, void *hip_stream, int32_t n_grid, const double *map_dev, double L, int32_t nk,
                                 double *work_dev, double *pk_sum_dev, double *k_sum_dev, unsigned long long *counts_dev);
 

@@ -483,3 +483,42 @@ def test_slab_kernels_side_by_side_equal_the_full_grid(gpu, N, W, monkeypatch):
     ok = cnt_full > 0
     assert ((psum - sums_full).abs()[:, ok] <= 1e-11 * sums_full.abs()[:, ok]).all().item()
     be.close()
+
+
+@pytest.mark.parametrize('world,ncols', [(1, 3), (4, 4), (8, 3)])
+def test_particle_routing_kernels(gpu, world, ncols):
+    """bfgx_route_particles_count_device / _fill_device (slab decomposition over GPUs): owners follow np.histogramdd's bin rule on the
+    first coordinate, particles outside the edges are dropped, every destination receives exactly its particles (any order)"""
+    import torch
+    from baryonification_amd import engine
+    dev = torch.device('cuda:0')
+    N, L, n = 64, 100.0, 700_000
+    rng = np.random.default_rng(world)
+    cols = rng.uniform(-0.02 * L, 1.02 * L, (ncols, n))
+    cols[0, :5] = [0.0, L, L / 2, np.nextafter(L, 2 * L), -1e-12]           # first edge, last edge (inclusive), an inner edge, just outside
+    edges = np.linspace(0, L, N + 1)
+    d_cols = torch.from_numpy(cols).to(dev)
+    d_edges = torch.from_numpy(edges).to(dev)
+    owner = torch.empty(n, dtype=torch.uint8, device=dev)
+    counts = torch.empty(world, dtype=torch.int32, device=dev)
+    engine.route_particles_count_device(d_cols[0].data_ptr(), n, N, d_edges.data_ptr(), world, owner.data_ptr(), counts.data_ptr())
+    b = np.searchsorted(edges, cols[0], side='right') - 1
+    b[cols[0] == edges[-1]] = N - 1
+    inside = (b >= 0) & (b < N)
+    want_owner = np.where(inside, b // (N // world), 255)
+    assert np.array_equal(owner.cpu().numpy(), want_owner)
+    c = counts.cpu().numpy().astype(np.int64)
+    assert np.array_equal(c, np.bincount(want_owner[inside], minlength=world)) and c.sum() < n
+    total = int(c.sum())
+    start = np.concatenate([[0], np.cumsum(c)[:-1]])
+    packed = torch.full((ncols, total), float('nan'), dtype=torch.float64, device=dev)
+    cursor = torch.empty(world, dtype=torch.int32, device=dev)
+    engine.route_particles_fill_device([d_cols[i].data_ptr() for i in range(ncols)], n, owner.data_ptr(), world, start, total, cursor.data_ptr(),
+                                       packed.data_ptr())
+    got = packed.cpu().numpy()
+    assert np.isfinite(got).all()
+    for d in range(world):
+        sel = np.nonzero(want_owner == d)[0]
+        blk = got[:, start[d]:start[d] + c[d]]
+        order_g, order_w = np.lexsort(blk[::-1]), np.lexsort(cols[:, sel][::-1])
+        assert np.array_equal(blk[:, order_g], cols[:, sel][:, order_w])          # the same particles, column by column
