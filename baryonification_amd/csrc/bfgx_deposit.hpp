@@ -78,35 +78,39 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
     const bool lds_edges = g.nb + 1 <= kDepEdgesLds;                 // the bin search then never leaves the CU
     if (lds_edges) for (int i = tid; i <= g.nb; i += 256) sedge[i] = edges[i];
     __syncthreads();
-    const double *e = lds_edges ? sedge : edges;
     const double scale = (double)g.nb / (edges[g.nb] - edges[0]);
     const int64_t base = (int64_t)blockIdx.x * kDepChunk;
     // 8 particles per thread in flight: the loads of a batch are issued before any of the bin searches
-    constexpr int kBatch = 8;
-    for (int q0 = 0; q0 < kDepPer; q0 += kBatch) {
-        double vx[kBatch], vy[kBatch], vz[kBatch];
+    // the search runs on `e`: called once per address space so that the LDS copy is read with ds_read (a pointer selected at run time
+    // between LDS and global memory is a flat pointer: every edge read then goes through the flat path)
+    auto run = [&](const auto *e) {
+        constexpr int kBatch = 8;
+        for (int q0 = 0; q0 < kDepPer; q0 += kBatch) {
+            double vx[kBatch], vy[kBatch], vz[kBatch];
 #pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            const int64_t p = base + (q0 + q) * 256 + tid;
-            const bool on = p < n;
-            vx[q] = on ? x[p] : 0.0; vy[q] = on ? y[p] : 0.0; vz[q] = (DIM == 3 && on) ? z[p] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            const int64_t p = base + (q0 + q) * 256 + tid;
-            if (p >= n) continue;
-            int bx = histogram_bin(e, g.nb, vx[q], scale);
-            const int by = histogram_bin(e, g.nb, vy[q], scale);
-            const int bz = (DIM == 3) ? histogram_bin(e, g.nb, vz[q], scale) : 0;
-            uint32_t key = kDepNoKey;
-            bx = (bx >= g.plane_lo && bx < g.plane_lo + g.plane_n) ? bx - g.plane_lo : -1;
-            if (bx >= 0 && by >= 0 && bz >= 0) {
-                key = dep_key(g, bx, by, bz);
-                atomicAdd(hist + (int)((key >> kDepLocalBits) >> g.lB2), 1);
+            for (int q = 0; q < kBatch; ++q) {
+                const int64_t p = base + (q0 + q) * 256 + tid;
+                const bool on = p < n;
+                vx[q] = on ? x[p] : 0.0; vy[q] = on ? y[p] : 0.0; vz[q] = (DIM == 3 && on) ? z[p] : 0.0;
             }
-            keys[p] = key;
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const int64_t p = base + (q0 + q) * 256 + tid;
+                if (p >= n) continue;
+                int bx = histogram_bin(e, g.nb, vx[q], scale);
+                const int by = histogram_bin(e, g.nb, vy[q], scale);
+                const int bz = (DIM == 3) ? histogram_bin(e, g.nb, vz[q], scale) : 0;
+                uint32_t key = kDepNoKey;
+                bx = (bx >= g.plane_lo && bx < g.plane_lo + g.plane_n) ? bx - g.plane_lo : -1;
+                if (bx >= 0 && by >= 0 && bz >= 0) {
+                    key = dep_key(g, bx, by, bz);
+                    atomicAdd(hist + (int)((key >> kDepLocalBits) >> g.lB2), 1);
+                }
+                keys[p] = key;
+            }
         }
-    }
+    };
+    if (lds_edges) run(sedge); else run(edges);
     __syncthreads();
     // per-workgroup histogram, bucket-major: an exclusive scan of this array hands every workgroup its range in every bucket
     // (global cursors would be 128 addresses hammered by 16 384 workgroups)
@@ -276,16 +280,18 @@ route_particles_count_kernel(int64_t n, const double *__restrict__ x, const doub
     const bool lds_edges = nb + 1 <= kDepEdgesLds;
     if (lds_edges) for (int i = tid; i <= nb; i += 256) sedge[i] = edges[i];
     __syncthreads();
-    const double *e = lds_edges ? sedge : edges;
     const double scale = (double)nb / (edges[nb] - edges[0]);
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t j0 = (int64_t)blockIdx.x * per, j1 = min(n, j0 + per);
-    for (int64_t j = j0 + tid; j < j1; j += 256) {
-        const int b = histogram_bin(e, nb, x[j], scale);
-        const int d = (b >= 0) ? min(b / cnt, world - 1) : (int)kRouteDropped;
-        owner[j] = (uint8_t)d;
-        if (b >= 0) atomicAdd(&hist[d], 1);
-    }
+    auto run = [&](const auto *e) {                     // (once per address space: see deposit_keys_kernel)
+        for (int64_t j = j0 + tid; j < j1; j += 256) {
+            const int b = histogram_bin(e, nb, x[j], scale);
+            const int d = (b >= 0) ? min(b / cnt, world - 1) : (int)kRouteDropped;
+            owner[j] = (uint8_t)d;
+            if (b >= 0) atomicAdd(&hist[d], 1);
+        }
+    };
+    if (lds_edges) run(sedge); else run(edges);
     __syncthreads();
     if (tid < world && hist[tid]) atomicAdd(counts + tid, hist[tid]);
 }
