@@ -546,10 +546,8 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         }
         return sx;
     };
-    Src nxt = fetch(tid);
     for (int idx = tid; idx < NR * LWs; idx += 256) {
-        const Src cur = nxt;
-        nxt = fetch(idx + 256);
+        const Src cur = fetch(idx);
         if (cur.ok && cur.own) sum_in += cur.val;
         if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
         const double val = cur.val;
