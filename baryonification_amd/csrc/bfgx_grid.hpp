@@ -361,9 +361,11 @@ grid_regrid_kernel(int N, int64_t ntot, const double *__restrict__ offsets, cons
                 atomicAdd(map_out + p + (int64_t)sw.apron * plane_cells, v);
                 sum_out = v;
             } else {
+                // (32-bit arithmetic: npix^ndim < 2^31 for every grid the plan accepts, and 64-bit divisions are software loops)
                 int p0, p1, p2 = 0;
-                if (DIM == 3) { p2 = (int)(p % N); const int64_t q = p / N; p1 = (int)(q % N); p0 = (int)(q / N); }
-                else { p1 = (int)(p % N); p0 = (int)(p / N); }
+                const unsigned pu = (unsigned)p, Nu = (unsigned)N;
+                if (DIM == 3) { p2 = (int)(pu % Nu); const unsigned q = pu / Nu; p1 = (int)(q % Nu); p0 = (int)(q / Nu); }
+                else { p1 = (int)(pu % Nu); p0 = (int)(pu / Nu); }
                 const double pos[3] = {o[0] + (double)p1, o[1] + (double)(p0 + sw.lo), o[2] + (double)p2};
                 sum_out = deposit_cell<DIM>(pos, v, N, map_out, sw, missed);
             }
