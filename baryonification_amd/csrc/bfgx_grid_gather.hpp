@@ -203,24 +203,24 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
             for (int q = 0; q < DIM; ++q) o[c][q] = oacc[(tid + 256 * c) * DIM + q];
         }
     }
-    // the regrid of the block's cells (grid_regrid_kernel, whole-grid case)
+    // the regrid of the block's cells (grid_regrid_kernel, whole-grid case).  map_out already holds a copy of map_in
+    // (grid_copy_sum_kernel): a cell that is not displaced deposits into itself with weight 1, i.e. it is done -- only the ~10 % of
+    // cells inside a ball take their value out again and spread it (2.3e8 -> 1.1e8 fp64 atomics on a 512^3 grid; the atomics are what
+    // bounds this half of the kernel).  sum_in here = the sum of (deposited - source) over the moved cells.
     double sum_in = 0.0, sum_out = 0.0;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         if (!live[c]) continue;
-        const int64_t p = (DIM == 3) ? ((int64_t)pc[c][0] * N + pc[c][1]) * N + pc[c][2] : (int64_t)pc[c][0] * N + pc[c][1];
-        const double v = map_in[p];
-        sum_in += v;
-        if (v == 0.0) continue;                          // an empty cell adds exactly nothing
 #pragma unroll
         for (int q = 0; q < DIM; ++q) if (!isfinite(o[c][q])) o[c][q] = 0.0;       // :580 / :591
-        if (o[c][0] == 0.0 && o[c][1] == 0.0 && o[c][2] == 0.0) {
-            atomicAdd(map_out + p, v);
-            sum_out += v;
-        } else {
-            const double pos[3] = {o[c][0] + (double)pc[c][1], o[c][1] + (double)pc[c][0], o[c][2] + (double)pc[c][2]};
-            sum_out += deposit_cell<DIM>(pos, v, N, map_out);
-        }
+        if (o[c][0] == 0.0 && o[c][1] == 0.0 && o[c][2] == 0.0) continue;
+        const int64_t p = (DIM == 3) ? ((int64_t)pc[c][0] * N + pc[c][1]) * N + pc[c][2] : (int64_t)pc[c][0] * N + pc[c][1];
+        const double v = map_in[p];
+        if (v == 0.0) continue;                          // an empty cell adds exactly nothing
+        const double pos[3] = {o[c][0] + (double)pc[c][1], o[c][1] + (double)pc[c][0], o[c][2] + (double)pc[c][2]};
+        const double dep = deposit_cell<DIM>(pos, v, N, map_out);
+        atomicAdd(map_out + p, -v);
+        sum_out += dep - v;
     }
     __shared__ double sa[256 / kWave], sb[256 / kWave];
     __shared__ unsigned long long sn[256 / kWave];
@@ -240,15 +240,44 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
     }
 }
 
-// sums[0] += sum(map_in), sums[1] += sum of the deposits (sums optional); *pair_total += contributing pairs (exact: < 2^53)
+// map_out = map_in (every cell deposits into itself unless the halo loop moves it); wg_sums[workgroup] = its part of sum(map_in)
 __global__ void __launch_bounds__(256)
-gather_sums_kernel(int64_t nblocks, const double *__restrict__ block_sums, double *__restrict__ sums, unsigned long long *__restrict__ pair_total)
+grid_copy_sum_kernel(int64_t n, const double *__restrict__ in, double *__restrict__ out, double *__restrict__ wg_sums)
+{
+    __shared__ double sw[256 / kWave];
+    double acc = 0.0;
+    const int64_t n2 = n >> 1;
+    const double2 *in2 = reinterpret_cast<const double2 *>(in);
+    double2 *out2 = reinterpret_cast<double2 *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const double2 v = in2[i];
+        out2[i] = v;
+        acc += v.x + v.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { out[n - 1] = in[n - 1]; acc += in[n - 1]; }
+#pragma unroll
+    for (int s = kWave >> 1; s > 0; s >>= 1) acc += __shfl_down(acc, s, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) sw[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) t += sw[w];
+        wg_sums[blockIdx.x] = t;
+    }
+}
+
+// sums[0] += sum(map_in) (the copy's per-workgroup sums), sums[1] += sum(map_in) + the moved cells' (deposited - source) (sums
+// optional); *pair_total += contributing pairs (exact: < 2^53)
+__global__ void __launch_bounds__(256)
+gather_sums_kernel(int64_t nblocks, const double *__restrict__ block_sums, int ncopy, const double *__restrict__ copy_sums,
+                   double *__restrict__ sums, unsigned long long *__restrict__ pair_total)
 {
     __shared__ double sa[256 / kWave], sb[256 / kWave], sc[256 / kWave];
     double xa = 0.0, xb = 0.0, xc = 0.0;
     for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (int64_t)gridDim.x * 256) {
-        xa += block_sums[3 * b]; xb += block_sums[3 * b + 1]; xc += block_sums[3 * b + 2];
+        xb += block_sums[3 * b + 1]; xc += block_sums[3 * b + 2];
     }
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < ncopy; b += (int64_t)gridDim.x * 256) { xa += copy_sums[b]; xb += copy_sums[b]; }
 #pragma unroll
     for (int s = kWave >> 1; s > 0; s >>= 1) { xa += __shfl_down(xa, s, kWave); xb += __shfl_down(xb, s, kWave); xc += __shfl_down(xc, s, kWave); }
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;

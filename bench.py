@@ -322,12 +322,13 @@ def main_grid(args):
             kernels[k] = float(np.mean([a.elapsed_time(b) for a, b in lst]))
         sums = d_sums.cpu().numpy()
         pk = (d_pk / d_cnt).cpu().numpy()
-        # algorithmic bytes per launch.  world == 1: 'offsets' is the cell-owned BaryonifyGrid pass (map_in read once, map_out written
-        # once, the halo lists; no pix_offsets array); 'pk': the real map read, the padded half spectrum written by the r2c pass,
+        # algorithmic bytes per launch.  world == 1: 'regrid' is the copy map_out = map_in (every cell deposits into itself unless it is
+        # moved), 'offsets' the cell-owned BaryonifyGrid pass (the halo lists; per moved cell its value and 9 read-modify-writes of
+        # map_out; no pix_offsets array); 'pk': the real map read, the padded half spectrum written by the r2c pass,
         # read + written by the middle pass and read by the last one (binned from LDS, nothing written back)
         spec = N * N * engine.fft_pitch(N) * 16
-        alg = {'regrid': N ** 3 * (3 * 8 + 8 + 8 * 8 + 8),
-               'offsets': (N ** 3 * 16 + nh * 8 * (4 + 344)) if world == 1 else pairs[0] * 3 * 8 + nh * 32,
+        alg = {'regrid': N ** 3 * 16 if world == 1 else N ** 3 * (3 * 8 + 8 + 8 * 8 + 8),
+               'offsets': (pairs[0] * (8 + 9 * 16) + nh * 8 * (4 + 344)) if world == 1 else pairs[0] * 3 * 8 + nh * 32,
                'deposit': npart * (3 * 8 + 8) + N ** 3 * 8, 'pk': N ** 3 * 8 + 4 * spec, 'displace': npart * 48 + nh * 32}
         dom = max(alg, key=lambda k: kernels.get(k) or 0.0)
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
@@ -344,10 +345,11 @@ def main_grid(args):
                           "particle_order": "coarse-cell raster" if args.sorted_particles else "random", "ngrid": N, "particles": npart, "halos_per_gpu": nh, "contributing_pairs_per_gpu": pairs[0],
                           "parallelism": "halo shards x%d + RCCL reduce(pix_offsets) -> rank 0 regrid + P(k)" % world if world > 1 else "single GPU"},
                "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
-               "kernel_ms_note": ("single GPU: 'offsets' = grid_gather_regrid_kernel (halo loop AND regrid of BaryonifyGrid in one cell-owned pass), "
+               "kernel_ms_note": ("single GPU: 'regrid' = grid_copy_sum_kernel (map_out = map_in: a cell that is not moved deposits into itself), "
+                                  "'offsets' = grid_gather_regrid_kernel (halo loop AND the regrid of the moved cells in one cell-owned pass), "
                                   "'bin' = the per-block halo lists (count, scan, fill)") if world == 1 and not snapshot else None,
                "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),
-               "roofline": {"kernel": {"regrid": "grid_regrid_kernel<3>",
+               "roofline": {"kernel": {"regrid": "grid_copy_sum_kernel" if world == 1 else "grid_regrid_kernel<3>",
                                        "offsets": "grid_gather_regrid_kernel<3> (halo loop + regrid, cell-owned)" if world == 1 else "grid_scatter_kernel<3,OFFSETS>",
                                        "deposit": "deposit_keys + 2 x deposit_split + deposit_tiles (bfgx_deposit.hpp)",
                                        "pk": "fft_r2c_lines + fft_c2c_strided + fft_c2c_strided<bins>", "displace": "snap_displace_kernel<3>"}[dom],
