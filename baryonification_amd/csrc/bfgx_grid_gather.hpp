@@ -246,15 +246,19 @@ grid_copy_sum_kernel(int64_t n, const double *__restrict__ in, double *__restric
 {
     __shared__ double sw[256 / kWave];
     double acc = 0.0;
-    const int64_t n2 = n >> 1;
-    const double2 *in2 = reinterpret_cast<const double2 *>(in);
-    double2 *out2 = reinterpret_cast<double2 *>(out);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
-        const double2 v = in2[i];
-        out2[i] = v;
-        acc += v.x + v.y;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {      // 16-byte accesses
+        const int64_t n2 = n >> 1;
+        const double2 *in2 = reinterpret_cast<const double2 *>(in);
+        double2 *out2 = reinterpret_cast<double2 *>(out);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+            const double2 v = in2[i];
+            out2[i] = v;
+            acc += v.x + v.y;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { out[n - 1] = in[n - 1]; acc += in[n - 1]; }
+    } else {                                                 // a caller's map at an odd multiple of 8 bytes
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = in[i]; out[i] = v; acc += v; }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { out[n - 1] = in[n - 1]; acc += in[n - 1]; }
 #pragma unroll
     for (int s = kWave >> 1; s > 0; s >>= 1) acc += __shfl_down(acc, s, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) sw[threadIdx.x / kWave] = acc;

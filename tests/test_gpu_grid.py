@@ -269,6 +269,14 @@ def test_grid_cell_owned_pass(gpu, ndim, N, nh):
     assert n_out == n_ref and (n_ref > 0) == (nh > 0)
     assert np.isfinite(b).all() and np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
     assert np.allclose(s_out.cpu().numpy(), s_ref.cpu().numpy(), rtol=1e-12, atol=0)
+    # maps that start at an odd multiple of 8 bytes (a caller's view into a larger buffer)
+    big_in, big_out = torch.empty(m_in.numel() + 1, dtype=torch.float64, device=dev), torch.empty(m_in.numel() + 1, dtype=torch.float64, device=dev)
+    big_in[1:] = m_in.reshape(-1)
+    big_out.fill_(float('nan'))
+    assert big_in[1:].data_ptr() % 16 == 8
+    assert plan.baryonify(dcat, big_in[1:].data_ptr(), big_out[1:].data_ptr()) == n_ref
+    torch.cuda.synchronize()
+    assert np.abs(a - big_out[1:].cpu().numpy().reshape(a.shape)).max() <= 1e-12 * np.abs(a).max()
     if nh:
         assert not np.array_equal(a, c['map'])
         os.environ['BFGX_GRID_ITEM_CAP'] = '5'                           # block lists start too small and are regrown
