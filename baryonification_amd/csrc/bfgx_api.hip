@@ -312,8 +312,18 @@ static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback
     HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 7 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel, largest |offset|^2 per tile
     if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, p->tiling.ntiles, (const int32_t *)p->tile_count,
-                       (const int32_t *)p->tile_count_b, (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles);
+    const int nt_i = p->tiling.ntiles, nsb = (nt_i + kScanTilesPerWg - 1) / kScanTilesPerWg;
+    if (nsb <= 1 || nsb > 1024) {
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_count,
+                           (const int32_t *)p->tile_count_b, (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles);
+    } else {        // NSIDE >= 2048: the scan spread over the tiles' blocks (three short launches instead of up to 48 serial rounds)
+        int32_t *tot = p->wide_tiles + nt_i + 1, *off = tot + 2048;
+        hipLaunchKernelGGL(tile_scan_part_kernel<0>, dim3(nsb), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
+                           (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles, tot, (const int32_t *)off);
+        hipLaunchKernelGGL(tile_scan_blocks_kernel, dim3(1), dim3(1024), 0, p->stream, nsb, nt_i, (const int32_t *)tot, off, p->tile_start, p->wide_tiles);
+        hipLaunchKernelGGL(tile_scan_part_kernel<1>, dim3(nsb), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
+                           (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles, tot, (const int32_t *)off);
+    }
     HIP_TRY(hipGetLastError());
     if (c->n > 0) if (int rc = launch_place(p, c)) return rc;
     return BFGX_OK;
@@ -659,7 +669,8 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             if (hipMemsetAsync(ctrl, 0, sizeof(int32_t) * (size_t)(T.ntiles + 8), p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
         }
         void *d9 = nullptr;
-        if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 1), &d9)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(wide tile list) failed"));
+        // (+ 4096 ints behind the list: per-block totals and offsets of the multi-workgroup tile scan)
+        if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 1 + 4096), &d9)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(wide tile list) failed"));
         p->wide_tiles = (int32_t *)d9;
         void *d8 = nullptr;
         if (dalloc(sizeof(double) * 2 * (size_t)(T.ntiles + 1), &d8)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(tile sums) failed"));

@@ -905,6 +905,71 @@ tile_scan_kernel(int ntiles, const int32_t *__restrict__ cnt_a, const int32_t *_
     if (tid == 0) { start[ntiles] = carry[0]; wide_tiles[0] = carry[1]; }
 }
 
+// The same scan for shells with more tiles than one workgroup covers in a round (NSIDE >= 2048: 2.4e4 .. 3.9e5 tiles, where the
+// single workgroup above spends up to 1 ms in 48 serial rounds): PHASE 0 = every workgroup sums its 8192 tiles into
+// block_tot[2 b .. 2 b + 1]; tile_scan_blocks_kernel scans those (<= 1024 blocks) into block_off and writes the two totals;
+// PHASE 1 = every workgroup scans its tiles starting from its offsets.
+constexpr int kScanTilesPerWg = 1024 * 8;
+template <int PHASE>
+__global__ void __launch_bounds__(1024)
+tile_scan_part_kernel(int ntiles, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b, const int32_t *__restrict__ cnt_w,
+                      int32_t *__restrict__ start, int32_t *__restrict__ wide_tiles, int32_t *__restrict__ block_tot, const int32_t *__restrict__ block_off)
+{
+    constexpr int kPer = 8;
+    __shared__ int32_t wtot[2][1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    const int base = blockIdx.x * kScanTilesPerWg;
+    const int lo = min(base + tid * kPer, ntiles), hi = min(lo + kPer, ntiles);
+    int32_t c[kPer], wv[kPer], s = 0, nw = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int i = lo + q;
+        c[q] = 0; wv[q] = 0;
+        if (i < hi) { const int32_t w = cnt_w[i]; c[q] = cnt_a[i] + cnt_b[i] + w; wv[q] = w > 0 ? 1 : 0; }
+        s += c[q]; nw += wv[q];
+    }
+    int32_t is = s, iw = nw;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int32_t us = __shfl_up(is, off, kWave), uw = __shfl_up(iw, off, kWave);
+        if (lane >= off) { is += us; iw += uw; }
+    }
+    if (lane == kWave - 1) { wtot[0][wid] = is; wtot[1][wid] = iw; }
+    __syncthreads();
+    int32_t ps = 0, pw = 0;
+    for (int w = 0; w < wid; ++w) { ps += wtot[0][w]; pw += wtot[1][w]; }
+    if (PHASE == 0) {
+        if (tid == 1023) { block_tot[2 * blockIdx.x] = ps + is; block_tot[2 * blockIdx.x + 1] = pw + iw; }
+        return;
+    }
+    int32_t run = block_off[2 * blockIdx.x] + ps + is - s, pos = block_off[2 * blockIdx.x + 1] + pw + iw - nw;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int i = lo + q;
+        if (i < hi) {
+            start[i] = run; run += c[q];
+            if (wv[q]) wide_tiles[1 + pos++] = i;
+        }
+    }
+}
+
+// exclusive scan of the per-block totals (nblocks <= 1024); start[ntiles] = all entries, wide_tiles[0] = tiles with wide entries
+__global__ void __launch_bounds__(1024)
+tile_scan_blocks_kernel(int nblocks, int ntiles, const int32_t *__restrict__ block_tot, int32_t *__restrict__ block_off,
+                        int32_t *__restrict__ start, int32_t *__restrict__ wide_tiles)
+{
+    __shared__ int32_t sa[1024], sb[1024];
+    const int tid = threadIdx.x;
+    sa[tid] = tid < nblocks ? block_tot[2 * tid] : 0;
+    sb[tid] = tid < nblocks ? block_tot[2 * tid + 1] : 0;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t ra = 0, rb = 0;
+        for (int b = 0; b < nblocks; ++b) { const int32_t ta = sa[b], tb = sb[b]; block_off[2 * b] = ra; block_off[2 * b + 1] = rb; ra += ta; rb += tb; }
+        start[ntiles] = ra; wide_tiles[0] = rb;
+    }
+}
+
 // tile binning, pass 2 (thread per halo): narrow halos with reserved slots are a plain scatter of halo indices; the others
 // draw slots from their region's cursor (many-tile halos enumerate their tiles again from the span kept in the TileRef)
 __global__ void __launch_bounds__(256)
