@@ -1103,8 +1103,15 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2>), dim3(nwalk), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
+    // the two sums of the mass check: added up by the last launch, or -- above 16384 tiles, where that single workgroup's loop
+    // takes 0.2 - 0.6 ms -- by 64 workgroups afterwards
+    const bool many = nt > 16384 && sums_dev != nullptr && ts != nullptr;
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 1>), dim3(nfix), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
-                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, sums_dev);
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, many ? (double *)nullptr : sums_dev);
+    if (many) {
+        (void)hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream);
+        hipLaunchKernelGGL(sum_tiles_multi_kernel, dim3(64), dim3(256), 0, p->stream, nt, (const double *)ts, sums_dev);
+    }
 }
 
 namespace { void dep_release_all(); void fft_release_all(); }
