@@ -855,7 +855,11 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
     }
     if (sums_dev) {
         KernelTimer kt(p, BFGX_K_SUM);
-        hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(256), 0, p->stream, t1 - t0, (const double *)(p->tile_sums + 2 * (size_t)t0), sums_dev);
+        if (t1 - t0 > 16384) {
+            HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
+            hipLaunchKernelGGL(sum_tiles_multi_kernel, dim3(64), dim3(256), 0, p->stream, t1 - t0, (const double *)(p->tile_sums + 2 * (size_t)t0), sums_dev);
+        } else
+            hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(256), 0, p->stream, t1 - t0, (const double *)(p->tile_sums + 2 * (size_t)t0), sums_dev);
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;
