@@ -251,8 +251,9 @@ tile_apron_kernel(Hpx h, Tiling T, const float *__restrict__ tile_omax, int ring
                 m = fmaxf(m, tile_omax[t20 + u]);
             }
         }
+        const bool still = !(m > 0.0f);                                  // no offset in the tile nor within reach of it
         m = fminf(__builtin_sqrtf(m) * 1.001f, (float)cap);             // (tile_omax holds |o|^2)
-        R = regrid_reach_rings(h.nside, (double)m);
+        R = still ? 0 : regrid_reach_rings(h.nside, (double)m);          // R = 0: the regrid of this tile is a copy
     }
     // apron columns: a source pixel c columns outside the tile on its ring reaches it only if
     // c <= 1.5 + (its move in columns of its own ring) + nr_source / nr_target.  The move in columns, lim / (sth - lim) nr / 2 pi,
@@ -464,6 +465,34 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     const int R = (PASS == 2) ? reach.apron[2 * tile] : 1;     // (a compile-time constant in the lean kernel)
     const int kap = (PASS == 1 || nphi == 1) ? 0 : reach.apron[2 * tile + 1];
     if (PASS == 0 && reach.apron[2 * tile] > 1) continue;      // (block-uniform) left to the kernel with the ring walk
+    if (PASS == 0 && reach.apron[2 * tile] == 0) {
+        // a still tile (a sparse catalog leaves most of the sphere alone): nothing moves in it nor into it from within the reach,
+        // so its pixels deposit into themselves -- a copy, with the reference's rule that only positive pixels are regridded
+        const int lane = tid & (kWave - 1), wid = tid / kWave;
+        for (int rr = wid; rr < i1 - i0; rr += 256 / kWave) {
+            int64_t st; int64_t nr64; bool shf_;
+            ring_info_small(h, i0 + rr, st, nr64, shf_);
+            const int ks = tile_ks(tj, (int)nr64, nphi), ke = tile_ks(tj + 1, (int)nr64, nphi);
+            for (int k = ks + lane; k < ke; k += kWave) {
+                const double v = map_in[st + k];
+                const double dep = (v > 0.0) ? v : 0.0;                       // HealpixRunner.py:335
+                map_out[st + k] = dep;
+                sum_in += v; sum_out += dep;
+            }
+        }
+        if (tile_sums) {
+#pragma unroll
+            for (int sft = kWave >> 1; sft > 0; sft >>= 1) { sum_in += __shfl_down(sum_in, sft, kWave); sum_out += __shfl_down(sum_out, sft, kWave); }
+            if (lane == 0) { acc[2 * wid] = sum_in; acc[2 * wid + 1] = sum_out; }
+            __syncthreads();
+            if (tid == 0) {
+                double sa_ = 0.0, sb_ = 0.0;
+                for (int wv = 0; wv < 256 / kWave; ++wv) { sa_ += acc[2 * wv]; sb_ += acc[2 * wv + 1]; }
+                tile_sums[2 * (int64_t)tile] = sa_; tile_sums[2 * (int64_t)tile + 1] = sb_;
+            }
+        }
+        continue;
+    }
     for (int i = tid; i < T.BR * T.W; i += 256) acc[i] = 0.0;
     const int NT = T.BR + 2 * R + 2;                           // rings rth0 .. rth0 + NT - 1 in the ring tables
     const int rth0 = i0 - R - 1;

@@ -516,3 +516,37 @@ def test_route_kernels_pack_every_halo_for_every_rank_it_touches(gpu):
         assert np.array_equal(np.sort(ids), want[j])                       # the right halos, each once
         assert np.array_equal(blk, host[ids])                               # whole rows travel together
     plan.close()
+
+
+@pytest.mark.parametrize('nh', [0, 3, 60])
+def test_sparse_catalog_still_tiles_are_copied(gpu, nh):
+    """a catalog that leaves most of the sphere alone: tiles without an offset in or within reach of them are copied by K2
+    (positive pixels only, as the reference regrids them: HealpixRunner.py:335), the others regridded -- fused call and separate
+    regrid both == the oracle's regrid of the same pix_offsets"""
+    from oracle import oracle as O
+    N, nside = 4000, 256
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    npix = 12 * nside * nside
+    hmap = syn.make_map(nside)
+    rng = np.random.default_rng(nh)
+    hmap[rng.integers(0, npix, 500)] = 0.0                                   # empty and negative pixels deposit nothing
+    hmap[rng.integers(0, npix, 500)] = -1.5
+    d_map = torch.from_numpy(hmap).to(dev)
+    cd, cols = _cat_dev(torch, _lib, dev, cat, idx=np.arange(nh))
+    off = torch.full((npix * 3,), float('nan'), dtype=torch.float64, device=dev)
+    out_f, out_s = torch.full((npix,), float('nan'), dtype=torch.float64, device=dev), torch.full((npix,), float('nan'), dtype=torch.float64, device=dev)
+    s_f, s_s = torch.zeros(2, dtype=torch.float64, device=dev), torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out_f.data_ptr(), s_f.data_ptr(), acc_f64=True)
+    plan.regrid(d_map.data_ptr(), off.data_ptr(), out_s.data_ptr(), s_s.data_ptr(), acc_f64=True)
+    torch.cuda.synchronize()
+    plan.status()
+    o = off.cpu().numpy().reshape(npix, 3)
+    assert np.isfinite(o).all()
+    moved = int((np.abs(o).sum(axis=1) > 0).sum())
+    assert (moved == 0) if nh == 0 else (0 < moved < npix // 4)               # most of the sphere is still
+    ora = O.regrid(nside, hmap, o)
+    for got, sums in ((out_f, s_f), (out_s, s_s)):
+        g = got.cpu().numpy()
+        assert np.isfinite(g).all() and np.abs(g - ora).max() <= 1e-10 * np.abs(ora).max()
+        assert np.isclose(sums[0].item(), hmap.sum(), rtol=1e-12) and np.isclose(sums[1].item(), hmap[hmap > 0].sum(), rtol=1e-12)
+    plan.close()
