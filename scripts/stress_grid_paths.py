@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Randomised cross-check on one GPU (not part of the test suite; run through gpurun): the cell-owned BaryonifyGrid pass against
+the halo-owned kernels (pix_offsets + regrid) for random grid sizes / halo counts / dimensions, and the shell regrid with still
+tiles against the oracle's regrid for random sparse catalogs.  Prints one line per case and exits non-zero on a mismatch."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+
+
+def grid_case(rng, torch, engine, _lib, syn, k):
+    ndim = int(rng.integers(2, 4))
+    N = int(rng.integers(9, 97)) if ndim == 3 else int(rng.integers(17, 400))
+    nh = int(rng.integers(0, 1500))
+    L = float(rng.uniform(1.0, 4.0)) * N
+    bins = (np.arange(N) + 0.5) * (L / N)
+    M = (10 ** rng.uniform(12.3, 15.1, max(nh, 1))).astype(np.float32).astype(np.float64)[:nh]
+    pos = rng.uniform(-0.0, L, (max(nh, 1), 3)).astype(np.float32).astype(np.float64)[:nh]
+    zr = 0.3
+    z = np.linspace(zr - 0.05, zr + 0.05, 3)
+    Mt = np.geomspace(10 ** 12.4, 10 ** 15.0, 8)                       # some halos fall outside the table: NaN poisoning
+    r = np.geomspace(1e-3, 2e2, 200)
+    d = syn.displacement_table(z, Mt, r) * float(rng.choice([1.0, 5.0, 40.0]))
+    cos = dict(syn.COSMO, w0=-1.0)
+    m, keep = engine.model_from_tables([np.log(1 + z), np.log(Mt), np.log(r)], d, cos, float(rng.uniform(2.0, 9.0)), 8.0)
+    dev = torch.device('cuda:0')
+    t = [torch.tensor(a, dtype=torch.float64, device=dev) for a in (M, pos[:, 0], pos[:, 1], pos[:, 2])]
+    lnM = torch.tensor(np.log(M.astype(np.float32)).astype(np.float64), device=dev)
+    plan = engine.GridPlan(m, keep, bins, ndim, zr, max(nh, 1), 0, torch.cuda.current_stream().cuda_stream)
+    dcat = _lib.make_grid_catalog_dev(nh, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr() if ndim == 3 else 0, lnM.data_ptr())
+    hmap = rng.poisson(2.0, (N,) * ndim).astype(np.float64)
+    hmap[rng.random(hmap.shape) < 0.05] = -0.5
+    m_in = torch.tensor(hmap, device=dev)
+    off = torch.empty((N ** ndim, ndim), dtype=torch.float64, device=dev)
+    ref, out = torch.empty_like(m_in), torch.full_like(m_in, float('nan'))
+    s_ref, s_out = (torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(2))
+    n_ref = plan.offsets(dcat, off.data_ptr())
+    plan.regrid(m_in.data_ptr(), off.data_ptr(), ref.data_ptr(), s_ref.data_ptr())
+    n_out = plan.baryonify(dcat, m_in.data_ptr(), out.data_ptr(), s_out.data_ptr())
+    torch.cuda.synchronize()
+    a, b = ref.cpu().numpy(), out.cpu().numpy()
+    err = np.abs(a - b).max() / max(np.abs(a).max(), 1e-300)
+    ok = n_out == n_ref and np.isfinite(b).all() and err <= 1e-11 and np.allclose(s_out.cpu().numpy(), s_ref.cpu().numpy(), rtol=1e-11, atol=1e-9)
+    print("grid  %3d: ndim %d N %3d halos %4d pairs %8d  max|d|/max %.1e  %s" % (k, ndim, N, nh, n_ref, err, "ok" if ok else "MISMATCH"), flush=True)
+    plan.close()
+    return ok
+
+
+def shell_case(rng, torch, engine, _lib, syn, O, k):
+    nside = int(rng.choice([64, 128, 256]))
+    nh = int(rng.choice([0, 1, 5, 40, 400, 3000]))
+    cat = syn.make_catalog(max(nh, 4000))
+    z, M, r = syn.table_grid(cat)
+    table = syn.displacement_table(z, M, r) * float(rng.choice([1.0, 30.0, 300.0]))
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    model, keep = engine.model_from_tables(axes, table, syn.COSMO, 10.0, 10.0)
+    dev = torch.device('cuda:0')
+    plan = engine.ShellPlan(model, keep, nside, max(nh, 1), 0, torch.cuda.current_stream().cuda_stream)
+    if rng.random() < 0.5:                                              # a patch of the sky
+        cat = {kk: v.copy() for kk, v in cat.items()}
+        cat['ra'] = cat['ra'] % 40.0
+        cat['dec'] = np.clip(cat['dec'], -20.0, 30.0)
+    cols = {kk: torch.from_numpy(np.ascontiguousarray(v[:nh])).to(dev) for kk, v in cat.items()}
+    cd = _lib.make_catalog_dev(nh, cols['M'].data_ptr(), cols['z'].data_ptr(), cols['ra'].data_ptr(), cols['dec'].data_ptr())
+    npix = 12 * nside * nside
+    hmap = syn.make_map(nside)
+    hmap[rng.integers(0, npix, 200)] = 0.0
+    hmap[rng.integers(0, npix, 200)] = -2.0
+    d_map = torch.from_numpy(hmap).to(dev)
+    off = torch.full((npix * 3,), float('nan'), dtype=torch.float64, device=dev)
+    out = torch.full((npix,), float('nan'), dtype=torch.float64, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=True)
+    torch.cuda.synchronize()
+    plan.status()
+    o = off.cpu().numpy().reshape(npix, 3)
+    ora = O.regrid(nside, hmap, o)
+    g = out.cpu().numpy()
+    err = np.abs(g - ora).max() / np.abs(ora).max()
+    moved = int((np.abs(o).sum(axis=1) > 0).sum())
+    ok = np.isfinite(o).all() and np.isfinite(g).all() and err <= 1e-10 and np.isclose(sums[1].item(), hmap[hmap > 0].sum(), rtol=1e-10)
+    print("shell %3d: nside %3d halos %4d moved pixels %7d / %7d  max|d|/max %.1e  %s" % (k, nside, nh, moved, npix, err, "ok" if ok else "MISMATCH"), flush=True)
+    plan.close()
+    return ok
+
+
+def main():
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    from oracle import oracle as O
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    bad = 0
+    for k in range(n):
+        bad += not grid_case(rng, torch, engine, _lib, syn, k)
+        bad += not shell_case(rng, torch, engine, _lib, syn, O, k)
+    print("mismatches: %d" % bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
