@@ -87,6 +87,59 @@ def shell_case(rng, torch, engine, _lib, syn, O, k):
     return ok
 
 
+def offsets_case(rng, torch, engine, _lib, syn, O, k):
+    """K0 + K1 (fp64) and K3 against the oracle's halo loop: list lengths per tile from 1 to hundreds (chunk sizes), several NSIDE"""
+    nside = int(rng.choice([32, 64, 128, 256, 512]))
+    nh = int(rng.choice([1, 7, 100, 1500, 6000]))
+    eps = float(rng.choice([4.0, 10.0, 25.0]))
+    paint = bool(rng.random() < 0.4)
+    cat = syn.make_catalog(max(nh, 4000))
+    if rng.random() < 0.3:
+        cat = {kk: v.copy() for kk, v in cat.items()}
+        cat['dec'][: max(nh // 10, 1)] = rng.choice([89.9, -89.95, 89.0], max(nh // 10, 1))      # discs on the pole caps
+    z, M, r = syn.table_grid(cat)
+    table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    with np.errstate(divide='ignore'):
+        model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, eps, eps, log_values=paint)
+    dev = torch.device('cuda:0')
+    plan = engine.ShellPlan(model, keep, nside, nh, 0, torch.cuda.current_stream().cuda_stream)
+    sub = {kk: np.ascontiguousarray(v[:nh]) for kk, v in cat.items()}
+    cols = {kk: torch.from_numpy(v).to(dev) for kk, v in sub.items()}
+    lnz, lnM = _lib.table_coords(sub['M'], sub['z'])
+    tz, tM = torch.from_numpy(lnz).to(dev), torch.from_numpy(lnM).to(dev)
+    cd = _lib.make_catalog_dev(nh, cols['M'].data_ptr(), cols['z'].data_ptr(), cols['ra'].data_ptr(), cols['dec'].data_ptr(),
+                               ln1pz_ptr=tz.data_ptr(), lnM_ptr=tM.data_ptr())
+    npix = 12 * nside * nside
+    bg = O.Background.from_dict(syn.COSMO)
+    if paint:
+        with np.errstate(divide='ignore'):
+            tab = O.Table(axes, np.log(table))
+        ora = O.paint_shell(nside, sub, tab, eps, bg)
+        got = torch.full((npix,), float('nan'), dtype=torch.float64, device=dev)
+        plan.paint(cd, got.data_ptr(), acc_f64=True)
+        mixed = torch.full((npix,), float('nan'), dtype=torch.float64, device=dev)
+        plan.paint(cd, mixed.data_ptr(), acc_f64=2)
+        torch.cuda.synchronize()
+        g, mx = got.cpu().numpy(), mixed.cpu().numpy()
+        scale = max(np.abs(ora).max(), 1e-300)
+        err = np.abs(g - ora).max() / scale
+        ok = err <= 1e-10 and bool((np.abs(mx - g) <= 5e-5 * np.abs(g) + 1e-12 * scale).all())
+    else:
+        tab = O.Table(axes, table, False, eps)
+        ora = O.baryonify_offsets(nside, sub, tab, eps, bg)
+        got = torch.full((npix * 3,), float('nan'), dtype=torch.float64, device=dev)
+        plan.offsets(cd, got.data_ptr(), True)
+        torch.cuda.synchronize()
+        g = got.cpu().numpy().reshape(npix, 3)
+        err = np.abs(g - ora).max()
+        ok = np.isfinite(g).all() and err <= 1e-12
+    plan.status()
+    print("%s %3d: nside %3d halos %4d eps %4.1f  max|d| %.1e  %s" % ("paint" if paint else "offs ", k, nside, nh, eps, err, "ok" if ok else "MISMATCH"), flush=True)
+    plan.close()
+    return ok
+
+
 def main():
     import torch
     from baryonification_amd import _lib, engine, synthetic as syn
@@ -97,6 +150,7 @@ def main():
     for k in range(n):
         bad += not grid_case(rng, torch, engine, _lib, syn, k)
         bad += not shell_case(rng, torch, engine, _lib, syn, O, k)
+        bad += not offsets_case(rng, torch, engine, _lib, syn, O, k)
     print("mismatches: %d" % bad)
     sys.exit(1 if bad else 0)
 
