@@ -3,9 +3,12 @@
 bench.py -- BaryonifyShell hot path on MI355X: halos/s for a 1e6-halo synthetic catalog into an
 NSIDE=1024 HEALPix shell (BASELINE.json configs[1]), inputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]     # N > 1 without a launcher: the N ranks are started as a CHILD
+                                                            # `python -m torch.distributed.run` (this process never touches HIP)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    ... bench.py --gpus N --scaling strong            # ONE 1e6-halo catalog split over the N GPUs (north_star's wording)
+    ... bench.py --gpus N                             # STRONG scaling (north_star): ONE 1e6-halo catalog split over the N GPUs;
+                                                      # the line carries the weak number (1e6 halos per GPU) as `value_weak`
+    ... bench.py --gpus N --scaling weak              # weak scaling only
     ... bench.py --gpus 8 --config 4                  # BASELINE config 4: 1e7 halos, NSIDE 2048, over the GPUs given
 
 One step = one full pass of the hot path: [N>1, default --exchange spatial: every halo's catalog row is routed (RCCL
@@ -13,8 +16,9 @@ all_to_all) to the ranks whose ring bands its disc touches ->] K0 halo_prep (per
 tile_scatter2 (pix_offsets; tile-owned LDS accumulation, no global atomics) -> [N>1: all_reduce(MAX) of the largest
 |offset|, exchange of that many apron rings ->] K2 tile_regrid3 (gathering regrid: every output pixel stored once) -> the
 two sums of the mass-conservation check [-> N>1: disjoint slices to rank 0].  --exchange slices / reduce keep the halo
-shards where they are and exchange pix_offsets instead.  N>1 is weak scaling by default (every rank owns its own 1e6-halo
-shard of an N x 1e6 catalog on the same shell); value = all halos / max-over-ranks time.
+shards where they are and exchange pix_offsets instead.  N>1 is STRONG scaling by default (ONE 1e6-halo catalog, shuffled as
+Parallelize.py:255 does, rank r holds the r-th slice); value = all halos / max-over-ranks time.  `value_weak` = the same step
+with 1e6 halos PER GPU on the same shell.
 --mode paint (BASELINE config 3 with --nside 2048): K0 -> K3, the pair phase in fp32 accumulated in fp64 into the fp64 map
 (--acc-f64: fp64 throughout; `value_acc_f64` carries that number on the default line).  --mode grid3d / snapshot: config 5.
 
@@ -44,8 +48,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=600, help='timed steps (default 600: a timed region of ~0.5 s at config 2)')
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
-                    help="N > 1: 'weak' = --halos per GPU (default), 'strong' = ONE --halos catalog split over the GPUs (north_star's wording)")
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help="N > 1: 'strong' (default) = ONE --halos catalog split over the GPUs (north_star's metric; the weak number rides "
+                         "along as `value_weak`), 'weak' = --halos per GPU")
     ap.add_argument('--config', type=int, default=0, choices=[0, 4],
                     help='4 = BASELINE config 4: 1e7 halos, NSIDE 2048, BaryonifyShell, strong scaling over the GPUs given (8 in the config)')
     ap.add_argument('--no-extras', action='store_true', help='skip value_acc_f64 and end_to_end (N = 1 only)')
@@ -68,8 +73,9 @@ def parse():
                     help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
                          "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
     ap.add_argument('--exchange', choices=['spatial', 'slices', 'reduce'], default='spatial',
-                    help="N > 1: 'slices' = all_to_all reduce-scatter by pixel slices + banded regrid + windows to rank 0 (default); "
-                         "'reduce' = one reduce(sum) of the whole accumulator to rank 0")
+                    help="N > 1: 'spatial' (default) = halos routed to the owners of the ring bands their discs touch, no accumulator "
+                         "crosses a link; 'slices' = halo shards + all_to_all reduce-scatter of pix_offsets by pixel slices + banded regrid; "
+                         "'reduce' = halo shards + one reduce(sum) of the whole accumulator to rank 0")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket the kernels with HIP events in the timed region (no roofline object)')
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample (single-thread baseline)')
@@ -363,34 +369,87 @@ def main_grid(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher (RANK unset): start the N ranks as a CHILD `python -m torch.distributed.run`
+    (one process per GPU over RCCL), relay its output and return code.  This parent has touched neither torch nor HIP, and it does
+    not exec: a process that has initialised the GPU must never be replaced.  One call drives all workers, as
+    SplitJoinParallel(runner, njobs).process() does (Parallelize.py:191-320)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this image
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dist_context(args):
+    """(rank, world, local_rank, device, backend) of this rank; checks the launch and the GPU.  BFGX_DIST_BACKEND=gloo: functional
+    rehearsal of the N > 1 path on a one-GPU box (all ranks share device 0, collectives staged through the host; timings of such a
+    run mean nothing).  BFGX_BENCH_STOP_AFTER_INIT=1 (launcher test, no GPU): rendezvous over gloo, rank 0 prints a stub line, exit."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node == --gpus, or without a launcher)" % (world, args.gpus))
+    backend = os.environ.get('BFGX_DIST_BACKEND', 'nccl')
+    if os.environ.get('BFGX_BENCH_STOP_AFTER_INIT') == '1':
+        dist.init_process_group('gloo')
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launcher_ok": True, "n_gpus": int(t.item()), "scaling": args.scaling}), flush=True)
+        dist.destroy_process_group()
+        sys.exit(0)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (libbfgx has no CPU fallback)")
+    local_rank = int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    return rank, world, local_rank, dev, backend
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))
     if args.mode in ('grid3d', 'snapshot'):
         return main_grid(args)
+    import torch.distributed as dist
+    rank, world, local_rank, dev, backend = ctx = dist_context(args)
+    if world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1':
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+    scaling = 'strong' if args.config == 4 else args.scaling
+    out = shell_line(args, ctx, scaling, brief=False)
+    if world > 1 and scaling == 'strong' and not args.no_extras and args.config != 4:
+        # the weak-scaling number of the same step (--halos per GPU on the same shell) rides along; `value` stays north_star's metric
+        w = shell_line(args, ctx, 'weak', brief=True)
+        if rank == 0:
+            out["value_weak"] = {k: w[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling", "mass_conserved")}
+            out["value_weak"]["workload"] = w["config"]["workload"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def shell_line(args, ctx, scaling, brief):
+    """One bench line of the HEALPix-shell path (rank 0 returns the dict, the others None).  `brief`: the timed region only (no
+    per-kernel events, fp64 / end-to-end extras or CPU baseline): the weak-scaling companion of a strong line."""
     import torch
     import torch.distributed as dist
     from baryonification_amd import _lib, engine, synthetic as syn
-
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus (got WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (libbfgx has no CPU fallback)"
-    # BFGX_DIST_BACKEND=gloo: functional rehearsal of the N > 1 path on a one-GPU box (all ranks share device 0 and the
-    # collectives are staged through the host); timings of such a run mean nothing
-    backend = os.environ.get('BFGX_DIST_BACKEND', 'nccl')
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1':
-        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+    rank, world, local_rank, dev, backend = ctx
 
     paint = args.mode == 'paint'
     if args.config == 4:            # BASELINE config 4: 1e7 halos, BaryonifyShell, NSIDE 2048, halo-sharded over 8 GPUs
-        args.nside, args.scaling = 2048, 'strong'
+        args.nside = 2048
         args.halos = 10_000_000 if args.halos == 1_000_000 else args.halos
     nside, npix = args.nside, 12 * args.nside ** 2
-    strong = args.scaling == 'strong'
+    strong = scaling == 'strong'
     total_halos = args.halos if strong else args.halos * world
     if strong:
         # ONE catalog (BASELINE seeds), shuffled as Parallelize.py:255 does, rank r takes the r-th ceil(N/world) slice
@@ -586,28 +645,17 @@ def main():
 
     step = run_steps(args.acc_f64)
     if slices or spatial:
-        # one untimed trial of the slice exchange; the ranks AGREE on whether it worked (a failure on one rank only -- out of
-        # memory, an overflowing entry list -- must not leave the others in a different collective)
-        ok = 1
+        # one untimed trial step.  A rank that fails (out of memory, an overflowing entry list) may have left its peers inside a
+        # collective, so nothing is agreed on afterwards and no fallback runs on the same communicator: the rank reports and exits
+        # non-zero, torch.distributed.run then ends the other ranks, and the launcher (or the user) starts a fresh run.
         try:
             step()
             fence()
+            (plan_sp if spatial else plan).status()
         except Exception as e:        # noqa: BLE001
-            ok = 0
-            print("bench[rank %d]: slice exchange failed (%s: %s)" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
-        if dist.is_initialized():
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == 'nccl' else 'cpu')
-            try:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            except Exception:         # noqa: BLE001  the communicator itself is broken: do not continue on it
-                sys.exit(3)
-        if not ok:
-            if rank == 0:
-                print("bench: falling back to --exchange reduce on every rank", file=sys.stderr, flush=True)
-            slices = spatial = False
-            step = run_steps(args.acc_f64)
-        elif not paint:
+            print("bench[rank %d]: the multi-rank step failed (%s: %s); try --exchange reduce" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            os._exit(3)
+        if not paint:
             # did a far deposit land in another rank's slice?  then every step routes the lists (collective decision)
             nf = d_foreign.clone() if backend == 'nccl' else d_foreign.cpu()
             if dist.is_initialized():
@@ -622,14 +670,14 @@ def main():
     # the timed region proper: EXACTLY --steps passes, no per-kernel events (they cost ~0.05 ms per step); `value` comes from it
     elapsed, _ = timed(step, args.steps, False)
     # the same K steps again with HIP events around every kernel on the launch stream (bfgx_plan_timing_*): kernel_ms, roofline
-    elapsed_ev, kt = timed(step, args.steps, True) if not args.no_kernel_events else (None, None)
+    elapsed_ev, kt = timed(step, args.steps, True) if not (args.no_kernel_events or brief) else (None, None)
     if os.environ.get('BFGX_BENCH_NOSTATUS') != '1':   # (timing-only ablation builds produce meaningless offsets)
         (plan_sp if spatial else plan).status()   # entry-list capacity, far-deposit list
     if (slices or spatial) and not paint:
         assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
 
     extra = {}
-    if world == 1 and paint and not args.acc_f64 and args.algo == 1 and not args.no_extras:
+    if world == 1 and paint and not args.acc_f64 and args.algo == 1 and not args.no_extras and not brief:
         step64 = run_steps(True)                 # fp64 pair math too (the 1e-10 parity path)
         for _ in range(3):
             step64()
@@ -638,7 +686,7 @@ def main():
         extra["value_acc_f64"] = {"value": total_halos / el64 * n64, "unit": "halos/s", "ms_per_step": el64 / n64 * 1e3, "steps": n64,
                                   "dtype": "f64 throughout (fp64 pair math, fp64 LDS accumulation, fp64 map)"}
         del step64
-    if world == 1 and not paint and not args.acc_f64 and args.algo == 1 and not args.no_extras:
+    if world == 1 and not paint and not args.acc_f64 and args.algo == 1 and not args.no_extras and not brief:
         # the same step with fp64 pix_offsets accumulators and fp64 pair math (1e-10 parity path)
         step64 = run_steps(True)
         for _ in range(3):
@@ -657,15 +705,17 @@ def main():
         tot = d_sums.clone() if backend == 'nccl' else d_sums.cpu()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         d_sums.copy_(tot)
+    out = None
     if rank == 0:
         sums = d_sums.cpu().numpy()
         ms_step = elapsed / args.steps * 1e3
         out = {
             "metric": "halos/sec for %s NSIDE=%d (1e6-halo synthetic catalog%s)" % (
-                "PaintProfilesShell" if paint else "BaryonifyShell", nside, " per GPU" if not strong else ", halo-sharded over the GPUs"),
+                "PaintProfilesShell" if paint else "BaryonifyShell", nside,
+                "" if world == 1 else (", ONE catalog split over the GPUs" if strong else " per GPU")),
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": ("f64" if args.acc_f64 else
                       "f64 ring-row geometry + f64 LDS accumulation + f64 map; f32 pair math (chord, ln r, read-out, exp)" if paint else
                       "f64 ring-row geometry + f64 LDS accumulation / map; f32 pair math, f32 pix_offsets, f32 regrid geometry"),
@@ -694,14 +744,12 @@ def main():
             out["kernel_ms"] = kernels
             out["roofline"] = roofline(args, kernels, n_pairs, nh, npix, paint)
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline and not paint:
+        if world == 1 and not args.no_cpu_baseline and not paint and not brief:
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
-        print(json.dumps(out), flush=True)
     plan.close()
     if 'plan_sp' in locals():
         plan_sp.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 def roofline(args, kernels, n_pairs, nh, npix, paint):

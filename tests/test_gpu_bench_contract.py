@@ -34,7 +34,7 @@ def _check_common(d, n_gpus=1):
 def test_default_mode_line_small(gpu):
     d = _run('--halos', '20000', '--nside', '128', '--steps', '5', '--warmup', '2', '--cpu-threads', '2')
     _check_common(d)
-    assert d['unit'] == 'halos/s' and d['steps'] == 5 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['mass_conserved'] is True
+    assert d['unit'] == 'halos/s' and d['steps'] == 5 and d['warmup'] == 2 and d['scaling'] == 'strong' and d['mass_conserved'] is True
     assert abs(d['value'] - 20000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
@@ -57,3 +57,19 @@ def test_paint_and_grid_lines_small(gpu):
     d = _run('--mode', 'snapshot', '--ngrid', '64', '--grid-halos', '500', '--steps', '2', '--warmup', '1', '--no-cpu-baseline')
     _check_common(d)
     assert d['unit'] == 'particles/s' and d['mass_conserved'] is True
+
+
+def test_two_ranks_self_launched_strong_and_weak(gpu):
+    """`python bench.py --gpus 2` as the driver types it (no launcher): the ranks are started as a child torch.distributed.run; both share
+    device 0 over gloo (a one-GPU box), the product's HIP kernels + every exchange step of the spatial sharding run for real"""
+    env = dict(os.environ, BFGX_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--halos', '20000', '--nside', '128', '--steps', '3',
+                          '--warmup', '1'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    _check_common(d, n_gpus=2)
+    assert d['scaling'] == 'strong' and d['mass_conserved'] is True and d['config']['halos_per_gpu'] == 10000
+    w = d['value_weak']
+    assert w['scaling'] == 'weak' and w['value'] > 0 and w['mass_conserved'] is True
