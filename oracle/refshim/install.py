@@ -99,7 +99,11 @@ def _make_pyccl():
     ccl.h_over_h0 = bgm.h_over_h0
 
     pyutils = types.ModuleType('pyccl.pyutils')
-    pyutils._fftlog_transform = _unavailable('_fftlog_transform')
+    # CCL's C FFTLog is absent: the published algorithm restated in oracle/fftlog.py stands in for it (parity with the CCL binary
+    # stays unpinned), so that the reference's OWN wrapper around it (utils/Pixel.py ConvolvedProfile: padding grid, windows,
+    # clip at pixel / 5, PCHIP read-back) runs unmodified -- tests/golden/make_golden_pixel.py
+    from oracle import fftlog as _F
+    pyutils._fftlog_transform = _F.fftlog_transform
     ccl.pyutils = pyutils
 
     # ---- halos

@@ -2,7 +2,12 @@
 
 The reference calls pyccl.pyutils._fftlog_transform, which is not available here (**parity with CCL unpinned**).  The oracle
 (oracle/fftlog.py) restates the published FFTLog algorithm and is pinned here against (a) analytic Hankel pairs and (b)
-scipy.fft.fht, an independent implementation of the same paper; the HIP path is then compared with the oracle (-m gpu)."""
+scipy.fft.fht, an independent implementation of the same paper; the HIP path is then compared with the oracle (-m gpu).
+The WRAPPER around the transform -- ConvolvedProfile.real / .projected, the windows -- is the reference's own code and is pinned by
+tests/golden/pixel_s19.npz: the unmodified reference classes run under refshim with oracle/fftlog.py playing the CCL transform
+(tests/golden/make_golden_pixel.py)."""
+import os
+
 import numpy as np
 import pytest
 from scipy import fft as sfft
@@ -88,6 +93,120 @@ def test_pixel_windows_cpu():
     sig = h.size / np.sqrt(8 * np.log(2)) / np.sqrt(2)
     assert np.allclose(h.projected(k), np.exp(-k * (k + 1) / 2 * sig ** 2)) and np.all(h.real(k) == 0)
     assert np.all(NoPix().real(k) == 1) and np.all(NoPix().projected(k) == 1)
+
+
+# ------------------------------------------------------------------------------------------ the reference's own wrapper (Pixel.py)
+GOLDEN_PIXEL = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pixel_s19.npz')
+
+
+def _ref_windows(name, size):
+    """the window functions restated from Pixel.py:322-366 (top hat of equal volume / area, diameter passed to the beam), :537-538
+    (Gaussian of FWHM = pixel / sqrt 2, k (k + 1)), :519-521 (no real-space HEALPix window), :576-582 (NoPix)"""
+    from scipy import special
+
+    def beam(k, R):
+        kr = k * (2 * R)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return np.where(kr > 0, 3 * special.spherical_jn(1, kr) / kr, 1)
+    if name.startswith('grid'):
+        return (lambda k: beam(k, np.cbrt(size ** 3 / (4 / 3 * np.pi)))), (lambda k: beam(k, np.sqrt(size ** 2 / np.pi))), False
+    if name.startswith('heal'):
+        sig = size / np.sqrt(8 * np.log(2)) / np.sqrt(2)
+        return (lambda k: np.zeros_like(k)), (lambda k: np.exp(-k * (1 + k) / 2 * sig ** 2)), True
+    return (lambda k: np.ones_like(k)), (lambda k: np.ones_like(k)), False
+
+
+def _pixel_cases():
+    g = np.load(GOLDEN_PIXEL)
+    return g, [str(c) for c in g['cases']]
+
+
+def test_oracle_convolved_profile_equals_reference_pixel_py():
+    """oracle.fftlog.convolved_real / convolved_projected == the reference's ConvolvedProfile fed the same profile rows"""
+    g, cases = _pixel_cases()
+    r = g['r']
+    for key in cases:
+        pname, xname, method = key.split('|')
+        size = float(g['size|' + xname])
+        w_real, w_proj, harmonic = _ref_windows(xname, size)
+        rows, r_fft, exp = g[key + '|rows'], g[key + '|r_fft'], g[key + '|expected']
+
+        def profile(x, rows=rows, r_fft=r_fft):
+            assert x.shape == r_fft.shape and np.abs(x / r_fft - 1).max() < 1e-13          # the padding grid of Pixel.py:134-139
+            return rows
+        par = dict(F.FFTLOG_DEFAULTS, plaw_fourier=-2, padding_lo_fftlog=1e-2, padding_hi_fftlog=1e2, padding_lo_extra=1e-4,
+                   padding_hi_extra=1e4)                                                     # Schneider19.py:124-128
+        if method == 'real':
+            got = F.convolved_real(profile, w_real, size, r, par)
+        else:
+            got = F.convolved_projected(profile, w_proj, size, r, harmonic, float(g['D_A_comoving']), par)
+        assert got.shape == exp.shape == (3, r.size)
+        assert np.abs(got - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1e-300), key
+    assert np.all(g['gas|heal256|real|expected'] == 0)                                       # Pixel.py:519-521
+
+
+def test_product_windows_equal_reference_windows():
+    from baryonification_amd.utils.Pixel import GridPixelApprox, HealPixel, NoPix
+    g, _ = _pixel_cases()
+    k = np.geomspace(1e-4, 1e5, 300)
+    for name, px in (('grid0p5', GridPixelApprox(0.5)), ('grid0p08', GridPixelApprox(0.08)), ('heal256', HealPixel(256)),
+                     ('heal2048', HealPixel(2048)), ('nopix', NoPix())):
+        size = float(g['size|' + name])
+        assert abs(px.size - size) <= 1e-15 * max(size, 1)
+        w_real, w_proj, harmonic = _ref_windows(name, size)
+        assert px.isHarmonic == harmonic
+        assert np.abs(px.real(k) - w_real(k)).max() <= 1e-15 and np.abs(px.projected(k) - w_proj(k)).max() <= 1e-15
+
+
+class _StoredProfile(object):
+    """a profile object that returns the rows the reference's profile returned (golden), whatever the port of the profile does"""
+
+    def __init__(self, g, key, par):
+        self.g, self.key, self.precision_fftlog = g, key, par
+
+    def _rows(self, r, scalar=False):
+        r_fft = self.g[self.key + '|r_fft']
+        assert r.shape == r_fft.shape and np.abs(r / r_fft - 1).max() < 1e-13
+        return self.g[self.key + '|rows']
+
+    def real(self, cosmo, r, M, a):
+        return self._rows(r)
+
+    def projected(self, cosmo, r, M, a):
+        return self._rows(r)
+
+
+@pytest.mark.gpu
+def test_hip_convolved_profile_vs_reference_pixel_py(gpu):
+    """the drop-in ConvolvedProfile (bfgx_fftlog_convolve on the GPU) == the reference's ConvolvedProfile on the same profile rows"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    g, cases = _pixel_cases()
+    r, M, a = g['r'], g['M'], float(g['a'])
+    cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+    par = dict(F.FFTLOG_DEFAULTS, plaw_fourier=-2, padding_lo_fftlog=1e-2, padding_hi_fftlog=1e2, padding_lo_extra=1e-4, padding_hi_extra=1e4)
+    pixels = {'grid0p5': bfg.utils.GridPixelApprox(0.5), 'grid0p08': bfg.utils.GridPixelApprox(0.08), 'heal256': bfg.utils.HealPixel(256),
+              'heal2048': bfg.utils.HealPixel(2048), 'nopix': bfg.utils.NoPix()}
+    # the comoving angular distance the harmonic cases divide by: ours vs the refshim background the golden was made with
+    from baryonification_amd.utils.Pixel import _comoving_angular_distance
+    assert abs(_comoving_angular_distance(cosmo, a) / float(g['D_A_comoving']) - 1) < 1e-12
+    for key in cases:
+        pname, xname, method = key.split('|')
+        conv = bfg.utils.ConvolvedProfile(_StoredProfile(g, key, par), pixels[xname])
+        got = getattr(conv, method)(cosmo, r, M, a)
+        exp = g[key + '|expected']
+        assert got.shape == exp.shape
+        # 1e-9 of the row's largest value: the two O(n^2) DFTs against numpy's FFT over 20+ decades of dynamic range
+        for gr, er in zip(got, exp):
+            assert np.abs(gr - er).max() <= 1e-9 * max(np.abs(er).max(), 1e-300), key
+    # our port of the Gas profile through the same path: the whole f3 chain against the reference (port accuracy: 1e-6)
+    keys, vals = [str(k) for k in g['par_keys']], g['par_vals']
+    gas = bfg.Profiles.Gas(**dict(zip(keys, (float(v) for v in vals))))
+    got = bfg.utils.ConvolvedProfile(gas, pixels['heal256']).projected(cosmo, r, M, a)
+    exp = g['gas|heal256|projected|expected']
+    assert np.abs(got - exp).max() <= 1e-6 * np.abs(exp).max()
+    one = bfg.utils.ConvolvedProfile(gas, pixels['heal256']).projected(cosmo, r, 2e14, a)
+    assert one.shape == g['gas|heal256|projected|scalarM'].shape and np.abs(one - g['gas|heal256|projected|scalarM']).max() <= 1e-6 * np.abs(one).max()
 
 
 # ------------------------------------------------------------------------------------------ GPU

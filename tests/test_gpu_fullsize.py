@@ -65,6 +65,19 @@ def test_config2_full_size_vs_oracle_and_properties(gpu):
     # default accumulators (f32 pix_offsets): the stated 1e-6 * mean(map) tolerance
     new32, s32 = regrid(offsets(cd, False, 1), False)
     assert np.abs(new32 - ora).max() <= 1e-6 * ora.mean() and np.isclose(s32[1], s32[0])
+    # the FUSED call bench.py times (bfgx_baryonify_device: K0 + K1 + K2 in one enqueue, fp32 pix_offsets, K1's per-tile maxima
+    # handed to K2), with the caller's table coordinates as bench.py passes them: straight against the oracle, same tolerance
+    cdc, keepc = _cat_dev(torch, _lib, dev, cat, coords=True)
+    plan.set_algo(1)
+    f_off = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    f_out = torch.zeros(npix, dtype=torch.float64, device=dev)
+    f_sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.baryonify(cdc, d_map.data_ptr(), f_off.data_ptr(), f_out.data_ptr(), f_sums.data_ptr(), acc_f64=False)
+    torch.cuda.synchronize()
+    plan.status()
+    fused, fs = f_out.cpu().numpy(), f_sums.cpu().numpy()
+    assert np.abs(fused - ora).max() <= 1e-6 * ora.mean() and np.isclose(fs[1], fs[0]) and np.isclose(fused.sum(), hmap.sum())
+    del f_off, f_out
 
     # (b) the two accumulation algorithms agree.  pix_offsets are differences of unit vectors, so the rounding
     # floor is absolute (~1e-16 per contribution), not relative to the ~5e-5 offsets

@@ -407,6 +407,80 @@ def test_config5_size_512_cubed(gpu):
     assert np.abs(grid - ora).max() <= 1e-12 * ora.max() and np.isclose(grid.sum(), val.sum(), rtol=1e-12)
 
 
+def test_config5_halo_loop_512_cubed_cell_owned_vs_scatter_and_oracle(gpu):
+    """BASELINE config 5 exactly as bench.py --mode grid3d builds it (512^3 cells, 1e5 halos, closed-form table): the cell-owned
+    BaryonifyGrid pass the bench times (bfgx_grid_baryonify_device, no pix_offsets array) == the scatter form (offsets + regrid,
+    oracle-pinned at 80^3) at 1e-12; the scatter form's pix_offsets == the oracle's FULL halo loop (Map2DRunner.py:539-575); the
+    regrid of a 4M-cell sample of source cells == the oracle's 5^3-cell loops (Map2DRunner.py:86-163); the mass sums."""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    from oracle import grid as G
+    from oracle import oracle as O
+    dev = torch.device('cuda:0')
+    N, nh, eps, zr = 512, 100_000, 5.0, 0.0
+    L = 205.0 / syn.COSMO['h']
+    bins = (np.arange(N) + 0.5) * (L / N)
+    rng = np.random.default_rng(syn.SEED_CATALOG)
+    M = syn.make_catalog(nh, seed=syn.SEED_CATALOG)['M'].astype(np.float32).astype(np.float64)
+    pos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    cat = {'M': M, 'x': pos[:, 0].copy(), 'y': pos[:, 1].copy(), 'z': pos[:, 2].copy()}
+    z, Mt, r = np.array([0.0, 0.01]), np.geomspace(0.99e12, 1.01e15, 10), np.geomspace(1e-3, 3e2, 500)
+    table = syn.displacement_table(z, Mt, r)
+    axes = [np.log(1 + z), np.log(Mt), np.log(r)]
+    model, keep = engine.model_from_tables(axes, table, dict(syn.COSMO, w0=-1.0), eps, eps)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = engine.GridPlan(model, keep, bins, 3, zr, nh, device=0, stream=stream)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in cat.items()}
+    lnM = torch.from_numpy(np.log(M.astype(np.float32)).astype(np.float64)).to(dev)
+    cat_dev = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr(), lnM.data_ptr())
+    torch.manual_seed(syn.SEED_MAP)
+    d_map = torch.poisson(torch.full((N ** 3,), 8.0, dtype=torch.float64, device=dev))       # ~0.03 % empty cells
+    d_off = torch.empty(N ** 3 * 3, dtype=torch.float64, device=dev)
+    d_cell = torch.full((N ** 3,), float('nan'), dtype=torch.float64, device=dev)
+    d_scat = torch.full((N ** 3,), float('nan'), dtype=torch.float64, device=dev)
+    s_cell, s_scat = (torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(2))
+    n_cell = plan.baryonify(cat_dev, d_map.data_ptr(), d_cell.data_ptr(), s_cell.data_ptr())
+    n_scat = plan.offsets(cat_dev, d_off.data_ptr())
+    plan.regrid(d_map.data_ptr(), d_off.data_ptr(), d_scat.data_ptr(), s_scat.data_ptr())
+    torch.cuda.synchronize()
+    total = float(d_map.sum().item())
+    scale = float(d_scat.abs().max().item())
+    # (1) the two forms of the halo loop + regrid
+    assert n_cell == n_scat > 1e7
+    assert torch.isfinite(d_cell).all().item() and (d_cell - d_scat).abs().max().item() <= 1e-12 * scale
+    assert not torch.equal(d_cell, d_map)
+    # (4) mass: HealpixRunner-style assert of Map2DRunner.py:601-605, from the kernels' own sums and from the maps
+    for s in (s_cell.cpu().numpy(), s_scat.cpu().numpy()):
+        assert np.isclose(s[0], total, rtol=1e-12) and np.isclose(s[1], s[0], rtol=1e-11)
+    assert np.isclose(float(d_cell.sum().item()), total, rtol=1e-11)
+    del d_cell
+    # (2) pix_offsets against the oracle's full halo loop (1.5e7 contributing cutout cells)
+    tab = O.Table(axes, table, False, eps)
+    ora_off, ora_pairs = G.baryonify_grid_offsets((N, N, N), bins, cat, zr, tab, eps, G.grid_background(syn.COSMO), return_pairs=True)
+    assert ora_pairs == n_scat
+    off = d_off.cpu().numpy().reshape(-1, 3)
+    assert np.array_equal(np.isfinite(off), np.isfinite(ora_off))               # NaN-poisoned cells are the same cells
+    fin = np.isfinite(ora_off)
+    assert np.abs(off[fin] - ora_off[fin]).max() <= 1e-10 * np.abs(ora_off[fin]).max()
+    assert np.count_nonzero(ora_off[fin]) > 1e7
+    # (3) regrid of a 4M-cell sample of SOURCE cells (the first 16 planes): GPU regrid of the map zeroed elsewhere vs the oracle
+    ns = 1 << 22
+    masked = torch.zeros_like(d_map)
+    masked[:ns] = d_map[:ns]
+    plan.regrid(masked.data_ptr(), d_off.data_ptr(), d_scat.data_ptr(), s_scat.data_ptr())
+    torch.cuda.synchronize()
+    got = d_scat.cpu().numpy().reshape(N, N, N)
+    p = np.arange(ns)
+    i, j, k = p // (N * N), (p // N) % N, p % N
+    own = np.stack([j, i, k], axis=1).astype(np.float64)         # meshgrid(indexing='xy'): column 0 carries the SECOND array axis
+    chk = np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing='xy')
+    assert [int(g.flatten()[1 * 9 + 2 * 3 + 0]) for g in chk] == [2, 1, 0]
+    posn = np.where(np.isfinite(off[:ns]), off[:ns], 0) + own           # the same offsets the GPU regrid read (pinned in (2))
+    ora = G.regrid_pixels(np.zeros((N, N, N)), posn, d_map[:ns].cpu().numpy())
+    assert np.abs(got - ora).max() <= 1e-12 * ora.max() and np.isclose(got.sum(), ora.sum(), rtol=1e-12)
+    plan.close()
+
+
 # ------------------------------------------------------------------------------------------ slab decomposition (config 5 over N GPUs)
 @pytest.mark.parametrize('N,W', [(64, 2), (64, 4), (128, 8)])
 def test_slab_kernels_side_by_side_equal_the_full_grid(gpu, N, W, monkeypatch):

@@ -183,3 +183,72 @@ def test_healpy_docstring_scalars():
     # >>> hp.nside2npix(8) -> 768 ; hp.npix2nside(768) -> 8 ; hp.nside2resol(128, arcmin=True) -> 27.483891294539248
     assert hp.nside2npix(8) == 768 and hp.npix2nside(768) == 8
     assert abs(np.degrees(hp.nside2resol(128)) * 60 - 27.483891294539248) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ query_disc known answers (hand-enumerated)
+# Pixel centres typed in by hand from the published tessellation (Gorski et al. 2005, section 4: rings of constant z, 4 pixels per ring
+# in the caps growing by 4 per ring, 4 NSIDE per equatorial ring, alternate rings offset by half a pixel; the numbering pinned by the
+# healpy docstring answers above: NSIDE 1 pixel 0 at (arccos 2/3, pi/4), pixel 4 at (pi/2, 0)).  Neither in-house pix2vec is used.
+def _centres_by_hand(nside):
+    q = np.pi / 4
+    if nside == 1:            # 3 rings of 4: z = 2/3 (phi = pi/4 + k pi/2), z = 0 (phi = k pi/2), z = -2/3 (phi = pi/4 + k pi/2)
+        rings = [(2 / 3, [q, 3 * q, 5 * q, 7 * q]), (0.0, [0, 2 * q, 4 * q, 6 * q]), (-2 / 3, [q, 3 * q, 5 * q, 7 * q])]
+    else:                     # NSIDE 2: caps z = +-11/12 (4 pixels), then z = 2/3, 1/3, 0, -1/3, -2/3 (8 pixels, every other ring offset)
+        assert nside == 2
+        half = [q / 2 + k * q for k in range(8)]              # pi/8, 3 pi/8, ...
+        full = [k * q for k in range(8)]                      # 0, pi/4, ...
+        cap = [q, 3 * q, 5 * q, 7 * q]
+        rings = [(11 / 12, cap), (2 / 3, half), (1 / 3, full), (0.0, half), (-1 / 3, full), (-2 / 3, half), (-11 / 12, cap)]
+    out = []
+    for z, phis in rings:
+        s = np.sqrt(1 - z * z)
+        out += [(s * np.cos(p), s * np.sin(p), z) for p in phis]
+    return np.array(out)
+
+
+def test_query_disc_hand_enumerated_known_answers():
+    # NSIDE 1, disc about (theta, phi) = (pi/2, 0) = the centre of pixel 4.  Distances of the 12 centres from it:
+    #   pixel 4: 0;  pixels 0, 3, 8, 11 (z = +-2/3, phi = +-pi/4): arccos(sqrt(5)/3 cos(pi/4)) = 58.19 deg;  pixels 5, 7: 90 deg;
+    #   pixels 1, 2, 9, 10: 121.81 deg;  pixel 6: 180 deg
+    c = np.array([1.0, 0.0, 0.0])
+    d58 = np.arccos(np.sqrt(5) / 3 * np.cos(np.pi / 4))
+    cases = [(1, c, 0.1, [4]), (1, c, d58 - 1e-6, [4]), (1, c, d58 + 1e-6, [0, 3, 4, 8, 11]), (1, c, np.pi / 2 - 1e-6, [0, 3, 4, 8, 11]),
+             (1, c, np.pi / 2 + 1e-6, [0, 3, 4, 5, 7, 8, 11]), (1, c, np.pi - d58 + 1e-6, [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]),
+             (1, c, np.pi - 1e-6, [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11])]
+    # NSIDE 1, disc about the north pole: the ring z = 2/3 lies at arccos(2/3) = 48.19 deg, z = 0 at 90 deg, z = -2/3 at 131.81 deg
+    n = np.array([0.0, 0.0, 1.0])
+    cases += [(1, n, np.arccos(2 / 3) - 1e-6, []), (1, n, np.arccos(2 / 3) + 1e-6, [0, 1, 2, 3]), (1, n, np.pi / 2 + 1e-6, list(range(8))),
+              (1, -n, np.arccos(2 / 3) + 1e-6, [8, 9, 10, 11])]
+    # NSIDE 2, about the north pole: rings at arccos(11/12) = 23.56 deg (pixels 0-3), arccos(2/3) = 48.19 (4-11), arccos(1/3) = 70.53 (12-19)
+    cases += [(2, n, 0.4, []), (2, n, 0.42, [0, 1, 2, 3]), (2, n, np.arccos(2 / 3) + 1e-6, list(range(12))), (2, n, np.arccos(1 / 3) + 1e-6, list(range(20))),
+              (2, -n, 0.42, [44, 45, 46, 47])]
+    # NSIDE 2, about (pi/2, pi/8) = the centre of pixel 20 (ring z = 0, first pixel, offset by half a pixel = pi/8):
+    #   neighbours on its own ring (21 and 27) at pi/4 = 45 deg; ring z = +-1/3, phi = 0 and pi/4 (pixels 12, 13 / 28, 29):
+    #   arccos(sqrt(8)/3 cos(pi/8)) = 29.42 deg
+    c20 = np.array([np.cos(np.pi / 8), np.sin(np.pi / 8), 0.0])
+    d29 = np.arccos(np.sqrt(8) / 3 * np.cos(np.pi / 8))
+    cases += [(2, c20, 0.2, [20]), (2, c20, d29 - 1e-6, [20]), (2, c20, d29 + 1e-6, [12, 13, 20, 28, 29])]
+    for nside, vec, rad, want in cases:
+        got_o = O.query_disc(nside, vec, rad).tolist()
+        got_s = hp.query_disc(nside, vec, rad).tolist()
+        assert got_o == want and got_s == want, (nside, vec, rad, got_o, got_s, want)
+        # the hand lists themselves against brute force over the hand-typed centres (guards the arithmetic in the comments)
+        v = _centres_by_hand(nside)
+        assert np.where(v @ vec > np.cos(rad))[0].tolist() == want
+
+
+@pytest.mark.parametrize('nside', [1, 2])
+def test_query_disc_random_discs_against_hand_typed_centres(nside):
+    """random discs at NSIDE 1 and 2: membership by brute force over the hand-typed centre table == both implementations"""
+    v = _centres_by_hand(nside)
+    assert v.shape == (12 * nside * nside, 3)
+    rng = np.random.default_rng(100 + nside)
+    for _ in range(300):
+        c = rng.normal(size=3)
+        c /= np.linalg.norm(c)
+        rad = rng.uniform(0.05, 3.0)
+        dist = np.arccos(np.clip(v @ c, -1, 1))
+        if np.abs(dist - rad).min() < 1e-9:
+            continue
+        want = np.where(dist < rad)[0].tolist()
+        assert O.query_disc(nside, c, rad).tolist() == want and hp.query_disc(nside, c, rad).tolist() == want
