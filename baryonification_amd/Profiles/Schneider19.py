@@ -88,10 +88,13 @@ class SchneiderProfiles(object):
         self.cutoff = kwargs.get('cutoff', 1e3)
         self.proj_cutoff = kwargs.get('proj_cutoff', self.cutoff)
         self._projected = self._projected_realspace
-        # ccl.halos.HaloProfile.precision_fftlog (pyccl 2.8.0 defaults): read by utils.Pixel.ConvolvedProfile (Pixel.py:72)
+        # ccl.halos.HaloProfile.precision_fftlog (pyccl 2.8.0 defaults) as SchneiderProfiles.__init__ overrides them
+        # (Schneider19.py:124-128; Thermodynamic.py:87-91 sets the same): read by utils.Pixel.ConvolvedProfile (Pixel.py:72)
         self.precision_fftlog = {'padding_lo_fftlog': 0.1, 'padding_lo_extra': 0.1, 'padding_hi_fftlog': 10.0, 'padding_hi_extra': 10.0,
                                  'large_padding_2D': False, 'n_per_decade': 100, 'extrapol': 'linx_liny',
                                  'plaw_fourier': -1.5, 'plaw_projected': -1.0}
+        self.update_precision_fftlog(plaw_fourier=-2)
+        self.update_precision_fftlog(padding_lo_fftlog=1e-2, padding_hi_fftlog=1e2, padding_lo_extra=1e-4, padding_hi_extra=1e4)
 
     # -- protocol -------------------------------------------------------------------------------------
     @property
@@ -215,6 +218,10 @@ class DarkMatter(SchneiderProfiles):
 
 class Stars(SchneiderProfiles):
     """central galaxy: Gaussian-truncated r^-2 (:591-626)"""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.update_precision_fftlog(padding_lo_fftlog=1e-5, padding_hi_fftlog=1e5)      # Schneider19.py:581-588
 
     def _real(self, cosmo, r, M, a):
         r_use, M_use = np.atleast_1d(r), np.atleast_1d(M)

@@ -202,6 +202,11 @@ def test_hip_convolved_profile_vs_reference_pixel_py(gpu):
     # our port of the Gas profile through the same path: the whole f3 chain against the reference (port accuracy: 1e-6)
     keys, vals = [str(k) for k in g['par_keys']], g['par_vals']
     gas = bfg.Profiles.Gas(**dict(zip(keys, (float(v) for v in vals))))
+    assert gas.precision_fftlog == par and bfg.Profiles.Pressure(gas=gas, darkmatterbaryon=gas).precision_fftlog == par      # Schneider19.py:124-128
+    assert bfg.Profiles.Stars(**dict(zip(keys, (float(v) for v in vals)))).precision_fftlog['padding_hi_fftlog'] == 1e5          # :588
+    rows = gas.projected(cosmo, g['gas|heal256|projected|r_fft'], M, a)
+    ref_rows = g['gas|heal256|projected|rows']
+    assert np.abs(rows / ref_rows - 1).max() <= 1e-6, np.abs(rows / ref_rows - 1).max()
     got = bfg.utils.ConvolvedProfile(gas, pixels['heal256']).projected(cosmo, r, M, a)
     exp = g['gas|heal256|projected|expected']
     assert np.abs(got - exp).max() <= 1e-6 * np.abs(exp).max()
