@@ -59,23 +59,34 @@ class DefaultRunner(object):
     def _catalog(self, keys):
         """bfgx_catalog over contiguous float64 columns.  The catalog is a structured array (strided columns), so every
         process() call would gather M, z, ra, dec into contiguous buffers and take two numpy logs over all halos (the table
-        coordinates np.log(1/a), np.log(M)); these are kept on the catalog object between calls instead.  A cheap fingerprint
-        (size, end points and a strided sample of every column) guards against in-place edits of the catalog."""
+        coordinates np.log(1/a), np.log(M)): ~20 ms per 1e6 halos.  These are kept on the catalog object between calls, keyed by
+        a hash of the WHOLE record buffer (xxh3 over every byte of every halo: ~2 ms per 1e6 halos), so that any in-place edit of
+        the catalog -- one halo, a swap that leaves sums unchanged -- is seen, as it is by the reference, which re-reads `cat` on
+        every call.  Without the xxhash module nothing is cached."""
         cat = self.HaloLightConeCatalog.cat
         names = ['M', 'z', 'ra', 'dec'] + list(keys)
-        step = max(1, cat.size // 4096)
-        finger = (cat.size, tuple(names)) + tuple(float(np.sum(cat[k][::step], dtype=np.float64)) + float(cat[k][-1] if cat.size else 0.0)
-                                                  for k in names)
-        cached = getattr(self.HaloLightConeCatalog, '_bfgx_columns', None)
+        finger = _catalog_fingerprint(cat, names)
+        cached = getattr(self.HaloLightConeCatalog, '_bfgx_columns', None) if finger is not None else None
         if cached is None or cached[0] != finger:
             cols = [_lib.f8(cat[k]) for k in names]
             cached = (finger, cols, _lib.table_coords(cols[0], cols[1]))
-            try:
-                self.HaloLightConeCatalog._bfgx_columns = cached
-            except AttributeError:
-                pass
+            if finger is not None:
+                try:
+                    self.HaloLightConeCatalog._bfgx_columns = cached
+                except AttributeError:
+                    pass
         cols = cached[1]
         return _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], cols[4:], coords=cached[2])
+
+
+def _catalog_fingerprint(cat, names):
+    """(size, dtype, column names, 64-bit xxh3 of all record bytes), or None when it cannot be formed (no xxhash)"""
+    try:
+        import xxhash
+    except ImportError:
+        return None
+    buf = cat if cat.flags.c_contiguous else np.ascontiguousarray(cat)
+    return (cat.size, str(cat.dtype), tuple(names), xxhash.xxh3_64(buf.view(np.uint8)).intdigest() if cat.size else 0)
 
 
 class BaryonifyShell(DefaultRunner):

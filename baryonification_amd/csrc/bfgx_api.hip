@@ -482,6 +482,7 @@ extern "C" {
 
 int bfgx_abi_version(void) { return BFGX_ABI_VERSION; }
 
+
 const char *bfgx_last_error(void) { return g_err.c_str(); }
 
 int bfgx_device_count(void)

@@ -37,19 +37,15 @@ __device__ inline double fma_(double a, double b, double c) { return __builtin_f
 
 template <> struct PMath<float> {
     static constexpr float kHuge = 1.0e37f;
-    static __device__ inline float rsq(float x)
-    {
-        const float y = __builtin_amdgcn_rsqf(x);
-        return y * __builtin_fmaf(-0.5f * x * y, y, 1.5f);                 // one Newton step
-    }
+    // v_rsq_f32 is good to 1 ulp, which is what every other fp32 step of the pair phase carries: no Newton step
+    static __device__ inline float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
     static __device__ inline float half_ln(float x) { return 0.34657359027997264f * __builtin_amdgcn_logf(x); }   // 0.5 ln 2 log2 x
     static __device__ inline float expv(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
-    // sin x and 1 - cos x for |x| <= 0.5 (truncation < 3e-9 relative)
+    // sin x and 1 - cos x for |x| <= 0.5 (truncation < 5e-9 relative)
     static __device__ inline void sin_omc(float x, float &sn, float &omc)
     {
         const float u = x * x;
-        float ps = 1.0f / 362880.0f;
-        ps = __builtin_fmaf(ps, u, -1.0f / 5040.0f);
+        float ps = -1.0f / 5040.0f;                                        // (x^9 / 9! < 5e-9 x for |x| <= 0.5)
         ps = __builtin_fmaf(ps, u, 1.0f / 120.0f);
         ps = __builtin_fmaf(ps, u, -1.0f / 6.0f);
         sn = __builtin_fmaf(x * u, ps, x);
@@ -203,7 +199,7 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     const real uu = (lx - tb.r0) * tb.inv_dr;
     const int i = max(0, min((int)uu, tb.nr - 2));
     const real tr_ = uu - (real)i;
-    const real *tp = tb.v + ph.cell + i * 8;
+    const real *tp = tb.v + (unsigned)(ph.cell + i * 8);           // (cell >= 0: 32-bit offset from the uniform table base)
     real q[8];
     if (BFGX_ABL2 == 6) { for (int k = 0; k < 8; ++k) q[k] = tr_ * (real)(k + 1); }
     else if (sizeof(real) == 4) {
@@ -233,16 +229,17 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     if (sizeof(real) == 4) o.amb = ok && cutting && fabsf((float)(u2 - ph.cut2)) <= 4e-6f * (float)ph.cut2;
     // offset / D = d a diff / (r_sep D) = (d a / D) u / |u|; renormalised (v + e)/|v + e| - v (:326-328) as a
     // series in t = 2 v.e + e.e (|v| = 1): e + g (v + e), g = -t/2 + 3 t^2/8 - 5 t^3/16 + 35 t^4/128
-    const real sc = d * ph.aD * rinv;
-    const real ex0 = sc * ux, ey0 = sc * uy, ez0 = sc * uz;
-    const real fx = fma_(-rg.sth, omc, rg.sth), fy = uy, fz = rg.zf;   // pixel unit vector, rotated frame
-    const real tt = (real)2 * (fx * ex0 + fy * ey0 + fz * ez0) + (ex0 * ex0 + ey0 * ey0 + ez0 * ez0);
+    const real sc = d * ph.aD * rinv;                              // e = sc u
+    const real fx = fma_(-rg.sth, omc, rg.sth), fy = uy, fz = rg.zf;   // pixel unit vector v, rotated frame
+    // v.u = v.(v - v_halo) = 1 - v.v_halo = |u|^2 / 2 for unit vectors, so t = 2 v.e + e.e = sc |u|^2 (1 + sc): no dot products
+    const real tt = sc * u2 * ((real)1 + sc);
     real g = (real)(35.0 / 128.0);
     g = fma_(g, tt, (real)-0.3125);
     g = fma_(g, tt, (real)0.375);
     g = fma_(g, tt, (real)-0.5);
     g = g * tt;
-    const real ex = fma_(g, fx + ex0, ex0), ey = fma_(g, fy + ey0, ey0), ez = fma_(g, fz + ez0, ez0);
+    const real c1 = fma_(g, sc, sc);                               // e + g (v + e) = (1 + g) sc u + g v
+    const real ex = fma_(c1, ux, g * fx), ey = fma_(c1, uy, g * fy), ez = fma_(c1, uz, g * fz);
     o.v0 = ex * ph.cph0 - ey * ph.sph0;                            // rotate back by +phi0
     o.v1 = ex * ph.sph0 + ey * ph.cph0;
     o.v2 = ez;

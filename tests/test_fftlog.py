@@ -254,17 +254,17 @@ def test_hip_convolved_profile_vs_oracle(gpu):
         conv = bfg.utils.ConvolvedProfile(prof, pixel)
         m = r >= 0.1
         got = conv.real(cosmo, r, M, a)
-        ora = F.convolved_real(lambda x: prof.real(cosmo, x, M, a), pixel.real, pixel.size, r)
+        ora = F.convolved_real(lambda x: prof.real(cosmo, x, M, a), pixel.real, pixel.size, r, prof.precision_fftlog)
         assert got.shape == (3, r.size) and np.abs(got - ora)[:, m].max() <= 1e-8 * np.abs(ora[:, m]).max()
         got2 = conv.projected(cosmo, r, M, a)
-        ora2 = F.convolved_projected(lambda x: prof.projected(cosmo, x, M, a), pixel.projected, pixel.size, r, False)
+        ora2 = F.convolved_projected(lambda x: prof.projected(cosmo, x, M, a), pixel.projected, pixel.size, r, False, None, prof.precision_fftlog)
         assert np.abs(got2 - ora2)[:, m].max() <= 1e-8 * np.abs(ora2[:, m]).max()
     # harmonic pixel: angles through D_A, clipping at pixel / 5 * D_A
     hpx = bfg.utils.HealPixel(256)
     conv = bfg.utils.ConvolvedProfile(prof, hpx)
     D_A = float(cosmo.angular_diameter_distance(a)) / a
     got = conv.projected(cosmo, r, M, a)
-    ora = F.convolved_projected(lambda x: prof.projected(cosmo, x, M, a), hpx.projected, hpx.size, r, True, D_A)
+    ora = F.convolved_projected(lambda x: prof.projected(cosmo, x, M, a), hpx.projected, hpx.size, r, True, D_A, prof.precision_fftlog)
     assert np.abs(got - ora).max() <= 1e-8 * np.abs(ora).max()
     assert np.all(conv.real(cosmo, r, M, a) == 0)                      # no real-space HEALPix window (Pixel.py:519-521)
     # scalar-M call mirrors the rank, attribute access falls through to the wrapped profile
