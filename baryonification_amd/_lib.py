@@ -103,6 +103,8 @@ SYMBOLS = {
     'bfgx_route_count_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'bfgx_route_fill_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
+    'bfgx_route_pack_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     'bfgx_bands_max_offset2_device': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'bfgx_max_offset2_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'bfgx_plan_tile_shape': (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),

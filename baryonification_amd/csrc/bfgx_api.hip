@@ -815,16 +815,23 @@ int bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings)
 int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
                              int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev)
 {
-    if (!p || !map_in_dev || !offsets_dev || !out_slice_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "banded regrid needs the tiled algorithm (algo 1)");
     int64_t need_lo = 0, need_hi = 0;
     if (int rc = bfgx_plan_band_apron(p, band0, band1, &need_lo, &need_hi)) return rc;
+    if (band0 == band1) {
+        // a rank that owns no band (more ranks than bands): empty buffers, whose data pointers are NULL, are fine
+        HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
+        if (sums_dev) HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
+        return BFGX_OK;
+    }
+    if (!map_in_dev || !offsets_dev || !out_slice_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (olo > need_lo || ohi < need_hi || olo < 0 || ohi > p->hpx.npix)
         return fail(BFGX_ERR_INVALID, "pix_offsets range [%lld, %lld) does not cover the bands and %d ring(s) either side [%lld, %lld)",
                     (long long)olo, (long long)ohi, p->band_reach, (long long)need_lo, (long long)need_hi);
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
-    if (band0 == band1) return BFGX_OK;
     const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * band0);
     const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
     {
@@ -914,12 +921,13 @@ int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev
 static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *out_slice_dev, int acc_f64, bool paint)
 {
     if (int rc = check_catalog(p, cat)) return rc;
-    if (!out_slice_dev) return fail(BFGX_ERR_INVALID, "output pointer is NULL");
     if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "band-restricted passes need the tiled algorithm (algo 1)");
     if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
     if ((p->model.tab.logv != 0) != paint) return fail(BFGX_ERR_INVALID, paint ? "profile painting needs a table with log_values = 1"
                                                                                : "displacement read-out needs a table with log_values = 0");
+    // a rank that owns no band (more ranks than bands) passes the data pointer of an empty buffer, which is NULL: nothing to do
     if (band0 == band1) return BFGX_OK;
+    if (!out_slice_dev) return fail(BFGX_ERR_INVALID, "output pointer is NULL");
     HIP_TRY(hipSetDevice(p->device));
     const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * band0);
     p->k1_tile_lo = p->band_tile0_host[band0];
@@ -1037,6 +1045,30 @@ int bfgx_route_fill_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, in
     if (n > 0) {
         hipLaunchKernelGGL(route_halos_kernel<true>, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRouteGrid)), dim3(256), 0, p->stream, a, n, rings_dev, (int32_t *)nullptr,
                            cursor_dev, rows_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return BFGX_OK;
+}
+
+int bfgx_route_pack_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, int64_t blockcap,
+                           int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *blocks_dev, int32_t *overflow_dev)
+{
+    bfgx_catalog c;
+    std::memset(&c, 0, sizeof(c));
+    c.n = n;
+    RouteArgs a;
+    if (n < 0 || !cursor_dev || !blocks_dev || !overflow_dev || (n > 0 && !rings_dev)) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (blockcap < 1) return fail(BFGX_ERR_INVALID, "block capacity must be >= 1");
+    if (int rc = route_args(p, &c, world, ring_bounds, ncols, cols_dev, a)) return rc;
+    a.blockcap = blockcap; a.overflow = overflow_dev;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemsetAsync(cursor_dev, 0, sizeof(int32_t) * world, p->stream));
+    hipLaunchKernelGGL(route_blank_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)world * blockcap + 255) / 256, 1024)), dim3(256), 0, p->stream,
+                       world, ncols, blockcap, blocks_dev);
+    HIP_TRY(hipGetLastError());
+    if (n > 0) {
+        hipLaunchKernelGGL(route_halos_kernel<true>, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRouteGrid)), dim3(256), 0, p->stream, a, n, rings_dev, (int32_t *)nullptr,
+                           cursor_dev, blocks_dev);
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;

@@ -806,6 +806,8 @@ struct RouteArgs {
     int32_t bounds[kRouteMaxRanks + 1];          // first ring of every rank's run of bands, + one past the last ring
     int64_t start[kRouteMaxRanks];               // fill pass: first row of every destination in the send buffer
     const double *col[kRouteMaxCols];            // the catalog columns to pack into rows
+    int64_t blockcap;                            // > 0: fixed-capacity blocks [world][ncols][blockcap] (column-major inside a block)
+    int32_t *overflow;                           // blockcap > 0: set to 1 when a destination receives more than blockcap halos
 };
 
 __device__ inline void route_range(const RouteArgs &a, int first, int last, int &jlo, int &jhi)
@@ -849,10 +851,27 @@ route_halos_kernel(RouteArgs a, int64_t n, const int32_t *__restrict__ rings, in
         int jlo, jhi;
         route_range(a, rings[2 * j], rings[2 * j + 1], jlo, jhi);
         for (int d = jlo; d <= jhi; ++d) {
-            double *row = rows + (a.start[d] + base[d] + atomicAdd(&taken[d], 1)) * a.ncols;
-            for (int c = 0; c < a.ncols; ++c) row[c] = a.col[c][j];
+            const int64_t slot = base[d] + atomicAdd(&taken[d], 1);
+            if (a.blockcap > 0) {
+                // fixed-capacity blocks: the splits of the all_to_all are known without reading any count back
+                if (slot >= a.blockcap) { *a.overflow = 1; continue; }
+                double *blk = rows + (int64_t)d * a.ncols * a.blockcap + slot;
+                for (int c = 0; c < a.ncols; ++c) blk[c * a.blockcap] = a.col[c][j];
+            } else {
+                double *row = rows + (a.start[d] + slot) * a.ncols;
+                for (int c = 0; c < a.ncols; ++c) row[c] = a.col[c][j];
+            }
         }
     }
+}
+
+// column 0 (M) of every fixed-capacity block := NaN, so that the rows a destination does not receive are dropped by K0 as invalid halos
+__global__ void __launch_bounds__(256)
+route_blank_kernel(int32_t world, int32_t ncols, int64_t blockcap, double *__restrict__ rows)
+{
+    const int64_t n = (int64_t)world * blockcap;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        rows[(i / blockcap) * ncols * blockcap + (i % blockcap)] = __builtin_nan("");
 }
 
 // exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total.  A tile's list is laid out as

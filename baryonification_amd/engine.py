@@ -65,6 +65,15 @@ class ShellPlan(object):
                                                      st.ctypes.data, len(col_ptrs), cols, C.c_void_p(int(cursor_ptr)),
                                                      C.c_void_p(int(rows_ptr) or None)))
 
+    def route_pack(self, n, rings_ptr, ring_bounds, blockcap, col_ptrs, cursor_ptr, blocks_ptr, overflow_ptr):
+        """routing in one pass with nothing read back (enqueue-only): blocks[world][len(col_ptrs)][blockcap], rows a destination does not
+        receive keep M = NaN (column 0); *overflow (int32, device, zeroed by the caller) is set when a block is too small"""
+        rb = np.ascontiguousarray(ring_bounds, dtype=np.int32)
+        cols = (C.c_void_p * len(col_ptrs))(*[int(c) for c in col_ptrs])
+        _lib.check(_lib.load().bfgx_route_pack_device(self._h, int(n), C.c_void_p(int(rings_ptr) or None), int(rb.size - 1), rb.ctypes.data,
+                                                     int(blockcap), len(col_ptrs), cols, C.c_void_p(int(cursor_ptr)), C.c_void_p(int(blocks_ptr)),
+                                                     C.c_void_p(int(overflow_ptr))))
+
     def bands_max_offset2(self, band0, band1, out_ptr):
         """largest |offset|^2 (float32, device) of the slice offsets_bands() has just written for the bands [band0, band1): reduced
         from the per-tile maxima K1 leaves, no pass over the slice"""

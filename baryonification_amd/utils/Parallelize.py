@@ -51,7 +51,7 @@ import os
 import numpy as np
 
 __all__ = ['SplitJoinParallel', 'SimpleParallel', 'shard_slices', 'distributed_process', 'band_partition', 'sliced_reduce',
-           'halo_exchange', 'gather_slices', 'route_halos', 'band_ring_bounds']
+           'halo_exchange', 'gather_slices', 'route_halos', 'route_halos_fixed', 'band_ring_bounds']
 
 
 def shard_slices(n, world):
@@ -134,6 +134,47 @@ def route_halos(cols, rings, ring_bounds, plan=None):
     recv = rows.new_empty((sum(outs), k))
     _a2a(recv.view(-1), rows.contiguous().view(-1), [o * k for o in outs], [i * k for i in ins])
     return recv.t().contiguous()
+
+
+def route_halos_fixed(cols, rings, ring_bounds, blockcap, plan=None, work=None):
+    """route_halos for a resident step: nothing is read back by the host.  Every (source, destination) pair gets a block of `blockcap`
+    rows -- the equal splits of ONE all_to_all_single --, rows a destination does not receive carry M = NaN (column 0), which K0 drops
+    as invalid halos.  Returns (columns [k][world * blockcap], overflow): `overflow` is an int32 tensor that is non-zero on a rank one
+    of whose blocks was too small (check it once, after the steps; route_halos() has no such limit).  `work`: dict reused between
+    calls (send / receive buffers).  With `plan` (a ShellPlan on the tensors' GPU) the packing is one libbfgx kernel."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    n, k = int(rings.shape[0]), len(cols)
+    dev = rings.device
+    work = work if work is not None else {}
+    key = (world, k, int(blockcap), str(dev))
+    if work.get('key') != key:
+        work.clear()
+        work.update(key=key, send=torch.empty((world, k, blockcap), dtype=torch.float64, device=dev),
+                    recv=torch.empty((world, k, blockcap), dtype=torch.float64, device=dev),
+                    out=torch.empty((k, world * blockcap), dtype=torch.float64, device=dev),
+                    cursor=torch.empty(world, dtype=torch.int32, device=dev), overflow=torch.zeros(1, dtype=torch.int32, device=dev))
+    send, recv, out = work['send'], work['recv'], work['out']
+    if plan is not None and rings.is_cuda:
+        plan.route_pack(n, rings.data_ptr(), ring_bounds, blockcap, [c.data_ptr() for c in cols], work['cursor'].data_ptr(), send.data_ptr(),
+                        work['overflow'].data_ptr())
+    else:
+        send[:, 0, :] = float('nan')
+        rbt = torch.as_tensor(np.asarray(ring_bounds, dtype=np.int64), device=dev)
+        first, last = rings[:, 0].long(), rings[:, 1].long()
+        j_lo = (torch.bucketize(first, rbt, right=True) - 1).clamp_(0, world - 1)
+        j_hi = (torch.bucketize(last, rbt, right=True) - 1).clamp_(0, world - 1)
+        stacked = torch.stack(cols, dim=0)
+        for d in range(world):
+            sel = torch.nonzero((first <= last) & (j_lo <= d) & (j_hi >= d), as_tuple=False).reshape(-1)
+            if sel.numel() > blockcap:
+                work['overflow'].fill_(1)
+                sel = sel[:blockcap]
+            send[d, :, :sel.numel()] = stacked[:, sel]
+    _a2a(recv.view(-1), send.view(-1), None, None)
+    out.view(k, world, blockcap).copy_(recv.permute(1, 0, 2))         # [source][column][row] -> contiguous columns
+    return out, work['overflow']
 
 
 def band_ring_bounds(cuts, rings_per_band, nside):
@@ -238,11 +279,12 @@ def _a2a(recv, send, outs, ins):
     return recv
 
 
-def halo_exchange(mine, pb, needs, width):
+def halo_exchange(mine, pb, needs, width, full=None):
     """After the reduce-scatter rank j holds the summed values of pixels [pb[j], pb[j+1]) (`mine`, `width` numbers per
     pixel); it needs the pixels needs[j] = (lo_j, hi_j), a superset that reaches into its neighbours' slices.  One
     all_to_all whose splits are empty except towards the ranks that need a piece of this rank's slice.  Returns the
-    tensor of pixels [lo_rank, hi_rank)."""
+    tensor of pixels [lo_rank, hi_rank).  `full`: that tensor, preallocated, with `mine` already a view of its middle part
+    (the slice was computed in place): only the apron pieces are written."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -264,8 +306,11 @@ def halo_exchange(mine, pb, needs, width):
     send = torch.cat([mine[(a - p0) * width:(b - p0) * width] for a, b in send_ranges]) if sum(ins) else mine.new_empty(0)
     recv = _a2a(mine.new_empty(sum(outs)), send, outs, ins)
     lo, hi = int(needs[rank][0]), int(needs[rank][1])
-    full = mine.new_empty((hi - lo) * width)
-    full[(p0 - lo) * width:(int(pb[rank + 1]) - lo) * width] = mine
+    if full is None:
+        full = mine.new_empty((hi - lo) * width)
+        full[(p0 - lo) * width:(int(pb[rank + 1]) - lo) * width] = mine
+    else:
+        assert full.numel() == (hi - lo) * width and mine.data_ptr() == full.data_ptr() + (p0 - lo) * width * full.element_size()
     o = 0
     for (a, b), n in zip(recv_ranges, outs):
         if n:

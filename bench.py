@@ -421,6 +421,12 @@ def main():
     import torch.distributed as dist
     rank, world, local_rank, dev, backend = ctx = dist_context(args)
     if world > 1 or os.environ.get('BFGX_FORCE_EXCHANGE') == '1':
+        if 'RANK' not in os.environ:          # BFGX_FORCE_EXCHANGE=1 from a plain `python bench.py`: a one-rank group
+            import socket
+            with socket.socket() as sck:
+                sck.bind(('127.0.0.1', 0))
+                port = sck.getsockname()[1]
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
     scaling = 'strong' if args.config == 4 else args.scaling
     out = shell_line(args, ctx, scaling, brief=False)
@@ -502,7 +508,7 @@ def shell_line(args, ctx, scaling, brief):
     spatial = (world > 1 or force_x) and args.exchange == 'spatial' and args.algo == 1
     if slices or spatial:
         from baryonification_amd.utils.Parallelize import (_hip_reach, band_partition, band_ring_bounds, gather_slices, halo_exchange,
-                                                           route_halos, sliced_reduce)
+                                                           route_halos, route_halos_fixed, sliced_reduce)
         first = plan.bands()
         cuts = band_partition(first, world)
         pb = first[cuts]
@@ -513,10 +519,17 @@ def shell_line(args, ctx, scaling, brief):
         # spatial sharding: the halos this rank holds (its chunk of the catalog) are routed to the ranks whose ring bands their discs
         # can touch; every rank then computes ITS pixels only -- no accumulator crosses a link
         rb = band_ring_bounds(cuts, plan.tile_shape()[0], nside)
-        cap = 2 * int(np.ceil(total_halos / world)) + 4096
+        # fixed-capacity routing: every (source, destination) pair owns a block of `blockcap` rows, the equal splits of ONE all_to_all, so
+        # that no count is read back by the host inside a step (the catalog is shuffled, Parallelize.py:255: a destination receives about
+        # nh / world halos from every source; 1.5 x that + 2048 is > 40 sigma).  An overflow is detected on the device, checked after the
+        # untimed trial step and answered with the variable-split routing (route_halos: one read-back per step)
+        blockcap = int(1.5 * np.ceil(nh / world)) + 2048
+        cap = max(world * blockcap, 2 * int(np.ceil(total_halos / world)) + 4096)
         plan_sp = engine.ShellPlan(model, keep, nside, cap, device=local_rank, stream=stream)
         d_rings = torch.empty((nh, 2), dtype=torch.int32, device=dev)
         cols_local = [t[k] for k in ('M', 'z', 'ra', 'dec', 'lnz', 'lnM')]
+        route_work = {}
+        sp_state = {'fixed': True, 'reach_known': False, 'nd': None, 'cd': None}
 
     def run_steps(acc_f64):
         """returns a closure doing one full pass of the hot path with the given accumulator type"""
@@ -542,22 +555,43 @@ def shell_line(args, ctx, scaling, brief):
 
         def step_spatial():
             plan_sp.disc_rings(cat_dev, d_rings.data_ptr())
-            got = route_halos(cols_local, d_rings, rb, plan=plan_sp)           # [6][n]: the halos whose discs can touch my ring bands
-            n = int(got.shape[1])
-            assert n <= cap, "rank %d received %d halos, more than the plan holds (%d): a strongly clustered sky" % (rank, n, cap)
-            cd = _lib.make_catalog_dev(n, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
-                                       ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
+            if sp_state['fixed']:
+                got, _ = route_halos_fixed(cols_local, d_rings, rb, blockcap, plan=plan_sp, work=route_work)   # [6][world * blockcap], NaN-padded
+                if sp_state['cd'] is None:                     # (the receive buffers are reused: the descriptor is built once)
+                    sp_state['cd'] = _lib.make_catalog_dev(int(got.shape[1]), got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
+                                                           ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
+                cd = sp_state['cd']
+            else:
+                got = route_halos(cols_local, d_rings, rb, plan=plan_sp)       # [6][n]: the halos whose discs can touch my ring bands
+                n = int(got.shape[1])
+                assert n <= cap, "rank %d received %d halos, more than the plan holds (%d): a strongly clustered sky" % (rank, n, cap)
+                cd = _lib.make_catalog_dev(n, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
+                                           ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
             b0, b1 = int(cuts[rank]), int(cuts[rank + 1])
             if paint:
                 plan_sp.paint_bands(cd, b0, b1, d_slice.data_ptr(), acc_f64=(1 if acc_f64 else 2))
                 gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
                 return
-            my_off = d_off[:(p1 - p0) * 3]
+            # once the reach is known the slice is computed in place inside the buffer that also holds the apron rings
+            if sp_state['reach_known']:
+                lo_, hi_ = sp_state['nd'][rank]
+                if sp_state.get('full') is None or sp_state['full'].dtype != acc_dtype:
+                    sp_state['full'] = torch.empty((hi_ - lo_) * 3, dtype=acc_dtype, device=dev)
+                my_off = sp_state['full'][(p0 - lo_) * 3:(p1 - lo_) * 3]
+            else:
+                my_off = d_off[:(p1 - p0) * 3]
             plan_sp.offsets_bands(cd, b0, b1, my_off.data_ptr(), acc_f64=acc_f64)
-            if dist.is_initialized():
-                _hip_reach(None, plan_sp, my_off, bands=(b0, b1))          # collective: rings of apron from the largest |offset| (K1's per-tile maxima)
-            nd = [plan_sp.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
-            off_apron = halo_exchange(my_off, pb, nd, 3)
+            if not sp_state['reach_known']:
+                # the reach of the gathering regrid (rings of apron every rank exchanges and gathers from) is agreed ONCE, in the untimed
+                # trial step: all_reduce(MAX) of the largest |offset| (K1's per-tile maxima) + one read-back.  The timed steps reuse it:
+                # a source pixel that moves further than the reach covers is never lost -- it takes the far-deposit route, and a far
+                # deposit that lands in another rank's slice is counted on the device (d_foreign, checked after the steps)
+                if dist.is_initialized():
+                    _hip_reach(None, plan_sp, my_off, bands=(b0, b1))
+                sp_state['nd'] = [plan_sp.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
+                sp_state['reach_known'] = True
+            nd = sp_state['nd']
+            off_apron = halo_exchange(my_off, pb, nd, 3, full=sp_state.get('full') if my_off.data_ptr() != d_off.data_ptr() else None)
             plan_sp.regrid_bands(b0, b1, d_map.data_ptr(), off_apron.data_ptr(), nd[rank][0], nd[rank][1], d_slice.data_ptr(), d_sums.data_ptr(),
                                  acc_f64=acc_f64)
             if route_far[0]:
@@ -653,8 +687,22 @@ def shell_line(args, ctx, scaling, brief):
             fence()
             (plan_sp if spatial else plan).status()
         except Exception as e:        # noqa: BLE001
+            import traceback
+            traceback.print_exc()
             print("bench[rank %d]: the multi-rank step failed (%s: %s); try --exchange reduce" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            sys.stderr.flush()
             os._exit(3)
+        if spatial:
+            # did a routing block overflow on any rank (a catalog that is not shuffled, a sky patch)?  then route with variable splits
+            ovf = route_work['overflow'].clone() if backend == 'nccl' else route_work['overflow'].cpu()
+            if dist.is_initialized():
+                dist.all_reduce(ovf, op=dist.ReduceOp.MAX)
+            if int(ovf.item()):
+                sp_state['fixed'] = False
+                if rank == 0:
+                    print("bench: a fixed-capacity routing block overflowed: routing with variable splits (one read-back per step)", file=sys.stderr, flush=True)
+                step()
+                fence()
         if not paint:
             # did a far deposit land in another rank's slice?  then every step routes the lists (collective decision)
             nf = d_foreign.clone() if backend == 'nccl' else d_foreign.cpu()

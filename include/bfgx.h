@@ -231,6 +231,12 @@ int  bfgx_disc_rings_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t *
 int  bfgx_route_count_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, int32_t *counts_dev);
 int  bfgx_route_fill_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, const int64_t *start,
                             int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *rows_dev);
+/* The same in ONE pass and with nothing read back by the host (a resident step: Parallelize.py:255-273 shuffles the catalog, so the counts
+ * per destination are close to n / world): fixed-capacity blocks blocks_dev[world][ncols][blockcap], column-major inside a block, the
+ * equal splits of ONE all_to_all.  Rows a destination does not receive keep M = NaN (column 0), which K0 drops as invalid halos;
+ * *overflow_dev (int32, zeroed by the caller) is set when a destination would receive more than blockcap halos. */
+int  bfgx_route_pack_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, int32_t world, const int32_t *ring_bounds, int64_t blockcap,
+                            int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *blocks_dev, int32_t *overflow_dev);
 int  bfgx_offsets_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t band0, int32_t band1, void *offsets_slice_dev, int acc_f64);
 int  bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t band0, int32_t band1, void *map_slice_dev, int acc_f64);
 /* K0 + K3: map_out[npix] += painted profile; accumulator f32 or f64 */

@@ -247,6 +247,17 @@ def _worker_route(rank, world, port, out_path):
         bounds = np.linspace(1, 400, world + 1).astype(np.int64)
         got = route_halos(cols, torch.from_numpy(np.stack([first, last], axis=1).astype(np.int32)), bounds)
         np.save(out_path + '.%d.npy' % rank, got.numpy())
+        # the fixed-capacity form (equal splits, nothing read back): the same halos, NaN-padded; a block that is too small raises the flag
+        from baryonification_amd.utils.Parallelize import route_halos_fixed
+        rings_t = torch.from_numpy(np.stack([first, last], axis=1).astype(np.int32))
+        fix, ovf = route_halos_fixed(cols, rings_t, bounds, 4000)
+        assert fix.shape == (4, world * 4000) and int(ovf.item()) == 0
+        keepm = ~torch.isnan(fix[0])
+        assert np.array_equal(np.sort(fix[0][keepm].numpy()), np.sort(got[0].numpy()))
+        order_a, order_b = np.argsort(fix[0][keepm].numpy()), np.argsort(got[0].numpy())
+        assert np.array_equal(fix[:, keepm].numpy()[:, order_a], got.numpy()[:, order_b])
+        _, ovf2 = route_halos_fixed(cols, rings_t, bounds, 50)
+        assert int(ovf2.item()) == 1
     finally:
         dist.destroy_process_group()
 

@@ -528,6 +528,21 @@ def test_route_kernels_pack_every_halo_for_every_rank_it_touches(gpu):
         ids = blk[:, 0].astype(np.int64)
         assert np.array_equal(np.sort(ids), want[j])                       # the right halos, each once
         assert np.array_equal(blk, host[ids])                               # whole rows travel together
+    # bfgx_route_pack_device: the same in one pass into fixed-capacity blocks [world][6][cap] (nothing read back inside a step); the rows a
+    # destination does not receive keep M = NaN; a block that is too small raises the overflow flag and drops the excess
+    for capb, over in ((int(c.max()) + 7, 0), (int(c.max()) - 1, 1)):
+        blocks = torch.full((world, 6, capb), -7.0, dtype=torch.float64, device=dev)
+        ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+        plan.route_pack(n, rings.data_ptr(), bounds, capb, [x.data_ptr() for x in cols], cursor.data_ptr(), blocks.data_ptr(), ovf.data_ptr())
+        b = blocks.cpu().numpy()
+        assert int(ovf.item()) == over
+        for j in range(world):
+            valid = ~np.isnan(b[j, 0])
+            m = int(valid.sum())
+            assert m == min(int(c[j]), capb) and valid[:m].all()            # the received rows are packed at the front of the block
+            ids = b[j, 0, :m].astype(np.int64)
+            assert np.unique(ids).size == m and np.isin(ids, want[j]).all() and (over or np.array_equal(np.sort(ids), want[j]))
+            assert np.array_equal(b[j, :, :m].T, host[ids])
     plan.close()
 
 
@@ -562,4 +577,26 @@ def test_sparse_catalog_still_tiles_are_copied(gpu, nh):
         g = got.cpu().numpy()
         assert np.isfinite(g).all() and np.abs(g - ora).max() <= 1e-10 * np.abs(ora).max()
         assert np.isclose(sums[0].item(), hmap.sum(), rtol=1e-12) and np.isclose(sums[1].item(), hmap[hmap > 0].sum(), rtol=1e-12)
+    plan.close()
+
+
+def test_rank_without_bands_is_a_no_op(gpu):
+    """more ranks than ring bands (small NSIDE): band_partition gives a rank the empty range [b, b); its buffers are empty tensors whose
+    data pointers are NULL -- the band-restricted passes and the banded regrid return without touching anything"""
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(500, 16, paint=False)
+    from baryonification_amd.utils.Parallelize import band_partition
+    first = plan.bands()
+    cuts = band_partition(first, 16)                         # NSIDE 16: 2 bands of 32 rings for 16 ranks
+    assert len(set(cuts.tolist())) < 17
+    cd, keepc = _cat_dev(torch, _lib, dev, cat)
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    assert empty.data_ptr() == 0
+    sums = torch.full((2,), 7.0, dtype=torch.float64, device=dev)
+    for b in sorted(set(int(c) for c in cuts)):
+        plan.offsets_bands(cd, b, b, empty.data_ptr(), acc_f64=False)
+        lo, hi = plan.band_apron(b, b)
+        plan.regrid_bands(b, b, 0, 0, lo, hi, 0, sums.data_ptr(), acc_f64=False)
+        torch.cuda.synchronize()
+        assert sums.tolist() == [0.0, 0.0]
+        sums.fill_(7.0)
     plan.close()
