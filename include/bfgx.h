@@ -143,10 +143,11 @@ int bfgx_paint_shell(const bfgx_catalog *cat_host, const bfgx_model *model, int6
 /* ---- all GPUs of one node from ONE call (SURVEY 8b "multi-GPU variant taking a device list") -----------------------
  * The counterpart of SplitJoinParallel (utils/Parallelize.py:191-320) for a binder that has nothing but this C ABI: the
  * catalog (already shuffled by the caller if wanted, Parallelize.py:255) is cut into ndev contiguous shards
- * (ceil(n / ndev) halos, :250-266), device devices[d] runs shard d, the partial accumulators are exchanged by pixel slices
- * with peer-to-peer copies over xGMI (each device pulls the range it owns from every other one), every device regrids the
- * OUTPUT pixels of its ring bands and copies its slice straight into map_out_host.  Same arguments, results and errors as
- * the single-device calls; opts->device is ignored, opts->algo must be 1.  `devices` may repeat a device. */
+ * (ceil(n / ndev) halos, :250-266) that go up to device devices[d]; the ring bands of the sphere are dealt out to the devices and
+ * every halo's row (48 B) is pulled, peer to peer over xGMI, by the device(s) whose bands its disc touches; each device computes
+ * the pixels it owns (no accumulator crosses a link), pulls the apron rings of pix_offsets the gathering regrid needs from its
+ * neighbours, regrids the OUTPUT pixels of its bands and copies its slice straight into map_out_host.  Same arguments, results and
+ * errors as the single-device calls; opts->device is ignored, opts->algo must be 1.  `devices` may repeat a device. */
 int bfgx_baryonify_shell_multi(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside, const double *map_in_host,
                                double *map_out_host, int32_t ndev, const int32_t *devices, const bfgx_opts *opts, bfgx_stats *stats);
 int bfgx_paint_shell_multi(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside, double *map_out_host,
