@@ -122,9 +122,10 @@ class PaintProfilesShell(DefaultRunner):
         cat, cols = self._catalog(p_keys)
         nside = int(self.LightconeShell.NSIDE)
         new_map = _lib.pinned_empty(self.LightconeShell.map.size)
-        # acc_f64: None / True = fp64 throughout (1e-10 parity); 2 or 'mixed' = fp32 pair math accumulated in fp64 (2.3x faster,
-        # 5e-5 of the pixel value); False = fp32 map
-        acc64 = 1 if self.acc_f64 is None else (2 if self.acc_f64 in (2, 'mixed') else int(bool(self.acc_f64)))
+        # acc_f64: None (default) / 2 / 'mixed' = fp32 pair math (chord, ln r, read-out, exp) accumulated in fp64 into the fp64 map -- the
+        # same split BaryonifyShell's default has, what bench.py --mode paint times; stated fp64 -> fp32 tolerance: 5e-5 of the pixel's
+        # value.  True = fp64 throughout (1e-10 parity with the reference, 2.3x slower); False = fp32 map
+        acc64 = 2 if (self.acc_f64 is None or self.acc_f64 in (2, 'mixed')) else int(bool(self.acc_f64))
         opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0, int(self.algo), 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data,

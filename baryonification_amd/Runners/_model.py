@@ -18,6 +18,84 @@ def _axes(model, p_keys):
     return [np.asarray(a, dtype=np.float64) for a in axes]
 
 
+# sampling of the table a callable (non-tabulated) model is given on first use: the README's radial grid (README.md:78-80) on the
+# (z, M) support of the runner's catalog
+BRIDGE_N_Z, BRIDGE_N_M, BRIDGE_N_R, BRIDGE_R_MIN, BRIDGE_R_MAX = 10, 20, 500, 1e-3, 3e2
+
+
+def _support(runner):
+    """(z_min, z_max, M_min, M_max) of the runner's catalog, opened by 1e-6 relative so that no halo sits on a table edge"""
+    cat = runner.HaloLightConeCatalog.cat if hasattr(runner, 'HaloLightConeCatalog') else runner.HaloNDCatalog.cat
+    M = np.asarray(cat['M'], dtype=np.float64)
+    if 'z' in cat.dtype.names:
+        z = np.asarray(cat['z'], dtype=np.float64)
+        z0, z1 = float(z.min()), float(z.max())
+    else:
+        z0 = z1 = float(runner.HaloNDCatalog.redshift)
+    z0, z1 = max(z0 * (1 - 1e-6) - 1e-9, 0.0), z1 * (1 + 1e-6) + 1e-9
+    return z0, z1, float(M.min()) * (1 - 1e-6), float(M.max()) * (1 + 1e-6)
+
+
+def tabulate_callable(runner, kind):
+    """The reference's runners call `model.displacement(r, M, a)` / `model.projected(cosmo, r, M, a)` once per halo on ANY object
+    (HealpixRunner.py:321, :441).  A model that carries no table (no raw_input_*) and cannot build one itself (no
+    setup_interpolator) is tabulated here, once, on the (z, M) support of the runner's catalog -- BRIDGE_N_Z x BRIDGE_N_M x
+    BRIDGE_N_R samples, z linear, M and r logarithmic -- and the table holder is cached on the model (`_bfgx_tabulated`), keyed by
+    the support.  Returns the holder (a Baryonification2D / TabulatedProfile of this package)."""
+    model = runner.model
+    z0, z1, M0, M1 = _support(runner)
+    key = (kind, z0, z1, M0, M1)
+    cached = getattr(model, '_bfgx_tabulated', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    from ..Profiles.BaryonCorrection import Baryonification2D
+    from ..utils.Tabulate import TabulatedProfile
+    from ..utils.cosmology import Cosmology, cosmo_to_dict
+    cosmo = getattr(model, 'cosmo', None) or runner.cosmo
+    cosmo_obj = cosmo if isinstance(cosmo, Cosmology) else Cosmology.from_dict(cosmo_to_dict(cosmo))
+    z = np.linspace(z0, z1, BRIDGE_N_Z) if z1 > z0 else np.array([z0, z0 + 1e-6])
+    Mg = np.geomspace(M0, M1, BRIDGE_N_M)
+    r = np.geomspace(BRIDGE_R_MIN, BRIDGE_R_MAX, BRIDGE_N_R)
+    if kind == 'displacement':
+        d = np.zeros((z.size, Mg.size, r.size))
+        for i, zi in enumerate(z):
+            for j, Mj in enumerate(Mg):
+                d[i, j] = np.asarray(model.displacement(r, Mj, 1.0 / (1.0 + zi)), dtype=np.float64).reshape(r.size)
+        # the model applies its own cut inside displacement() (BaryonCorrection.py:381-382); the holder must not cut again
+        holder = Baryonification2D(None, None, cosmo_obj, epsilon_max=float(getattr(model, 'epsilon_max', np.inf)),
+                                   mass_def=getattr(model, 'mass_def', None))
+        holder.set_table(z, Mg, r, d)
+    else:
+        # the runner paints model.projected(cosmo, r_sep / a, M, a) as it comes (HealpixRunner.py:441): no factor of `a` here (the
+        # reference's TabulatedProfile multiplies its OWN table by a, Tabulate.py:226 -- a raw profile is painted without it)
+        t2 = np.zeros((z.size, Mg.size, r.size))
+        for i, zi in enumerate(z):
+            a = 1.0 / (1.0 + zi)
+            try:
+                row = np.asarray(model.projected(cosmo_obj, r, Mg, a), dtype=np.float64)
+                assert row.shape == (Mg.size, r.size)
+            except Exception:        # noqa: BLE001  a profile that takes scalar masses only
+                row = np.stack([np.asarray(model.projected(cosmo_obj, r, Mj, a), dtype=np.float64).reshape(r.size) for Mj in Mg])
+            t2[i] = row
+        holder = TabulatedProfile(None, cosmo_obj, mass_def=getattr(model, 'mass_def', None))
+        holder.set_table(z, Mg, r, t2)
+    try:
+        model._bfgx_tabulated = (key, holder)
+    except AttributeError:
+        pass
+    return holder
+
+
+class _Proxy(object):
+    """a runner whose model is the tabulated holder (everything else falls through)"""
+
+    def __init__(self, runner, model):
+        self.__dict__['_r'], self.__dict__['model'] = runner, model
+
+    def __getattr__(self, name):
+        return getattr(self._r, name)
+
+
 def build_model(runner, kind, runner_cosmo=None):
     """kind = 'displacement' (BaryonifyShell / BaryonifyGrid), 'projected' (PaintProfilesShell, PaintProfilesGrid on
     2D maps) or 'real' (PaintProfilesGrid on 3D maps).  `runner_cosmo` overrides the runner-side cosmology dict (the
@@ -26,9 +104,12 @@ def build_model(runner, kind, runner_cosmo=None):
     p_keys = list(vars(model).get('p_keys', []))                      # HealpixRunner.py:282
     if kind == 'displacement':
         if not hasattr(model, 'raw_input_d'):
-            if hasattr(model, 'displacement'):
+            if hasattr(model, 'setup_interpolator'):          # a Baryonification2D/3D that was never set up: as the reference's displacement()
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            raise TypeError("BaryonifyShell needs a tabulated displacement model (Baryonification2D/3D)")
+            if callable(getattr(model, 'displacement', None)):
+                return build_model(_Proxy(runner, tabulate_callable(runner, kind)), kind, runner_cosmo)
+            raise TypeError("BaryonifyShell needs a model with a displacement(r, M, a) method or a displacement table "
+                            "(Baryonification2D/3D)")
         values = np.asarray(model.raw_input_d, dtype=np.float64)
         rdelta = bool(getattr(model, 'Rdelta_sampling', False))
         logv = False
@@ -36,8 +117,12 @@ def build_model(runner, kind, runner_cosmo=None):
     else:
         attr = 'raw_input_2D' if kind == 'projected' else 'raw_input_3D'
         if not hasattr(model, attr):
-            raise TypeError("painting on the GPU needs a tabulated profile (TabulatedProfile / "
-                            "ParamTabulatedProfile); wrap the profile and call setup_interpolator()/set_table()")
+            if hasattr(model, 'setup_interpolator'):
+                raise NameError("No Table created. Run setup_interpolator() method first")
+            if kind == 'projected' and callable(getattr(model, 'projected', None)):
+                return build_model(_Proxy(runner, tabulate_callable(runner, kind)), kind, runner_cosmo)
+            raise TypeError("painting needs a profile with a projected(cosmo, r, M, a) method or a tabulated profile "
+                            "(TabulatedProfile / ParamTabulatedProfile)")
         with np.errstate(divide='ignore', invalid='ignore'):
             values = np.log(np.asarray(getattr(model, attr), dtype=np.float64))   # Tabulate.py:237-238, :560-561
         rdelta, logv, eps_model = False, True, 0.0

@@ -65,6 +65,13 @@ def shuffled_order(n, seed=42):
     return np.random.default_rng(seed).choice(n, size=n, replace=False)
 
 
+def _paint_mode(runner):
+    """PaintProfilesShell.acc_f64 as the single-GPU runner reads it: None / 2 / 'mixed' = fp32 pair math into the fp64 map, True = fp64
+    throughout (the map exchanged between ranks is fp64 either way)"""
+    a = getattr(runner, 'acc_f64', None)
+    return 2 if (a is None or a in (2, 'mixed')) else (1 if a else 2)
+
+
 def _hip_compute(runner, kind, cat_cols, device):
     """Per-rank partial accumulator on `device` (torch tensor): pix_offsets (f32 [npix*3]) or painted map."""
     import torch
@@ -86,7 +93,7 @@ def _hip_compute(runner, kind, cat_cols, device):
         plan.offsets(cd, acc.data_ptr(), acc_f64=False)
     else:
         acc = torch.zeros(npix, dtype=torch.float64, device=dev)
-        plan.paint(cd, acc.data_ptr(), acc_f64=True)
+        plan.paint(cd, acc.data_ptr(), acc_f64=_paint_mode(runner))
     plan.status()            # blocking: the halo -> tile entry list did not overflow (a resident plan does not regrow it)
     return acc, plan
 
@@ -218,7 +225,7 @@ def _hip_compute_spatial(runner, kind, cat_cols, device, world, rank):
         plan.offsets_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=False)
     else:
         sl = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
-        plan.paint_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=True)
+        plan.paint_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=_paint_mode(runner))
     plan.status()            # blocking: the halo -> tile entry list did not overflow
     plan._spatial_keep = t   # the catalog columns live as long as the plan
     return sl, plan

@@ -58,14 +58,19 @@ def test_hip_vs_oracle(gpu, name, algo):
 
 
 def test_default_accumulators(gpu):
-    """defaults: BaryonifyShell f32 offsets, PaintProfilesShell f64 map"""
+    """defaults: BaryonifyShell f32 pair math + f32 pix_offsets; PaintProfilesShell f32 pair math accumulated in f64 into the f64 map
+    (stated tolerance 5e-5 of the pixel's value); acc_f64 = True is fp64 throughout"""
     g = load_golden('lowz_baryonify')
     r = product_runner(g)
     out = r.process()
     assert np.abs(out - g['expected']).max() <= 1e-6 * g['expected'].mean()
     g = load_golden('lowz_paint')
+    exp = g['expected']
     out = product_runner(g).process()
-    assert np.abs(out - g['expected']).max() <= 1e-10 * np.abs(g['expected']).max()
+    assert out.dtype == np.float64 and np.all(np.abs(out - exp) <= 5e-5 * np.abs(exp) + 1e-12 * np.abs(exp).max())
+    assert np.abs(out - exp).max() > 1e-10 * np.abs(exp).max()                       # (it IS the mixed mode)
+    out = product_runner(g, acc_f64=True).process()
+    assert np.abs(out - exp).max() <= 1e-10 * np.abs(exp).max()
 
 
 def test_empty_catalog(gpu):
@@ -209,10 +214,14 @@ def test_randomized_regimes_vs_oracle(gpu, seed, nside, zr, logM, eps):
     prof = bfg.utils.TabulatedProfile(None, cosmo)
     prof.set_table(z, M, r, P)
     pshell = bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=syn.COSMO)
-    out = bfg.Runners.PaintProfilesShell(Catalog, pshell, eps, prof, verbose=False).process()
+    pr = bfg.Runners.PaintProfilesShell(Catalog, pshell, eps, prof, verbose=False)
     with np.errstate(divide='ignore'):
         orap = O.paint_shell(nside, used, O.Table(axes, np.log(P)), eps, bg)
-    assert np.abs(out - orap).max() <= 1e-10 * np.abs(orap).max()
+    pr.acc_f64 = True                                                 # fp64 throughout
+    assert np.abs(pr.process() - orap).max() <= 1e-10 * np.abs(orap).max()
+    pr.acc_f64 = None                                                 # default: fp32 pair math into the fp64 map
+    out = pr.process()
+    assert np.all(np.abs(out - orap) <= 5e-5 * np.abs(orap) + 1e-12 * np.abs(orap).max())
 
 
 @pytest.mark.parametrize('name', ['lowz_baryonify', 'c1_baryonify', 'rdelta_baryonify', 'lowz_paint', 'param1_paint'])
@@ -256,3 +265,71 @@ def test_multi_device_c_entry_large_displacements(gpu, scale):
         assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
         assert np.isclose(sj.last_stats['sum_out'], sj.last_stats['sum_in']) and np.isclose(out.sum(), g['map_in'].sum())
     assert np.abs(one - g['map_in']).max() > 0 and pix > 0
+
+
+def test_callable_models_are_tabulated_on_first_use(gpu):
+    """HealpixRunner.py:321, :441 call model.displacement(r, M, a) / model.projected(cosmo, r, M, a) on ANY object.  A plain-Python model
+    (no raw_input_*, no setup_interpolator) goes through process(): it is tabulated once on the catalog's (z, M) support and the result
+    equals the oracle fed the same tabulation; objects with neither method are still refused"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    from baryonification_amd.Runners import _model as RM
+    from oracle import oracle as O
+    nside, N, eps = 128, 800, 8.0
+    cat = syn.make_catalog(N, seed=77)
+    cosmo = bfg.utils.Cosmology.from_dict(syn.COSMO)
+    bg = O.Background.from_dict(syn.COSMO)
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}
+
+    class PlainDisplacement(object):
+        """closed form, vectorised in r; the model-side cut at epsilon_max R (BaryonCorrection.py:381-382) is its own business"""
+        epsilon_max = 6.0
+        calls = 0
+
+        def displacement(self, r, M, a):
+            type(self).calls += 1
+            Rc = bg.get_radius(np.atleast_1d(M), a)[0] / a
+            x = np.asarray(r) / Rc
+            return np.where(x < self.epsilon_max, -0.05 * Rc * x * np.exp(-x) / (1 + x * x), 0.0)
+
+    class PlainProfile(object):
+        def projected(self, cosmo, r, M, a):
+            Rc = bg.get_radius(np.atleast_1d(M), a) / a
+            x = np.asarray(r)[None, :] / Rc[:, None]
+            out = (np.atleast_1d(M)[:, None] / 1e14) * np.exp(-x) / (1 + x) ** 2
+            return out if np.ndim(M) else out[0]
+
+    hmap = syn.make_map(nside, seed=5)
+    Shell = bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO)
+    model = PlainDisplacement()
+    runner = bfg.Runners.BaryonifyShell(Catalog, Shell, eps, model, verbose=False)
+    runner.acc_f64 = True
+    out = runner.process()
+    n_calls = PlainDisplacement.calls
+    assert n_calls == RM.BRIDGE_N_Z * RM.BRIDGE_N_M and hasattr(model, '_bfgx_tabulated')
+    holder = model._bfgx_tabulated[1]
+    axes = [holder.raw_input_z_range, holder.raw_input_M_range, holder.raw_input_r_range]
+    ora = O.baryonify_shell(nside, hmap, used, O.Table(axes, holder.raw_input_d, False, model.epsilon_max), eps, bg)
+    assert np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max() and np.abs(out - hmap).max() > 0 and np.isclose(out.sum(), hmap.sum())
+    runner.process()
+    assert PlainDisplacement.calls == n_calls                                   # the table is built once
+    prof = PlainProfile()
+    pshell = bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=syn.COSMO)
+    pr = bfg.Runners.PaintProfilesShell(Catalog, pshell, eps, prof, verbose=False)
+    pr.acc_f64 = True
+    painted = pr.process()
+    hp_ = prof._bfgx_tabulated[1]
+    with np.errstate(divide='ignore'):
+        orap = O.paint_shell(nside, used, O.Table([hp_.raw_input_z_range, hp_.raw_input_M_range, hp_.raw_input_r_range], np.log(hp_.raw_input_2D)), eps, bg)
+    assert painted.max() > 0 and np.abs(painted - orap).max() <= 1e-10 * np.abs(orap).max()
+    # the tabulation itself is faithful: the table read-out against the callable at the halos' own (z, M) and a few radii
+    j = np.argmax(cat['M'])
+    a_j = 1 / (1 + cat['z'][j])
+    rr = np.geomspace(0.02, 5.0, 7)
+    direct = prof.projected(cosmo, rr, cat['M'][j], a_j)
+    assert np.abs(hp_.projected(cosmo, rr, cat['M'][j], a_j) / direct - 1).max() < 2e-3
+    with pytest.raises(TypeError):
+        bfg.Runners.BaryonifyShell(Catalog, Shell, eps, object(), verbose=False).process()
+    with pytest.raises(NameError):                                              # a table class that was never set up: as the reference
+        bfg.Runners.BaryonifyShell(Catalog, Shell, eps, bfg.Profiles.Baryonification2D(None, None, cosmo), verbose=False).process()
