@@ -79,8 +79,8 @@ grid_block_lists_kernel(GridGeom g, int64_t nh, const GridHaloRec *__restrict__ 
 template <int DIM, int NC>
 __global__ void __launch_bounds__(256, 6)
 grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restrict__ recs, const int32_t *__restrict__ blk_start,
-                          const int32_t *__restrict__ blk_list, const double *__restrict__ map_in, double *__restrict__ map_out,
-                          double *__restrict__ block_sums)
+                          const int32_t *__restrict__ blk_list, const int32_t *__restrict__ blk_nz, const double *__restrict__ map_in,
+                          double *__restrict__ map_out, double *__restrict__ block_sums)
 {
     // Two phases per batch of kGatherBatch halos.  (1) every thread tests its cells against the halos' bounding boxes and a
     // conservative r^2 bound (integer + a few fp64 operations per (halo, cell)) and queues the survivors in LDS -- a ball fills a
@@ -95,7 +95,7 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
     __shared__ uint16_t queue[kGatherBatch * Blk::cells];                // (halo of the batch << 12) | cell: cannot overflow
     __shared__ int qn;
     const int N = g.npix, nbk = gather_blocks_per_axis(N, S), tid = threadIdx.x, lane = tid & (kWave - 1);
-    const unsigned blk = blockIdx.x;
+    const unsigned blk = (unsigned)blk_nz[blockIdx.x];    // launched over the blocks that list a halo only
     int c0, c1, c2 = 0;                                  // first cell of the block along the array axes (32-bit divisions)
     if (DIM == 3) { c2 = (int)(blk % (unsigned)nbk) << S; const unsigned q = blk / (unsigned)nbk; c1 = (int)(q % (unsigned)nbk) << S; c0 = (int)(q / (unsigned)nbk) << S; }
     else { c1 = (int)(blk % (unsigned)nbk) << S; c0 = (int)(blk / (unsigned)nbk) << S; }
@@ -237,6 +237,25 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
         for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; tn += sn[w]; }
         // (no atomic on one pair counter here: 2.6e5 workgroups adding to the same address serialise -- 1.2 ms on a 512^3 grid)
         block_sums[3 * (size_t)blk] = ta; block_sums[3 * (size_t)blk + 1] = tb; block_sums[3 * (size_t)blk + 2] = (double)tn;
+    }
+}
+
+// nz[0 .. *nnz) = the blocks whose halo list is not empty (any order): one atomic per workgroup on the counter
+__global__ void __launch_bounds__(256)
+grid_nonempty_blocks_kernel(int64_t nblk, const int32_t *__restrict__ start, int32_t *__restrict__ nz, int32_t *__restrict__ nnz)
+{
+    __shared__ int s_n, s_base;
+    __shared__ int32_t s_list[256];
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < nblk; b0 += (int64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const int64_t b = b0 + threadIdx.x;
+        if (b < nblk && start[b + 1] > start[b]) s_list[atomicAdd(&s_n, 1)] = (int32_t)b;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n) s_base = atomicAdd(nnz, s_n);
+        __syncthreads();
+        if ((int)threadIdx.x < s_n) nz[s_base + threadIdx.x] = s_list[threadIdx.x];
+        __syncthreads();
     }
 }
 
