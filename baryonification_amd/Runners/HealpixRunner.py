@@ -57,26 +57,68 @@ class DefaultRunner(object):
             assert ok, txt
 
     def _catalog(self, keys):
-        """bfgx_catalog over contiguous float64 columns.  The catalog is a structured array (strided columns), so every
-        process() call would gather M, z, ra, dec into contiguous buffers and take two numpy logs over all halos (the table
-        coordinates np.log(1/a), np.log(M)): ~20 ms per 1e6 halos.  These are kept on the catalog object between calls, keyed by
-        a hash of the WHOLE record buffer (xxh3 over every byte of every halo: ~2 ms per 1e6 halos), so that any in-place edit of
-        the catalog -- one halo, a swap that leaves sums unchanged -- is seen, as it is by the reference, which re-reads `cat` on
-        every call.  Without the xxhash module nothing is cached."""
+        """(bfgx_catalog over contiguous float64 columns, keep-alive, verify).  The catalog is a structured array (strided columns), so
+        every process() call would gather M, z, ra, dec into contiguous buffers and take two numpy logs over all halos (the table
+        coordinates np.log(1/a), np.log(M)): ~20 ms per 1e6 halos.  These are kept on the catalog object between calls, keyed by a hash
+        of the WHOLE record buffer (xxh3 over every byte of every halo), so that any in-place edit of the catalog -- one halo, a swap
+        that leaves sums unchanged -- is seen, as it is by the reference, which re-reads `cat` on every call.  The hash (~2 ms per 1e6
+        halos) is taken by a worker thread WHILE the GPU call runs on the cached columns (ctypes releases the GIL); `verify()` joins
+        it after the call and returns False if the catalog has changed, in which case the caller drops the result, and the call is
+        repeated on fresh columns.  Without the xxhash module nothing is cached."""
         cat = self.HaloLightConeCatalog.cat
         names = ['M', 'z', 'ra', 'dec'] + list(keys)
-        finger = _catalog_fingerprint(cat, names)
-        cached = getattr(self.HaloLightConeCatalog, '_bfgx_columns', None) if finger is not None else None
-        if cached is None or cached[0] != finger:
-            cols = [_lib.f8(cat[k]) for k in names]
-            cached = (finger, cols, _lib.table_coords(cols[0], cols[1]))
-            if finger is not None:
-                try:
-                    self.HaloLightConeCatalog._bfgx_columns = cached
-                except AttributeError:
-                    pass
+        cached = getattr(self.HaloLightConeCatalog, '_bfgx_columns', None)
+        verify = None
+        if cached is not None and cached[0] is not None and cached[0][:3] == (cat.size, str(cat.dtype), tuple(names)):
+            fut = _hash_pool().submit(_catalog_fingerprint, cat, names)
+            expect = cached[0]
+            verify = lambda: fut.result() == expect                               # noqa: E731
+        else:
+            cached = self._catalog_rebuild(cat, names)
         cols = cached[1]
-        return _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], cols[4:], coords=cached[2])
+        c, keep = _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], cols[4:], coords=cached[2])
+        return c, keep, verify
+
+    def _catalog_rebuild(self, cat, names):
+        finger = _catalog_fingerprint(cat, names)
+        cols = [_lib.f8(cat[k]) for k in names]
+        cached = (finger, cols, _lib.table_coords(cols[0], cols[1]))
+        if finger is not None:
+            try:
+                self.HaloLightConeCatalog._bfgx_columns = cached
+            except AttributeError:
+                pass
+        return cached
+
+    def _call_with_catalog(self, keys, call):
+        """call(bfgx_catalog) with the cached columns; repeated on fresh ones if the catalog turns out to have been edited in place"""
+        cat, cols, verify = self._catalog(keys)
+        try:
+            out = call(cat)
+        except Exception:
+            if verify is None or verify():
+                raise                                 # the columns were current: the error is real
+            out = None
+        if verify is not None and not verify():
+            try:
+                del self.HaloLightConeCatalog._bfgx_columns
+            except AttributeError:
+                pass
+            cat, cols, _ = self._catalog(keys)
+            out = call(cat)
+        del cols
+        return out
+
+
+_HASH_POOL = None
+
+
+def _hash_pool():
+    global _HASH_POOL
+    if _HASH_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _HASH_POOL = ThreadPoolExecutor(1, thread_name_prefix='bfgx-catalog-hash')
+    return _HASH_POOL
 
 
 def _catalog_fingerprint(cat, names):
@@ -97,17 +139,18 @@ class BaryonifyShell(DefaultRunner):
         keys = vars(self.model).get('p_keys', [])
         self._check_keys(keys)
         model, p_keys, keep = build_model(self, 'displacement')
-        cat, cols = self._catalog(p_keys)
         orig_map = _lib.f8(self.LightconeShell.map)
         nside = int(self.LightconeShell.NSIDE)
         new_map = _lib.pinned_empty(orig_map.size)          # page-locked: the D2H copy of the result runs at PCIe rate
         opts = _lib.bfgx_opts(int(self.device), int(bool(self.acc_f64)), 1, 1, int(self.algo), 0)
         stats = _lib.bfgx_stats()
-        rc = _lib.load().bfgx_baryonify_shell(C.byref(cat), C.byref(model), nside, orig_map.ctypes.data,
-                                              new_map.ctypes.data, C.byref(opts), C.byref(stats))
-        _lib.check(rc)
+
+        def call(cat):
+            _lib.check(_lib.load().bfgx_baryonify_shell(C.byref(cat), C.byref(model), nside, orig_map.ctypes.data,
+                                                        new_map.ctypes.data, C.byref(opts), C.byref(stats)))
+        self._call_with_catalog(p_keys, call)
         self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
-        del keep, cols
+        del keep
         return new_map
 
 
@@ -119,7 +162,6 @@ class PaintProfilesShell(DefaultRunner):
         self._check_keys(keys)
         assert self.model is not None, "You must provide a model"     # HealpixRunner.py:415
         model, p_keys, keep = build_model(self, 'projected')
-        cat, cols = self._catalog(p_keys)
         nside = int(self.LightconeShell.NSIDE)
         new_map = _lib.pinned_empty(self.LightconeShell.map.size)
         # acc_f64: None (default) / 2 / 'mixed' = fp32 pair math (chord, ln r, read-out, exp) accumulated in fp64 into the fp64 map -- the
@@ -128,9 +170,10 @@ class PaintProfilesShell(DefaultRunner):
         acc64 = 2 if (self.acc_f64 is None or self.acc_f64 in (2, 'mixed')) else int(bool(self.acc_f64))
         opts = _lib.bfgx_opts(int(self.device), 0, acc64, 0, int(self.algo), 0)
         stats = _lib.bfgx_stats()
-        rc = _lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data,
-                                          C.byref(opts), C.byref(stats))
-        _lib.check(rc)
+
+        def call(cat):
+            _lib.check(_lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data, C.byref(opts), C.byref(stats)))
+        self._call_with_catalog(p_keys, call)
         self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
-        del keep, cols
+        del keep
         return new_map

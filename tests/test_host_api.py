@@ -183,7 +183,7 @@ def test_warm_process_call_allocates_nothing(gpu):
     assert out1.ctypes.data != out2.ctypes.data and out2.ctypes.data != out3.ctypes.data
     # another model -> another plan (allocations), and both stay cached
     gp = load_golden('lowz_paint')
-    rp = product_runner(gp)
+    rp = product_runner(gp, acc_f64=True)
     p1 = rp.process()
     n2 = L.bfgx_debug_alloc_count()
     assert n2 > n1
@@ -201,3 +201,43 @@ def test_warm_process_call_allocates_nothing(gpu):
     assert out5.ctypes.data == addr
     L.bfgx_cache_clear()
     _lib.pinned_pool_clear()
+
+
+@pytest.mark.gpu
+def test_in_place_catalog_edit_between_calls_is_seen(gpu):
+    """the contiguous catalog columns are cached on the catalog object between process() calls; an in-place edit of ONE halo that a
+    sampled fingerprint would miss -- and a swap of two halos that leaves every column sum unchanged -- must be seen, as the reference,
+    which re-reads `cat` on every call, sees it"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    from oracle import oracle as O
+    nside, N = 64, 20_000
+    cat = syn.make_catalog(N, seed=3, logM_lo=13.0, logM_hi=14.5)
+    z, M, r = syn.table_grid(cat, pad=1e-3)
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO), epsilon_max=10.0)
+    d = syn.displacement_table(z, M, r)
+    model.set_table(z, M, r, d)
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    hmap = syn.make_map(nside)
+    runner = bfg.Runners.BaryonifyShell(Catalog, bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO), 10.0, model, verbose=False)
+    runner.acc_f64 = True
+    bg = O.Background.from_dict(syn.COSMO)
+    tab = O.Table([np.log(1 + z), np.log(M), np.log(r)], d, False, 10.0)
+
+    def oracle():
+        used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}
+        return O.baryonify_shell(nside, hmap, used, tab, 10.0, bg)
+
+    out0 = runner.process()
+    assert np.abs(out0 - oracle()).max() <= 1e-10 * hmap.max() and hasattr(Catalog, '_bfgx_columns')
+    j = 7777                                                    # not a multiple of any sampling stride, not the last element
+    Catalog.cat['M'][j] *= 1.05                                 # stays inside the table (pad)
+    out1 = runner.process()
+    ora1 = oracle()
+    assert np.abs(out1 - ora1).max() <= 1e-10 * hmap.max() and np.abs(out1 - out0).max() > 0
+    a, b = 123, 4567                                            # swap two halos' positions: every column sum is unchanged
+    for k in ('ra', 'dec'):
+        Catalog.cat[k][a], Catalog.cat[k][b] = Catalog.cat[k][b], Catalog.cat[k][a]
+    out2 = runner.process()
+    assert np.abs(out2 - oracle()).max() <= 1e-10 * hmap.max() and np.abs(out2 - out1).max() > 0
+    assert np.array_equal(runner.process(), out2) or np.abs(runner.process() - out2).max() <= 1e-13 * hmap.max()      # unchanged catalog: cached
