@@ -338,6 +338,9 @@ def main_grid(args):
                'deposit': npart * (3 * 8 + 8) + N ** 3 * 8, 'pk': N ** 3 * 8 + 4 * spec, 'displace': npart * 48 + nh * 32}
         dom = max(alg, key=lambda k: kernels.get(k) or 0.0)
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
+        g_traffic, _, g_src = committed_traffic({"ngrid": N, "particles": npart, "particle_order": "coarse-cell raster" if args.sorted_particles else "random",
+                                                 "halos_per_gpu": nh} if world == 1 else {"ngrid": -1}, dom,
+                                                metric_has="BaryonifySnapshot" if snapshot else "BaryonifyGrid")
         if snapshot:
             sums = np.array([float(npart), float(d_out.sum().item())])       # every particle lands in the box
         out = {"metric": ("particles/sec for BaryonifySnapshot + deposit + FFT P(k) on a %d^3 grid" % N) if snapshot else
@@ -359,8 +362,8 @@ def main_grid(args):
                                        "offsets": "grid_gather_regrid_kernel<3> (halo loop + regrid, cell-owned)" if world == 1 else "grid_scatter_kernel<3,OFFSETS>",
                                        "deposit": "deposit_keys + 2 x deposit_split + deposit_tiles (bfgx_deposit.hpp)",
                                        "pk": "fft_r2c_lines + fft_c2c_strided + fft_c2c_strided<bins>", "displace": "snap_displace_kernel<3>"}[dom],
-                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                            "algorithmic_bytes_per_launch": alg[dom]}}
+                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": g_traffic,
+                            "traffic_source": g_src, "algorithmic_bytes_per_launch": alg[dom]}}
         if world == 1 and not args.no_cpu_baseline and not snapshot:
             out["cpu_baseline"] = cpu_baseline_grid(args, cat, bins, zr, axes, table, eps)
         print(json.dumps(out), flush=True)
@@ -800,6 +803,24 @@ def shell_line(args, ctx, scaling, brief):
     return out if rank == 0 else None
 
 
+def committed_traffic(match, key, metric_has=None):
+    """HBM bytes per launch (and SQ_INSTS_VALU) of kernel group `key` from the committed rocprofv3 --pmc passes of THIS configuration:
+    profiles/traffic_<tag>.json, written by scripts/traffic_pmc.sh (one counter per pass, FETCH_SIZE doubled as the gfx950 guide
+    prescribes).  `match`: the config keys that must agree with the file's bench line.  Returns (traffic, valu, file) or (None, None, None)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(HERE, 'profiles', 'traffic_*.json'))):
+        try:
+            tj = json.load(open(f))
+            c = tj.get('config', {})
+            if metric_has is not None and metric_has not in (tj.get('metric') or ''):
+                continue
+            if all(c.get(k) == v for k, v in match.items()) and key in tj.get('kernels', {}):
+                return tj['kernels'][key], tj.get('valu_wave_insts', {}).get(key), os.path.basename(f)
+        except Exception:        # noqa: BLE001
+            continue
+    return None, None, None
+
+
 def roofline(args, kernels, n_pairs, nh, npix, paint):
     """The dominant kernel (by measured time) against the HBM roof SURVEY 8(d) defines: algorithmic bytes per launch / average
     launch duration (HIP events on the launch stream over K steps).  traffic / VALU counts come from the committed rocprofv3 --pmc
@@ -813,17 +834,12 @@ def roofline(args, kernels, n_pairs, nh, npix, paint):
              "regrid": ("tile_regrid3_kernel<%s, %s, 0>" % (real, real)) if args.algo == 1 else "regrid_kernel",
              "paint": ("tile_scatter2_kernel<PAINT, double, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
     ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
-    traffic = valu = None
-    try:
-        tj = json.load(open(os.path.join(HERE, 'profiles', 'traffic_latest.json')))
-        c = tj['config']
-        if (c['halos_per_gpu'], c['nside'], c['algo'], c['mode']) == (nh, args.nside, args.algo, args.mode) and not args.acc_f64:
-            traffic = tj['kernels'].get(dom)
-            valu = tj.get('valu_wave_insts', {}).get(dom)
-    except Exception:        # noqa: BLE001
-        pass
+    traffic = valu = src = None
+    if not args.acc_f64 and args.algo == 1 and args.table == 'closed-form':
+        traffic, valu, src = committed_traffic({"halos_per_gpu": nh, "nside": args.nside, "pairs_per_gpu": n_pairs}, dom,
+                                               metric_has="PaintProfilesShell" if paint else "BaryonifyShell")
     r = {"kernel": names[dom], "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
+         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg[dom],
          "launch_ms": kernels[dom]}
     if valu:
         # what binds the kernel: vector issue.  Measured on MI355X (scripts/ubench/valu_rate.hip, profiles/r02_ubench_valu_rate.txt):
