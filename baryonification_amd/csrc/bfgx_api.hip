@@ -1325,7 +1325,8 @@ struct PoolBuf {
 };
 
 struct CacheEntry {
-    uint64_t key = 0, stamp = 0;
+    uint64_t key = 0, key2 = 0, stamp = 0;     // two independent 64-bit hashes of (device, nside, model contents) + table size
+    int64_t table_values = 0;
     bfgx_plan *plan = nullptr;
     PoolBuf cols[kCatCols], in, out, off, sums;
     hipStream_t copy_stream = nullptr;       // the map travels to the device while K0 / K1 run on the plan's stream
@@ -1337,18 +1338,25 @@ std::vector<CacheEntry *> g_cache;
 uint64_t g_cache_stamp = 0;
 constexpr size_t kCacheMax = 4;
 
+uint64_t g_hash_mul = 0x100000001b3ull;       // multiplier of hash_bytes (set by model_key: two passes with different constants)
+
 uint64_t hash_bytes(uint64_t h, const void *data, size_t bytes)
 {
     const unsigned char *c = (const unsigned char *)data;
+    const uint64_t mul = g_hash_mul;
     size_t i = 0;
-    for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, c + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
-    for (; i < bytes; ++i) h = (h ^ c[i]) * 0x100000001b3ull;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, c + i, 8); h = (h ^ w) * mul; h ^= h >> 29; }
+    for (; i < bytes; ++i) h = (h ^ c[i]) * mul;
     return h;
 }
 
-uint64_t model_key(int device, int64_t nside, const bfgx_model *m)
+// which = 0: FNV-style offset basis and prime; which = 1: a second, independent pass (other basis, other odd multiplier) -- a cache hit
+// needs both to agree (and the table size), so that one 64-bit collision cannot hand a model another model's device table
+uint64_t model_key(int device, int64_t nside, const bfgx_model *m, int which = 0)
 {
-    uint64_t h = 0xcbf29ce484222325ull;
+    g_hash_mul = which ? 0x9e3779b97f4a7c15ull : 0x100000001b3ull;
+    struct Restore { ~Restore() { g_hash_mul = 0x100000001b3ull; } } restore;
+    uint64_t h = which ? 0x2545f4914f6cdd1dull : 0xcbf29ce484222325ull;
     h = hash_bytes(h, &device, sizeof(device));
     h = hash_bytes(h, &nside, sizeof(nside));
     const bfgx_table &t = m->table;
@@ -1381,9 +1389,11 @@ void cache_drop(CacheEntry *e)
 int cache_acquire(int device, int64_t nside, const bfgx_model *model, int64_t n, CacheEntry **out)
 {
     if (int rc = validate_model(model)) return rc;           // before hashing: the table pointers must be readable
-    const uint64_t key = model_key(device, nside, model);
+    const uint64_t key = model_key(device, nside, model), key2 = model_key(device, nside, model, 1);
+    int64_t nvals = 1;
+    for (int d = 0; d < model->table.ndim; ++d) nvals *= model->table.n[d];
     CacheEntry *e = nullptr;
-    for (CacheEntry *c : g_cache) if (c->key == key) e = c;
+    for (CacheEntry *c : g_cache) if (c->key == key && c->key2 == key2 && c->table_values == nvals) e = c;
     if (e && e->plan->max_halos < n) {                       // grew: rebuild the plan (its workspace scales with max_halos)
         (void)hipSetDevice(device);
         bfgx_plan_destroy(e->plan);
@@ -1397,7 +1407,7 @@ int cache_acquire(int device, int64_t nside, const bfgx_model *model, int64_t n,
             g_cache.erase(g_cache.begin() + (long)lru);
         }
         e = new CacheEntry();
-        e->key = key;
+        e->key = key; e->key2 = key2; e->table_values = nvals;
         g_cache.push_back(e);
     }
     if (!e->plan) {

@@ -78,10 +78,11 @@ typedef struct bfgx_catalog {
     int64_t n;
     const double *M, *z, *ra, *dec;
     const double *extra[BFGX_MAX_EXTRA];  /* cat[p_keys[k]], in table-axis order; NULL if unused */
-    /* optional (NULL = derive on the device): the halo's table coordinates np.log(1 + z) and np.log(M) as the CALLER's
-     * numpy computes them (BaryonCorrection.py:364-366, Tabulate.py:279-281).  README.md:78-80 builds tables whose edges
-     * are exactly the catalog's min/max, so whether an edge halo is inside the table hangs on the last bit of these logs.
-     * The one-shot host API fills them itself when they are NULL. */
+    /* optional (NULL = derive on the device): the halo's table coordinates as the CALLER's numpy computes them, in exactly the
+     * reference's form: `a = 1 / (1 + z); ln1pz = np.log(1 / a)` (NOT np.log(1 + z): the two differ in the last bit) and
+     * `lnM = np.log(M)` (BaryonCorrection.py:364-366, Tabulate.py:279-281; the Python binding: _lib.table_coords).  README.md:78-80
+     * builds tables whose edges are exactly the catalog's min/max, so whether an edge halo is inside the table hangs on the last bit
+     * of these logs.  The one-shot host API fills them itself, in the same form (libm), when they are NULL. */
     const double *ln1pz, *lnM;
 } bfgx_catalog;
 
