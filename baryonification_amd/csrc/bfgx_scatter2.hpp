@@ -190,7 +190,11 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     real sn, omc;
     PM::sin_omc(x, sn, omc);
     const real ux = fma_(-rg.sth, omc, rc.ds), uy = rg.sth * sn, uz = rc.dz;   // (v_pix - v_halo) / D, HealpixRunner.py:314-316
-    const real u2 = ux * ux + uy * uy + uz * uz;
+    // |u|^2.  Painting needs nothing else of u, and with sin^2 x + (1 - cos x)^2 = 2 (1 - cos x):
+    //   |u|^2 = ds^2 + dz^2 + 2 sth (sth - ds) (1 - cos x),   sth - ds = sin(theta_halo)
+    // -- the chord to the ring's point at the halo's azimuth plus the azimuthal part, both positive: sin x, ux and uy drop out
+    const real u2 = (MODE == MODE_PAINT) ? fma_((real)2 * rg.sth * (rg.sth - rc.ds), omc, fma_(rc.ds, rc.ds, rc.dz * rc.dz))
+                                         : ux * ux + uy * uy + uz * uz;
     bool ok = act && (u2 > (real)0) && !ph.oob;                    // r_sep = 0: diff / r_sep is NaN -> 0 (:322-323)
     const real u2s = (u2 > (real)0) ? u2 : (real)1;
     const real rinv = PM::rsq(u2s);                                // 1 / |u|
