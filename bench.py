@@ -526,7 +526,7 @@ def shell_line(args, ctx, scaling, brief):
         # that no count is read back by the host inside a step (the catalog is shuffled, Parallelize.py:255: a destination receives about
         # nh / world halos from every source; 1.5 x that + 2048 is > 40 sigma).  An overflow is detected on the device, checked after the
         # untimed trial step and answered with the variable-split routing (route_halos: one read-back per step)
-        blockcap = int(1.5 * np.ceil(nh / world)) + 2048
+        blockcap = int(1.5 * np.ceil(np.ceil(total_halos / world) / world)) + 2048      # (the same on every rank: shards differ by one halo)
         cap = max(world * blockcap, 2 * int(np.ceil(total_halos / world)) + 4096)
         plan_sp = engine.ShellPlan(model, keep, nside, cap, device=local_rank, stream=stream)
         d_rings = torch.empty((nh, 2), dtype=torch.int32, device=dev)

@@ -63,13 +63,13 @@ def test_two_ranks_self_launched_strong_and_weak(gpu):
     """`python bench.py --gpus 2` as the driver types it (no launcher): the ranks are started as a child torch.distributed.run; both share
     device 0 over gloo (a one-GPU box), the product's HIP kernels + every exchange step of the spatial sharding run for real"""
     env = dict(os.environ, BFGX_DIST_BACKEND='gloo')
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--halos', '20000', '--nside', '128', '--steps', '3',
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--halos', '20001', '--nside', '128', '--steps', '3',
                           '--warmup', '1'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     _check_common(d, n_gpus=2)
-    assert d['scaling'] == 'strong' and d['mass_conserved'] is True and d['config']['halos_per_gpu'] == 10000
+    assert d['scaling'] == 'strong' and d['mass_conserved'] is True and d['config']['halos_per_gpu'] == 10001      # (shards that differ by one halo: every rank must still use the same routing block size)
     w = d['value_weak']
     assert w['scaling'] == 'weak' and w['value'] > 0 and w['mass_conserved'] is True
