@@ -36,12 +36,37 @@ struct SnapHaloRec {
     int32_t oob, valid;
 };
 
-// one halo of a cell's list: what the containment test needs sits in the list itself (contiguous per cell), the full
-// record is only fetched on a hit.  The displace kernel is bound by random 64-byte requests, not by bytes.
+// one halo of a cell's list, 16 bytes -- four to a 64-byte line (the displace kernel is bound by random 64-byte requests, not by
+// bytes; with the fp64 position and radius in the list an entry took 40 bytes and a cell's list two to three lines).  What sits here is
+// a conservative PRE-FILTER of the containment test: the halo's wrapped position in 20-bit fixed point per axis and an upper bound of
+// the query radius that covers the quantisation (L / 2^21 per axis) and the fp32 arithmetic of the test.  A particle that passes is
+// queued, and the exact fp64 test of the reference (scipy's squared-distance comparison, SnapshotRunner.py:225) is made on the full
+// record, which is fetched for queued candidates only.
 struct SnapEntry {
-    double pos[3], Rq2;
-    int32_t idx, _pad;
+    uint64_t xyz;                     // floor(p / L * 2^20) for x | y << 20 | z << 40
+    float rq_ub;                      // >= R_q + the slack above
+    int32_t idx;
 };
+constexpr double kSnapFix = 1048576.0;            // 2^20
+
+__device__ inline SnapEntry snap_make_entry(const SnapGeom &g, const SnapHaloRec &r, int32_t idx)
+{
+    SnapEntry en;
+    en.xyz = 0;
+    for (int ax = 0; ax < g.ndim; ++ax) {
+        double p = r.pos[ax];
+        p -= floor(p / g.L) * g.L;
+        unsigned long long q = (unsigned long long)(p / g.L * kSnapFix);
+        if (q > 1048575ull) q = 1048575ull;
+        en.xyz |= q << (20 * ax);
+    }
+    const double rq = sqrt(r.Rq2) + 3.0e-6 * g.L;             // quantisation sqrt(3) L 2^-21 + fp32 rounding of |L| values, with room
+    float f = (float)rq;
+    if ((double)f < rq) f = __int_as_float(__float_as_int(f) + 1);
+    en.rq_ub = f * 1.000001f;
+    en.idx = idx;
+    return en;
+}
 
 __device__ inline int snap_cell(double v, const SnapGeom &g)
 {
@@ -116,6 +141,32 @@ __device__ inline int64_t snap_cube_cell(const SnapGeom &g, const SnapHaloRec &r
     return snap_cell_index(g, cx, cy, cz);
 }
 
+// does the query ball of halo r reach into the c-th cell of its cube?  Per axis the distance from the halo to the cell's slab
+// [i h, (i + 1) h] (periodic, halo position wrapped into the box), widened by 1e-9 L against rounding; the ball touches the cell iff the
+// squared distances add up to no more than R_q^2.  A ball fills pi / 6 of its bounding cube: listing the halo only where the ball
+// reaches keeps the corner cells of the cube (and their particles) out of the lists -- the displace kernel is bound by the list
+// look-ups of the particles in listed cells.  Conservative: a cell that holds a point of the ball is never dropped.
+__device__ inline bool snap_cube_cell_touched(const SnapGeom &g, const SnapHaloRec &r, int c)
+{
+    const int nz = (g.ndim == 3) ? r.cn[2] : 1;
+    const int iz = c % nz, q = c / nz, iy = q % r.cn[1], ix = q / r.cn[1];
+    const int idx[3] = {ix, iy, iz};
+    const double h = g.L / (double)g.nc, slack = 1e-9 * g.L;
+    double d2 = 0.0;
+    for (int ax = 0; ax < g.ndim; ++ax) {
+        if (r.cn[ax] >= g.nc) continue;                      // the cube spans the whole axis: no restriction from it
+        int cc = r.clo[ax] + idx[ax]; cc -= (cc >= g.nc) ? g.nc : 0;
+        double p = r.pos[ax];
+        p -= floor(p / g.L) * g.L;
+        double dc = ((double)cc + 0.5) * h - p;              // cell centre - halo, minimum image
+        if (dc > 0.5 * g.L) dc -= g.L;
+        if (dc < -0.5 * g.L) dc += g.L;
+        const double d = fabs(dc) - 0.5 * h - slack;
+        if (d > 0.0) d2 += d * d;
+    }
+    return d2 <= r.Rq2;
+}
+
 // one WAVE per halo, lanes = the cells of its cube (27 - 125 of them): the atomics of a halo are in flight together instead of
 // one after the other in a single thread (list fill 0.63 -> 0.07 ms at 1e5 halos)
 __global__ void __launch_bounds__(256)
@@ -127,7 +178,8 @@ snap_halo_count_kernel(SnapGeom g, int64_t nh, const SnapHaloRec *__restrict__ r
     const SnapHaloRec &r = recs[j];
     if (!r.valid) return;
     const int ncell = r.cn[0] * r.cn[1] * ((g.ndim == 3) ? r.cn[2] : 1);
-    for (int c = lane; c < ncell; c += kWave) atomicAdd(cell_count + snap_cube_cell(g, r, c), 1);
+    for (int c = lane; c < ncell; c += kWave)
+        if (snap_cube_cell_touched(g, r, c)) atomicAdd(cell_count + snap_cube_cell(g, r, c), 1);
 }
 
 __global__ void __launch_bounds__(256)
@@ -139,10 +191,10 @@ snap_halo_fill_kernel(SnapGeom g, int64_t nh, const SnapHaloRec *__restrict__ re
     if (j >= nh) return;
     const SnapHaloRec &r = recs[j];
     if (!r.valid) return;
-    SnapEntry en;
-    en.pos[0] = r.pos[0]; en.pos[1] = r.pos[1]; en.pos[2] = r.pos[2]; en.Rq2 = r.Rq2; en.idx = (int32_t)j; en._pad = 0;
+    const SnapEntry en = snap_make_entry(g, r, (int32_t)j);
     const int ncell = r.cn[0] * r.cn[1] * ((g.ndim == 3) ? r.cn[2] : 1);
     for (int c = lane; c < ncell; c += kWave) {
+        if (!snap_cube_cell_touched(g, r, c)) continue;
         const int64_t cell = snap_cube_cell(g, r, c);
         entries[cell_start[cell] + atomicAdd(cell_cursor + cell, 1)] = en;
     }
@@ -239,9 +291,15 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
     const int tid = threadIdx.x;
     unsigned long long npairs = 0;
 
-    // read-out of one hit and its contribution to particle `slot` (SnapshotRunner.py:228-244)
-    auto hit = [&](int slot, const SnapEntry &en, double dx, double dy, double dz, double d2) {
-        const SnapHaloRec &r = recs[en.idx];
+    // exact containment test of particle `slot` against halo `idx` (:225 / :237 query_ball_point, fp64 as the reference), then the
+    // read-out of the hit and its contribution to the particle (SnapshotRunner.py:228-244)
+    auto hit = [&](int slot, int idx) {
+        const SnapHaloRec &r = recs[idx];
+        const double dx = min_image(spos[0][slot] - r.pos[0], g.L), dy = min_image(spos[1][slot] - r.pos[1], g.L);
+        const double dz = (DIM == 3) ? min_image(spos[2][slot] - r.pos[2], g.L) : 0.0;
+        double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
+        if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
+        if (!(d2 <= r.Rq2)) return;
         // libm-free (bfgx_math.hpp)
         const double inv_d = (d2 > 0.0) ? fast_rsq(d2) : 0.0;
         const double d = d2 * inv_d;                                             // :228 compute_distance
@@ -262,18 +320,23 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
         }
     };
 
-    // containment test of particle `slot` against list entry e: a hit is queued for phase 2 (queuing the candidates too, so that
-    // this test runs one per lane, was measured: no gain -- the loop waits for the list entries, not for diverged lanes)
-    auto test = [&](int slot, int e) {
-        const SnapEntry &en = entries[e];
-        const double dx = min_image(spos[0][slot] - en.pos[0], g.L), dy = min_image(spos[1][slot] - en.pos[1], g.L);
-        const double dz = (DIM == 3) ? min_image(spos[2][slot] - en.pos[2], g.L) : 0.0;
-        double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
-        if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
-        if (!(d2 <= en.Rq2)) return;                                             // :225 / :237 query_ball_point
+    // pre-filter of particle `slot` (fp32 position pf) against list entry e: a candidate is only QUEUED for phase 2 (queuing every
+    // entry, so that this test runs one per lane, was measured: no gain -- the loop waits for the list entries, not for diverged lanes)
+    const float Lf = (float)g.L, fixf = (float)(g.L / kSnapFix);
+    auto test = [&](int slot, const float pf[3], const SnapEntry en) {
+        float d2 = 0.0f;
+#pragma unroll
+        for (int ax = 0; ax < DIM; ++ax) {
+            const float hp = ((float)((en.xyz >> (20 * ax)) & 1048575ull) + 0.5f) * fixf;
+            float d = pf[ax] - hp;
+            d -= (d > 0.5f * Lf) ? Lf : 0.0f;
+            d += (d < -0.5f * Lf) ? Lf : 0.0f;
+            d2 = __builtin_fmaf(d, d, d2);
+        }
+        if (!(d2 <= en.rq_ub * en.rq_ub)) return;
         const int qi = atomicAdd(&qn, 1);
-        if (qi < kSnapQueue) { qslot[qi] = slot; qent[qi] = e; }
-        else hit(slot, en, dx, dy, dz, d2);                                      // hit queue full (a cluster core): done here
+        if (qi < kSnapQueue) { qslot[qi] = slot; qent[qi] = en.idx; }
+        else hit(slot, en.idx);                                                  // queue full (a cluster core): done here
     };
 
     // grid-stride over blocks of 256 particles: a bounded number of workgroups, so that the pair census ends in a few thousand
@@ -294,22 +357,22 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
                 const int64_t c = snap_cell_index(g, snap_cell(x, g), snap_cell(y, g), (DIM == 3) ? snap_cell(z, g) : 0);
                 int e0 = 0, e1 = 0;
                 if ((bitmap[c >> 5] >> (c & 31)) & 1u) { e0 = cell_start[c]; e1 = cell_start[c + 1]; }
-                for (int e = e0; e < e1; ++e) test(tid, e);
+                const float pf[3] = {(float)x, (float)y, (float)z};
+                // four entries (one 64-byte line when aligned) are requested together: the loop waits for list entries, so its length
+                // in round trips is what counts
+                for (int e = e0; e < e1; e += 4) {
+                    SnapEntry en[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) en[k] = entries[min(e + k, e1 - 1)];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (e + k < e1) test(tid, pf, en[k]);
+                }
             }
         }
         __syncthreads();
         // ---- phase 2: the queued hits, one per lane
         const int nq = min(qn, kSnapQueue);
-        for (int i = tid; i < nq; i += 256) {
-            const int slot = qslot[i];
-            const SnapEntry &en = entries[qent[i]];
-            const double hx = spos[0][slot], hy = spos[1][slot], hz = spos[2][slot];
-            const double dx = min_image(hx - en.pos[0], g.L), dy = min_image(hy - en.pos[1], g.L);
-            const double dz = (DIM == 3) ? min_image(hz - en.pos[2], g.L) : 0.0;
-            double d2 = add_nc(mul_nc(dx, dx), mul_nc(dy, dy));
-            if (DIM == 3) d2 = add_nc(d2, mul_nc(dz, dz));
-            hit(slot, en, dx, dy, dz, d2);
-        }
+        for (int i = tid; i < nq; i += 256) hit(qslot[i], qent[i]);
         __syncthreads();
         // ---- phase 3
         if (on) {
