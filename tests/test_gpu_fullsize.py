@@ -600,3 +600,77 @@ def test_rank_without_bands_is_a_no_op(gpu):
         assert sums.tolist() == [0.0, 0.0]
         sums.fill_(7.0)
     plan.close()
+
+
+def test_config4_full_size_eight_rank_decomposition_on_one_gpu(gpu):
+    """BASELINE config 4 (1e7 halos, BaryonifyShell, NSIDE 2048, 8 GPUs) at FULL size on one GPU, the eight ranks of the spatial sharding
+    played one after the other: every rank takes the halos whose discs can touch its ring bands (disc_rings), computes pix_offsets for
+    ITS pixels (K0 + K1 on its tiles) and regrids its bands from its slice + the apron rings of its neighbours.  The eight slices ==
+    the single-GPU pass (pix_offsets to fp32 rounding, the map to the stated fp32 tolerance), the pair counts add up, the mass is conserved --
+    i.e. what the first real 8-GPU run will compute, minus the transport"""
+    from baryonification_amd.utils.Parallelize import band_partition, band_ring_bounds
+    N, nside, world = 10_000_000, 2048, 8
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    npix = 12 * nside * nside
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+    cd, cols = _cat_dev(torch, _lib, dev, cat, coords=True)
+    full_off = torch.empty(npix * 3, dtype=torch.float32, device=dev)
+    full_out = torch.empty(npix, dtype=torch.float64, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    plan.baryonify(cd, d_map.data_ptr(), full_off.data_ptr(), full_out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    torch.cuda.synchronize()
+    plan.status()
+    s = sums.cpu().numpy()
+    assert np.isclose(s[1], s[0]) and np.isclose(float(full_out.sum().item()), hmap.sum())       # HealpixRunner.py:344-346
+    n_full = plan.count_pairs(cd, True)
+    assert n_full > 2e9
+    rings = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    plan.disc_rings(cd, rings.data_ptr())
+    first = plan.bands()
+    cuts = band_partition(first, world)
+    rb = band_ring_bounds(cuts, plan.tile_shape()[0], nside)
+    m2 = torch.empty(1, dtype=torch.float32, device=dev)
+    plan.max_offset2(full_off.data_ptr(), npix, m2.data_ptr(), acc_f64=False)
+    plan.set_band_reach(plan.reach_rings(float(m2.item()) ** 0.5))
+    off_scale, map_scale = float(full_off.abs().max().item()), float(full_out.abs().max().item())
+    taken, s_in, s_out, n_far = 0, 0.0, 0.0, 0
+    new = torch.full((npix,), float('nan'), dtype=torch.float64, device=dev)
+    far_acc = torch.zeros(npix, dtype=torch.float64, device=dev)              # far deposits (pole caps) may land in any rank's slice
+    for rk in range(world):
+        sel = torch.nonzero((rings[:, 0].long() < int(rb[rk + 1])) & (rings[:, 1].long() >= int(rb[rk]))).reshape(-1)
+        taken += int(sel.numel())
+        t = {k: v[sel].contiguous() for k, v in cols.items()}
+        cdr = _lib.make_catalog_dev(int(sel.numel()), t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr(),
+                                    ln1pz_ptr=t['lnz'].data_ptr(), lnM_ptr=t['lnM'].data_ptr())
+        b0, b1 = int(cuts[rk]), int(cuts[rk + 1])
+        p0, p1 = int(first[b0]), int(first[b1])
+        lo, hi = plan.band_apron(b0, b1)
+        buf = torch.full(((hi - lo) * 3,), float('nan'), dtype=torch.float32, device=dev)
+        plan.offsets_bands(cdr, b0, b1, buf[(p0 - lo) * 3:].data_ptr(), acc_f64=False)
+        torch.cuda.synchronize()
+        plan.status()
+        mine = buf[(p0 - lo) * 3:(p1 - lo) * 3]
+        assert torch.isfinite(mine).all().item() and (mine - full_off[p0 * 3:p1 * 3]).abs().max().item() <= 2e-6 * off_scale
+        # the apron rings come from the neighbours' slices: here from the single-GPU pass, which the neighbours' slices equal
+        buf[:(p0 - lo) * 3] = full_off[lo * 3:p0 * 3]
+        buf[(p1 - lo) * 3:] = full_off[p1 * 3:hi * 3]
+        rs = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.regrid_bands(b0, b1, d_map.data_ptr(), buf.data_ptr(), lo, hi, new[p0:].data_ptr(), rs.data_ptr(), acc_f64=False)
+        fp, fv = plan.far_fetch()
+        n_far += len(fp)
+        if len(fp):
+            far_acc.index_add_(0, torch.from_numpy(fp).to(dev), torch.from_numpy(fv).to(dev))
+        r2 = rs.cpu().numpy()
+        s_in += r2[0]; s_out += r2[1]
+        del buf, t
+    torch.cuda.synchronize()
+    assert N <= taken <= 1.3 * N
+    assert np.isclose(s_out, s_in) and np.isclose(s_in, hmap.sum())
+    assert torch.isfinite(new).all().item()                                   # every pixel of every slice was stored
+    new += far_acc
+    # (a slice's fp32 pix_offsets can differ from the single pass in the last bit -- the order of the LDS additions --, which moves a
+    # pixel's value by up to ~1e-7 of it: the stated fp32 tolerance, 1e-6 mean(map), applies; most pixels agree exactly)
+    diff = (new - full_out).abs()
+    assert diff.max().item() <= 1e-6 * hmap.mean() and (diff > 1e-12 * map_scale).float().mean().item() < 0.05 and n_far < npix // 100
+    plan.close()
