@@ -738,7 +738,9 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         const bool implied = (m.tab.logv != 0) || (!r.fb && cut >= 2.0 * sh * (1.0 + 1e-9));     // paint: no model-side cut at all
         o.rowrec[j] = rr;
         PairRecT<real> pr;
-        pr.lnoffD = (real)(r.lnoff + fast_log(D));
+        // a halo outside the (z, M) table reads NaN (RGI fill_value): its ln r offset is pushed beyond any table, so that the pair
+        // phase's range test drops it without a flag of its own
+        pr.lnoffD = oob ? (real)1.0e30 : (real)(r.lnoff + fast_log(D));
         pr.cut2 = implied ? (real)3.0e38 : (real)rr.cut2;
         pr.aD = (real)(a / D);
         pr.cph0 = (real)r.cph0; pr.sph0 = (real)r.sph0;

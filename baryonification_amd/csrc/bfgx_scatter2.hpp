@@ -56,6 +56,7 @@ template <> struct PMath<float> {
         omc = u * pc;
     }
     static __device__ inline bool finite(float v) { return __builtin_isfinite(v); }
+    static __device__ inline float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 };
 
 template <> struct PMath<double> {
@@ -71,6 +72,7 @@ template <> struct PMath<double> {
         omc = 2.0 * sh * sh;
     }
     static __device__ inline bool finite(double v) { return __builtin_isfinite(v); }
+    static __device__ inline double med3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 };
 
 // ---------------------------------------------------------------------------------- LDS records
@@ -195,13 +197,16 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     // -- the chord to the ring's point at the halo's azimuth plus the azimuthal part, both positive: sin x, ux and uy drop out
     const real u2 = (MODE == MODE_PAINT) ? fma_((real)2 * rg.sth * (rg.sth - rc.ds), omc, fma_(rc.ds, rc.ds, rc.dz * rc.dz))
                                          : ux * ux + uy * uy + uz * uz;
-    bool ok = act && (u2 > (real)0) && !ph.oob;                    // r_sep = 0: diff / r_sep is NaN -> 0 (:322-323)
-    const real u2s = (u2 > (real)0) ? u2 : (real)1;
+    // r_sep = 0 (diff / r_sep is NaN -> 0, :322-323): |u|^2 is floored at 1e-37, whose ln lies below any table (and u = 0 adds nothing
+    // anyway); a halo outside the (z, M) table carries lnoffD = +1e30 (K0), which fails the range test: no flags of their own
+    bool ok = act;
+    const real u2s = (u2 > (real)1e-37) ? u2 : (real)1e-37;
     const real rinv = PM::rsq(u2s);                                // 1 / |u|
     const real lx = PM::half_ln(u2s) + ph.lnoffD;                  // ln(r_sep / a) [- ln R when Rdelta]
     ok = ok && (lx >= tb.r0) && (lx <= tb.r1);                     // RGI fill_value = nan
     const real uu = (lx - tb.r0) * tb.inv_dr;
-    const int i = max(0, min((int)uu, tb.nr - 2));
+    const real uc = PM::med3(uu, (real)0, (real)(tb.nr - 2));      // (clamped BEFORE the conversion: uu may be +-huge)
+    const int i = (int)uc;
     const real tr_ = uu - (real)i;
     const real *tp = tb.v + (unsigned)(ph.cell + i * 8);           // (cell >= 0: 32-bit offset from the uniform table base)
     real q[8];
