@@ -509,7 +509,7 @@ struct FbRec { int32_t ring[4], k[4]; };   // the 4 get_interp_weights neighbour
 template <typename real>
 struct alignas(16) PairRecT {              // what the pair phase needs of a halo, in the precision of the pair math
     real lnoffD;                           // ln(1/a) [- ln R_model] + ln D:  ln r axis coordinate = ln|u| + lnoffD,  u = diff / D
-    real cut2;                             // (rcut a / D)^2, or a huge number when the disc itself implies r < eps R
+    real cut2;                             // 1 / (rcut a / D)^2, or 0 when the disc itself implies r < eps R
     real aD;                               // a / D: offset / D = d aD u / |u|
     real cph0, sph0;                       // rotation back by +phi0
     real w[4];                             // (z, M) corner weights
@@ -741,7 +741,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         // a halo outside the (z, M) table reads NaN (RGI fill_value): its ln r offset is pushed beyond any table, so that the pair
         // phase's range test drops it without a flag of its own
         pr.lnoffD = oob ? (real)1.0e30 : (real)(r.lnoff + fast_log(D));
-        pr.cut2 = implied ? (real)3.0e38 : (real)rr.cut2;
+        pr.cut2 = implied ? (real)0 : (real)(1.0 / rr.cut2);       // 1 / cut^2 (see pair_eval); 0: the disc itself implies r < eps R
         pr.aD = (real)(a / D);
         pr.cph0 = (real)r.cph0; pr.sph0 = (real)r.sph0;
         for (int c = 0; c < 4; ++c) pr.w[c] = (real)wv[c < NC ? c : 0];

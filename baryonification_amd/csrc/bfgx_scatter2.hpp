@@ -233,9 +233,11 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     }
     ok = ok && PM::finite(d) && d != (real)0;                      // :323
     o.ok_nocut = ok;
-    const bool cutting = ph.cut2 < PM::kHuge;                      // BaryonCorrection.py:381-382
-    o.ok = ok && (!cutting || u2 < ph.cut2);
-    if (sizeof(real) == 4) o.amb = ok && cutting && fabsf((float)(u2 - ph.cut2)) <= 4e-6f * (float)ph.cut2;
+    // BaryonCorrection.py:381-382: r < eps R  <=>  t = |u|^2 / cut^2 - 1 < 0.  The pair record carries 1 / cut^2 (0 when the disc itself
+    // implies r < eps R: t = -1, always inside, never ambiguous); the fp32 decision is re-made in fp64 where |t| <= 4e-6
+    const real tc = fma_(u2, ph.cut2, (real)-1);
+    o.ok = ok && (tc < (real)0);
+    if (sizeof(real) == 4) o.amb = ok && (fabsf((float)tc) <= 4e-6f);
     // offset / D = d a diff / (r_sep D) = (d a / D) u / |u|; renormalised (v + e)/|v + e| - v (:326-328) as a
     // series in t = 2 v.e + e.e (|v| = 1): e + g (v + e), g = -t/2 + 3 t^2/8 - 5 t^3/16 + 35 t^4/128
     const real sc = d * ph.aD * rinv;                              // e = sc u
