@@ -18,6 +18,7 @@
 // axis of the cutout with the "y" coordinate x[i] + dy and the second with x[j] + dx while the first axis is
 // indexed around x_cen; linspace(-N/2, N/2, N) * res spaces the cutout samples by N/(N-1) pixels.
 #pragma once
+#include <cstddef>
 #include "bfgx_kernels.hpp"
 
 namespace bfgx {
@@ -50,14 +51,17 @@ struct GridHaloRec {
     double rcut;                      // MODE 0: eps_model * R_model (comoving); MODE 1: eps_runner * R_j (comoving)
     double lnoff;                     // added to ln r: -ln R_model when the table is Rdelta-sampled, else 0
     double rmat[4];
-    double w[kNCmax];
-    int32_t rowoff[kNCmax];
     int32_t cen[3];                   // x_cen, y_cen, z_cen = centre pixel along cutout axes i, j, k
     int32_t nsize;                    // 0: halo skipped
     int32_t lo[3], n[3];              // bounding box of the contributing cutout indices
     int32_t oob, ell;
     int32_t chunk0, nchunks;
+    // the (z, M[, property]) corner rows LAST: a kernel that stages records in LDS copies the head and the NC corners a table has
+    // (4 for a 3-axis table), not all kNCmax
+    double w[kNCmax];
+    int32_t rowoff[kNCmax];
 };
+static_assert(offsetof(GridHaloRec, w) % 8 == 0 && offsetof(GridHaloRec, rowoff) == offsetof(GridHaloRec, w) + 8 * kNCmax, "GridHaloRec layout");
 
 // np.argmin(np.abs(bins - x)) for strictly ascending bins (first index attaining the minimum)
 __device__ inline int nearest_bin(const double *__restrict__ b, int n, double x)

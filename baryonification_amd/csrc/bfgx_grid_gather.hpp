@@ -133,8 +133,11 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
     for (int base = s0; base < s1; base += kGatherBatch) {
         const int nb = min(kGatherBatch, s1 - base);
         __syncthreads();
-        for (int t = tid; t < nb * kRecWords; t += 256) {
-            const int h = t / kRecWords, w = t - h * kRecWords;
+        // head of the record + the NC corner weights and row offsets this table has (not all kNCmax: 50 of 86 words for NC = 4)
+        constexpr int kHead = (int)(offsetof(GridHaloRec, w) / 4), kUsed = kHead + 3 * NC;
+        for (int t = tid; t < nb * kUsed; t += 256) {
+            const int h = t / kUsed, k = t - h * kUsed;
+            const int w = (k < kHead + 2 * NC) ? k : k + 2 * (kNCmax - NC);
             reinterpret_cast<int32_t *>(&R[h])[w] = reinterpret_cast<const int32_t *>(recs + blk_list[base + h])[w];
         }
         __syncthreads();
