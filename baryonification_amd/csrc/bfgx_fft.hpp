@@ -95,25 +95,97 @@ struct PkBins {
     int nk, b0;
     double *pk_sum, *k_sum;
     unsigned long long *counts;
+    const uint8_t *tab;           // BIN = 2: the k-bin of every mode in the order the last pass reads it, 255 = outside the bins
+    int tab_pitch;
 };
+
+// the k-bin of mode (a, b, c): k = sqrt(klin[a]^2 + klin[c]^2 + klin[b]^2) (the notebook's summation order), bin = floor((k - kb0) / dk);
+// -1 outside [0, nk)
+__device__ inline int pk_bin_of(const PkBins &pb, int a, int b, int c, double &k)
+{
+    const double ka = pb.klin[a], kb = pb.klin[b], kc = pb.klin[c];
+    k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
+    // floor((k - kb0) / dk): the quotient through the reciprocal, the division itself only where that could change the floor
+    const double ue = (k - pb.kb0) * pb.inv_dk;
+    double u = floor(ue);
+    if (fabs(ue - rint(ue)) < 1e-6 * (fabs(ue) + 1.0)) u = floor((k - pb.kb0) / pb.dk);
+    if (!(u >= 0.0) || !(u < (double)pb.nk)) return -1;
+    return (int)u;
+}
 
 // one |F|^2 sample into the LDS histogram: k = sqrt(klin[a]^2 + klin[c]^2 + klin[b]^2) (the notebook's summation order),
 // bin = floor((k - kb0) / dk); the c-mirrored half of the spectrum counts through a weight of 2
 __device__ inline void pk_bin_sample(const PkBins &pb, int N, int a, int b, int c, double2 f, double *hp, double *hk, unsigned long long *hc)
 {
-    const double ka = pb.klin[a], kb = pb.klin[b], kc = pb.klin[c];
-    const double k = sqrt(add_nc(add_nc(mul_nc(ka, ka), mul_nc(kc, kc)), mul_nc(kb, kb)));
-    // floor((k - kb0) / dk): the quotient through the reciprocal, the division itself only where that could change the floor
-    const double ue = (k - pb.kb0) * pb.inv_dk;
-    double u = floor(ue);
-    if (fabs(ue - rint(ue)) < 1e-6 * (fabs(ue) + 1.0)) u = floor((k - pb.kb0) / pb.dk);
-    if (!(u >= 0.0) || !(u < (double)pb.nk)) return;
-    const int bin = (int)u;
+    double k;
+    const int bin = pk_bin_of(pb, a, b, c, k);
+    if (bin < 0) return;
     const double p = f.x * f.x + f.y * f.y;
     const int mult = (c > 0 && c < (N >> 1)) ? 2 : 1;
     atomicAdd(hp + bin, mult * p);
     atomicAdd(hk + bin, mult * k);
     atomicAdd(hc + bin, (unsigned long long)mult);
+}
+
+// Which bin a mode falls into, how many modes a bin holds and the sum of their |k| depend on (N, L, nk) alone, not on the map: they are
+// tabulated once per configuration (like the twiddles) -- the bin of every mode as one byte [b][a][c] and, per column b of the middle
+// axis, the bins' counts and |k| sums (a slab rank adds up the columns it owns) -- so that the last pass of a power spectrum only
+// looks the bin up and adds |F|^2 (no sqrt, no floor, one LDS atomic per mode instead of three).  One workgroup per b.
+__global__ void __launch_bounds__(kFftBlock)
+pk_table_build_kernel(PkBins pb, int N, int nz, int lt, int nzt, uint8_t *__restrict__ tab, double *__restrict__ ksum_b,
+                      unsigned long long *__restrict__ cnt_b)
+{
+    // layout = the order in which the last pass reads it: [b][kz tile][i][l], i the (permuted) row slot of the tile: a wave's 64 look-ups
+    // are 64 consecutive bytes
+    extern __shared__ double2 fbuf[];
+    double *hk = reinterpret_cast<double *>(fbuf);
+    unsigned long long *hc = reinterpret_cast<unsigned long long *>(hk + pb.nk);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < pb.nk; i += kFftBlock) { hk[i] = 0.0; hc[i] = 0ull; }
+    __syncthreads();
+    const int per_tile = N << lt;
+    for (int t = threadIdx.x; t < nzt * per_tile; t += kFftBlock) {
+        const int kzt = t / per_tile, r = t - kzt * per_tile;
+        const int l = r & ((1 << lt) - 1), i = r >> lt;
+        const int a = (i * 37) & (N - 1), c = (kzt << lt) + l;
+        int bin = -1;
+        if (c < nz) {
+            double k;
+            bin = pk_bin_of(pb, a, b, c, k);
+            if (bin >= 0) {
+                const int mult = (c > 0 && c < (N >> 1)) ? 2 : 1;
+                atomicAdd(hk + bin, mult * k);
+                atomicAdd(hc + bin, (unsigned long long)mult);
+            }
+        }
+        tab[((size_t)b * nzt + kzt) * per_tile + r] = (bin < 0) ? (uint8_t)255 : (uint8_t)bin;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pb.nk; i += kFftBlock) { ksum_b[(size_t)b * pb.nk + i] = hk[i]; cnt_b[(size_t)b * pb.nk + i] = hc[i]; }
+}
+
+// k_sum[bin] += sum over the columns [b0, b0 + nb) of ksum_b, counts likewise (the tabulated part of a power spectrum's sums): one
+// workgroup per bin, its threads over the columns
+__global__ void __launch_bounds__(256)
+pk_table_sums_kernel(int nk, int b0, int nb, const double *__restrict__ ksum_b, const unsigned long long *__restrict__ cnt_b,
+                     double *__restrict__ k_sum, unsigned long long *__restrict__ counts)
+{
+    __shared__ double sk[256 / kWave];
+    __shared__ unsigned long long sc[256 / kWave];
+    const int i = blockIdx.x;
+    double ks = 0.0;
+    unsigned long long cs = 0ull;
+    for (int b = b0 + threadIdx.x; b < b0 + nb; b += 256) { ks += ksum_b[(size_t)b * nk + i]; cs += cnt_b[(size_t)b * nk + i]; }
+#pragma unroll
+    for (int s = kWave >> 1; s > 0; s >>= 1) { ks += __shfl_down(ks, s, kWave); cs += __shfl_down(cs, s, kWave); }
+    if ((threadIdx.x & (kWave - 1)) == 0) { sk[threadIdx.x / kWave] = ks; sc[threadIdx.x / kWave] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tk = 0.0;
+        unsigned long long tc = 0ull;
+        for (int w = 0; w < 256 / kWave; ++w) { tk += sk[w]; tc += sc[w]; }
+        k_sum[i] += tk; counts[i] += tc;
+    }
 }
 
 // passes 2 and 3: complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
@@ -169,7 +241,8 @@ __device__ inline void lds_fft_stages_t(double2 *buf, int N, const double2 *tw)
 // LDS of one workgroup of the strided passes: the tile, the twiddles, (BIN) the histogram
 __host__ __device__ inline size_t fft_c2c_lds_bytes(int N, int lt, int nk) { return sizeof(double2) * (((size_t)N << lt) + (size_t)(N >> 1)) + sizeof(double) * 3 * (size_t)nk; }
 
-template <bool BIN, int LT>
+// BIN: 0 = in place; 1 = binned from LDS, bins computed per mode; 2 = binned from LDS, bins from the table (PkBins::tab)
+template <int BIN, int LT>
 __global__ void __launch_bounds__(kFftBlock)
 fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
                        const double2 *__restrict__ tw, int nzt, int nouter, PkBins pb)
@@ -201,14 +274,23 @@ fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int
                 // neighbouring lanes take rows 37 apart (an odd multiplier permutes the rows): rows next to each other have
                 // almost the same |k| and would serialise on one histogram cell
                 const int a = (i * 37) & (N - 1);
-                if (kz0 + l < nz) pk_bin_sample(pb, N, a, pb.b0 + o, kz0 + l, fbuf[(a << LT) + l], hp, hk, hc);
+                if (BIN == 2) {
+                    const int bin = pb.tab[(((size_t)(pb.b0 + o) * nzt + (kz0 >> LT)) * N << LT) + t];  // (pad columns carry 255)
+                    if (bin != 255) {
+                        const double2 f = fbuf[(a << LT) + l];
+                        const int c = kz0 + l;
+                        atomicAdd(hp + bin, ((c > 0 && c < (N >> 1)) ? 2.0 : 1.0) * (f.x * f.x + f.y * f.y));
+                    }
+                } else if (kz0 + l < nz) pk_bin_sample(pb, N, a, pb.b0 + o, kz0 + l, fbuf[(a << LT) + l], hp, hk, hc);
             } else base[(int64_t)i * stride + l] = fbuf[t];
         }
     }
     if (BIN) {
         __syncthreads();
-        for (int i = threadIdx.x; i < pb.nk; i += kFftBlock)
-            if (hc[i]) { atomicAdd(pb.pk_sum + i, hp[i]); atomicAdd(pb.k_sum + i, hk[i]); atomicAdd(pb.counts + i, hc[i]); }
+        for (int i = threadIdx.x; i < pb.nk; i += kFftBlock) {
+            if (BIN == 2) { if (hp[i] != 0.0) atomicAdd(pb.pk_sum + i, hp[i]); }
+            else if (hc[i]) { atomicAdd(pb.pk_sum + i, hp[i]); atomicAdd(pb.k_sum + i, hk[i]); atomicAdd(pb.counts + i, hc[i]); }
+        }
     }
 }
 
