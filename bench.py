@@ -670,8 +670,12 @@ def shell_line(args, ctx, scaling, brief):
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        t_enq = time.perf_counter() - t0
         fence()
         el = time.perf_counter() - t0
+        if os.environ.get('BFGX_BENCH_ENQUEUE_TIME') == '1' and rank == 0:        # how much of a step is host-side enqueue time
+            print("bench: %d steps enqueued in %.3f ms per step, done in %.3f ms per step" % (steps, t_enq / steps * 1e3, el / steps * 1e3),
+                  file=sys.stderr, flush=True)
         kt = tp.timing_read() if events else None
         tp.timing_enable(False)
         if world > 1:
