@@ -28,6 +28,8 @@ kernel on the launch stream (bfgx_plan_timing_*) for `kernel_ms` and `roofline` 
 `ms_per_step_with_kernel_events` shows what the events cost).  At N = 1 the line also carries `value_acc_f64` (the same
 step in fp64 throughout), `end_to_end` (the drop-in BaryonifyShell.process() from numpy arrays, PCIe-inclusive) and
 `cpu_baseline` (the CPU oracle -- oracle/, the checker, never the product -- on the box's host cores).
+Diagnostics (stderr, never in `value`): BFGX_BENCH_STAGE_TIMES=1 adds one untimed, stage-by-stage synchronised step of the N > 1 path and
+prints its stage times; BFGX_BENCH_ENQUEUE_TIME=1 prints how much of a step is host-side enqueue time.
 """
 import argparse
 import json
@@ -533,6 +535,15 @@ def shell_line(args, ctx, scaling, brief):
         cols_local = [t[k] for k in ('M', 'z', 'ra', 'dec', 'lnz', 'lnM')]
         route_work = {}
         sp_state = {'fixed': True, 'reach_known': False, 'nd': None, 'cd': None}
+        stage_t = {}
+
+        def mark(name):
+            """BFGX_BENCH_STAGE_TIMES=1: one extra, untimed step with a synchronisation after every stage (rank 0 prints the stage times)"""
+            if sp_state.get('staging'):
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                stage_t[name] = stage_t.get(name, 0.0) + (now - sp_state['t_last']) * 1e3
+                sp_state['t_last'] = now
 
     def run_steps(acc_f64):
         """returns a closure doing one full pass of the hot path with the given accumulator type"""
@@ -558,6 +569,7 @@ def shell_line(args, ctx, scaling, brief):
 
         def step_spatial():
             plan_sp.disc_rings(cat_dev, d_rings.data_ptr())
+            mark('disc_rings')
             if sp_state['fixed']:
                 got, _ = route_halos_fixed(cols_local, d_rings, rb, blockcap, plan=plan_sp, work=route_work)   # [6][world * blockcap], NaN-padded
                 if sp_state['cd'] is None:                     # (the receive buffers are reused: the descriptor is built once)
@@ -570,10 +582,13 @@ def shell_line(args, ctx, scaling, brief):
                 assert n <= cap, "rank %d received %d halos, more than the plan holds (%d): a strongly clustered sky" % (rank, n, cap)
                 cd = _lib.make_catalog_dev(n, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
                                            ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
+            mark('route')
             b0, b1 = int(cuts[rank]), int(cuts[rank + 1])
             if paint:
                 plan_sp.paint_bands(cd, b0, b1, d_slice.data_ptr(), acc_f64=(1 if acc_f64 else 2))
+                mark('K0+K3')
                 gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
+                mark('gather')
                 return
             # once the reach is known the slice is computed in place inside the buffer that also holds the apron rings
             if sp_state['reach_known']:
@@ -584,6 +599,7 @@ def shell_line(args, ctx, scaling, brief):
             else:
                 my_off = d_off[:(p1 - p0) * 3]
             plan_sp.offsets_bands(cd, b0, b1, my_off.data_ptr(), acc_f64=acc_f64)
+            mark('K0+K1')
             if not sp_state['reach_known']:
                 # the reach of the gathering regrid (rings of apron every rank exchanges and gathers from) is agreed ONCE, in the untimed
                 # trial step: all_reduce(MAX) of the largest |offset| (K1's per-tile maxima) + one read-back.  The timed steps reuse it:
@@ -595,8 +611,10 @@ def shell_line(args, ctx, scaling, brief):
                 sp_state['reach_known'] = True
             nd = sp_state['nd']
             off_apron = halo_exchange(my_off, pb, nd, 3, full=sp_state.get('full') if my_off.data_ptr() != d_off.data_ptr() else None)
+            mark('apron exchange')
             plan_sp.regrid_bands(b0, b1, d_map.data_ptr(), off_apron.data_ptr(), nd[rank][0], nd[rank][1], d_slice.data_ptr(), d_sums.data_ptr(),
                                  acc_f64=acc_f64)
+            mark('K2')
             if route_far[0]:
                 fp, fv = plan_sp.far_fetch()
                 lists = [None] * world
@@ -607,7 +625,9 @@ def shell_line(args, ctx, scaling, brief):
                         d_slice.index_add_(0, torch.from_numpy(qp[m] - p0).to(dev), torch.from_numpy(qv[m]).to(dev))
             else:
                 plan_sp.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
+            mark('far')
             gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
+            mark('gather')
 
         def step():
             if spatial:
@@ -726,6 +746,13 @@ def shell_line(args, ctx, scaling, brief):
     elapsed, _ = timed(step, args.steps, False)
     # the same K steps again with HIP events around every kernel on the launch stream (bfgx_plan_timing_*): kernel_ms, roofline
     elapsed_ev, kt = timed(step, args.steps, True) if not (args.no_kernel_events or brief) else (None, None)
+    if spatial and os.environ.get('BFGX_BENCH_STAGE_TIMES') == '1':
+        fence()
+        sp_state['staging'], sp_state['t_last'] = True, time.perf_counter()
+        step()
+        sp_state['staging'] = False
+        if rank == 0:
+            print("bench: stage times of one synchronised step [ms]: %s" % json.dumps({k: round(v, 3) for k, v in stage_t.items()}), file=sys.stderr, flush=True)
     if os.environ.get('BFGX_BENCH_NOSTATUS') != '1':   # (timing-only ablation builds produce meaningless offsets)
         (plan_sp if spatial else plan).status()   # entry-list capacity, far-deposit list
     if (slices or spatial) and not paint:
