@@ -757,6 +757,31 @@ def shell_line(args, ctx, scaling, brief):
         (plan_sp if spatial else plan).status()   # entry-list capacity, far-deposit list
     if (slices or spatial) and not paint:
         assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
+    check = None
+    if os.environ.get('BFGX_BENCH_CHECK') == '1' and strong and (slices or spatial) and rank == 0:
+        # self-check (tests): the map the ranks assembled on rank 0 against ONE single-GPU pass over the whole catalog (fp32 pair math
+        # on both sides: they agree to the stated fp32 tolerance, most pixels exactly)
+        full = syn.make_catalog(total_halos)
+        tf = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in full.items()}
+        lz, lm = _lib.table_coords(full['M'], full['z'])
+        tf['lnz'], tf['lnM'] = torch.from_numpy(lz).to(dev), torch.from_numpy(lm).to(dev)
+        pf = engine.ShellPlan(model, keep, nside, total_halos, device=local_rank, stream=stream)
+        cdf = _lib.make_catalog_dev(total_halos, tf['M'].data_ptr(), tf['z'].data_ptr(), tf['ra'].data_ptr(), tf['dec'].data_ptr(),
+                                    ln1pz_ptr=tf['lnz'].data_ptr(), lnM_ptr=tf['lnM'].data_ptr())
+        ref = torch.zeros(npix, dtype=torch.float64, device=dev)
+        if paint:
+            pf.paint(cdf, ref.data_ptr(), acc_f64=(1 if args.acc_f64 else 2))
+        else:
+            woff = torch.zeros(npix * 3, dtype=torch.float64 if args.acc_f64 else torch.float32, device=dev)
+            pf.baryonify(cdf, d_map.data_ptr(), woff.data_ptr(), ref.data_ptr(), 0, acc_f64=args.acc_f64)
+        torch.cuda.synchronize()
+        pf.status()
+        got = d_fin if (slices or spatial) else d_out
+        scale = float(ref.abs().max().item()) if paint else float(ref.mean().item())
+        check = {"max_abs_diff_vs_single_gpu": float((got - ref).abs().max().item()), "scale": scale,
+                 "scale_is": "max |map|" if paint else "mean(map)"}
+        pf.close()
+        del tf, ref
 
     extra = {}
     if world == 1 and paint and not args.acc_f64 and args.algo == 1 and not args.no_extras and not brief:
@@ -826,6 +851,8 @@ def shell_line(args, ctx, scaling, brief):
             out["kernel_ms"] = kernels
             out["roofline"] = roofline(args, kernels, n_pairs, nh, npix, paint)
         out.update(extra)
+        if check is not None:
+            out["check"] = check
         if world == 1 and not args.no_cpu_baseline and not paint and not brief:
             out["cpu_baseline"] = cpu_baseline(args, cat, hmap, axes, table)
     plan.close()

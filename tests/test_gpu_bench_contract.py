@@ -62,7 +62,7 @@ def test_paint_and_grid_lines_small(gpu):
 def test_two_ranks_self_launched_strong_and_weak(gpu):
     """`python bench.py --gpus 2` as the driver types it (no launcher): the ranks are started as a child torch.distributed.run; both share
     device 0 over gloo (a one-GPU box), the product's HIP kernels + every exchange step of the spatial sharding run for real"""
-    env = dict(os.environ, BFGX_DIST_BACKEND='gloo')
+    env = dict(os.environ, BFGX_DIST_BACKEND='gloo', BFGX_BENCH_CHECK='1')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--halos', '20001', '--nside', '128', '--steps', '3',
                           '--warmup', '1'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -73,3 +73,7 @@ def test_two_ranks_self_launched_strong_and_weak(gpu):
     assert d['scaling'] == 'strong' and d['mass_conserved'] is True and d['config']['halos_per_gpu'] == 10001      # (shards that differ by one halo: every rank must still use the same routing block size)
     w = d['value_weak']
     assert w['scaling'] == 'weak' and w['value'] > 0 and w['mass_conserved'] is True
+    # the map the two ranks assembled (fixed-capacity routing with NaN-padded rows, band-restricted K0 + K1, apron exchange, banded
+    # regrid, gather) == one single-GPU pass over the whole catalog, to the stated fp32 tolerance
+    c = d['check']
+    assert c['max_abs_diff_vs_single_gpu'] <= 2e-6 * c['scale'], c
