@@ -27,7 +27,10 @@ namespace bfgx {
 #define BFGX_ABL2 0               // >0: timing-only ablation builds (scripts/ablate2.sh); never shipped
 #endif
 constexpr int kW2 = 8;            // waves per workgroup
-constexpr int kChunk2 = 16;       // entries a wave takes at a time
+#ifndef BFGX_CHUNK2
+#define BFGX_CHUNK2 16
+#endif
+constexpr int kChunk2 = BFGX_CHUNK2;   // entries a wave takes at a time (8 / 12 / 20 measured: 0.486 / 0.466 / see DESIGN section 4)
 constexpr int kPlanePad = 11;     // doubles between accumulator planes: plane stride = 22 banks mod 64 (conflict-free flush)
 
 // ---------------------------------------------------------------------------------- pair-phase math per precision
