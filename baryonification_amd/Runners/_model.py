@@ -106,7 +106,7 @@ def build_model(runner, kind, runner_cosmo=None):
         if not hasattr(model, 'raw_input_d'):
             if hasattr(model, 'setup_interpolator'):          # a Baryonification2D/3D that was never set up: as the reference's displacement()
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            if callable(getattr(model, 'displacement', None)):
+            if callable(getattr(model, 'displacement', None)) and hasattr(runner, 'HaloLightConeCatalog'):      # (shell runners)
                 return build_model(_Proxy(runner, tabulate_callable(runner, kind)), kind, runner_cosmo)
             raise TypeError("BaryonifyShell needs a model with a displacement(r, M, a) method or a displacement table "
                             "(Baryonification2D/3D)")
@@ -119,7 +119,7 @@ def build_model(runner, kind, runner_cosmo=None):
         if not hasattr(model, attr):
             if hasattr(model, 'setup_interpolator'):
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            if kind == 'projected' and callable(getattr(model, 'projected', None)):
+            if kind == 'projected' and callable(getattr(model, 'projected', None)) and hasattr(runner, 'HaloLightConeCatalog'):
                 return build_model(_Proxy(runner, tabulate_callable(runner, kind)), kind, runner_cosmo)
             raise TypeError("painting needs a profile with a projected(cosmo, r, M, a) method or a tabulated profile "
                             "(TabulatedProfile / ParamTabulatedProfile)")
