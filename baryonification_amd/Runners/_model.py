@@ -25,20 +25,21 @@ BRIDGE_N_Z, BRIDGE_N_M, BRIDGE_N_R, BRIDGE_R_MIN, BRIDGE_R_MAX = 10, 20, 500, 1e
 
 def _support(runner):
     """(z_min, z_max, M_min, M_max) of the runner's catalog, opened by 1e-6 relative so that no halo sits on a table edge"""
-    cat = runner.HaloLightConeCatalog.cat if hasattr(runner, 'HaloLightConeCatalog') else runner.HaloNDCatalog.cat
+    shell = hasattr(runner, 'HaloLightConeCatalog')
+    cat = runner.HaloLightConeCatalog.cat if shell else runner.HaloNDCatalog.cat
     M = np.asarray(cat['M'], dtype=np.float64)
-    if 'z' in cat.dtype.names:
+    if shell:                                             # (an ND catalog's 'z' column is a position)
         z = np.asarray(cat['z'], dtype=np.float64)
         z0, z1 = float(z.min()), float(z.max())
-    else:
+    else:                                                 # a box at one redshift (GridRunner / SnapshotRunner): two slices around it
         z0 = z1 = float(runner.HaloNDCatalog.redshift)
-    z0, z1 = max(z0 * (1 - 1e-6) - 1e-9, 0.0), z1 * (1 + 1e-6) + 1e-9
+    z0, z1 = max(z0 * (1 - 1e-6) - 1e-6, 0.0), z1 * (1 + 1e-6) + 1e-6
     return z0, z1, float(M.min()) * (1 - 1e-6), float(M.max()) * (1 + 1e-6)
 
 
 def tabulate_callable(runner, kind):
-    """The reference's runners call `model.displacement(r, M, a)` / `model.projected(cosmo, r, M, a)` once per halo on ANY object
-    (HealpixRunner.py:321, :441).  A model that carries no table (no raw_input_*) and cannot build one itself (no
+    """The reference's runners call `model.displacement(r, M, a)` / `model.projected(cosmo, r, M, a)` / `model.real(cosmo, r, M, a)`
+    once per halo on ANY object (HealpixRunner.py:321, :441; Map2DRunner.py:534, :752, :781; SnapshotRunner.py:228).  A model that carries no table (no raw_input_*) and cannot build one itself (no
     setup_interpolator) is tabulated here, once, on the (z, M) support of the runner's catalog -- BRIDGE_N_Z x BRIDGE_N_M x
     BRIDGE_N_R samples, z linear, M and r logarithmic -- and the table holder is cached on the model (`_bfgx_tabulated`), keyed by
     the support.  Returns the holder (a Baryonification2D / TabulatedProfile of this package)."""
@@ -53,7 +54,7 @@ def tabulate_callable(runner, kind):
     from ..utils.cosmology import Cosmology, cosmo_to_dict
     cosmo = getattr(model, 'cosmo', None) or runner.cosmo
     cosmo_obj = cosmo if isinstance(cosmo, Cosmology) else Cosmology.from_dict(cosmo_to_dict(cosmo))
-    z = np.linspace(z0, z1, BRIDGE_N_Z) if z1 > z0 else np.array([z0, z0 + 1e-6])
+    z = np.linspace(z0, z1, BRIDGE_N_Z if hasattr(runner, 'HaloLightConeCatalog') else 2)
     Mg = np.geomspace(M0, M1, BRIDGE_N_M)
     r = np.geomspace(BRIDGE_R_MIN, BRIDGE_R_MAX, BRIDGE_N_R)
     if kind == 'displacement':
@@ -69,13 +70,14 @@ def tabulate_callable(runner, kind):
         # the runner paints model.projected(cosmo, r_sep / a, M, a) as it comes (HealpixRunner.py:441): no factor of `a` here (the
         # reference's TabulatedProfile multiplies its OWN table by a, Tabulate.py:226 -- a raw profile is painted without it)
         t2 = np.zeros((z.size, Mg.size, r.size))
+        profile = model.projected if kind == 'projected' else model.real
         for i, zi in enumerate(z):
             a = 1.0 / (1.0 + zi)
             try:
-                row = np.asarray(model.projected(cosmo_obj, r, Mg, a), dtype=np.float64)
+                row = np.asarray(profile(cosmo_obj, r, Mg, a), dtype=np.float64)
                 assert row.shape == (Mg.size, r.size)
             except Exception:        # noqa: BLE001  a profile that takes scalar masses only
-                row = np.stack([np.asarray(model.projected(cosmo_obj, r, Mj, a), dtype=np.float64).reshape(r.size) for Mj in Mg])
+                row = np.stack([np.asarray(profile(cosmo_obj, r, Mj, a), dtype=np.float64).reshape(r.size) for Mj in Mg])
             t2[i] = row
         holder = TabulatedProfile(None, cosmo_obj, mass_def=getattr(model, 'mass_def', None))
         holder.set_table(z, Mg, r, t2)
@@ -106,7 +108,7 @@ def build_model(runner, kind, runner_cosmo=None):
         if not hasattr(model, 'raw_input_d'):
             if hasattr(model, 'setup_interpolator'):          # a Baryonification2D/3D that was never set up: as the reference's displacement()
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            if callable(getattr(model, 'displacement', None)) and hasattr(runner, 'HaloLightConeCatalog'):      # (shell runners)
+            if callable(getattr(model, 'displacement', None)):
                 return build_model(_Proxy(runner, tabulate_callable(runner, kind)), kind, runner_cosmo)
             raise TypeError("BaryonifyShell needs a model with a displacement(r, M, a) method or a displacement table "
                             "(Baryonification2D/3D)")
@@ -119,9 +121,9 @@ def build_model(runner, kind, runner_cosmo=None):
         if not hasattr(model, attr):
             if hasattr(model, 'setup_interpolator'):
                 raise NameError("No Table created. Run setup_interpolator() method first")
-            if kind == 'projected' and callable(getattr(model, 'projected', None)) and hasattr(runner, 'HaloLightConeCatalog'):
+            if callable(getattr(model, kind, None)):
                 return build_model(_Proxy(runner, tabulate_callable(runner, kind)), kind, runner_cosmo)
-            raise TypeError("painting needs a profile with a projected(cosmo, r, M, a) method or a tabulated profile "
+            raise TypeError("painting needs a profile with a projected / real (cosmo, r, M, a) method or a tabulated profile "
                             "(TabulatedProfile / ParamTabulatedProfile)")
         with np.errstate(divide='ignore', invalid='ignore'):
             values = np.log(np.asarray(getattr(model, attr), dtype=np.float64))   # Tabulate.py:237-238, :560-561

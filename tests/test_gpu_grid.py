@@ -604,3 +604,95 @@ def test_particle_routing_kernels(gpu, world, ncols):
         blk = got[:, start[d]:start[d] + c[d]]
         order_g, order_w = np.lexsort(blk[::-1]), np.lexsort(cols[:, sel][::-1])
         assert np.array_equal(blk[:, order_g], cols[:, sel][:, order_w])          # the same particles, column by column
+
+
+def test_callable_models_on_the_grid_and_snapshot_runners(gpu):
+    """Map2DRunner.py:534, :752, :781 and SnapshotRunner.py:228 call model.displacement / .projected / .real per halo on any object.
+    Plain-Python models go through BaryonifyGrid, PaintProfilesGrid (2D: projected, 3D: real) and BaryonifySnapshot: each is tabulated
+    once (two redshift slices around the box's own, the catalog's mass range) and the result equals the oracle fed that tabulation"""
+    import baryonification_amd as bfg
+    from baryonification_amd.Runners import _model as RM
+    from oracle import grid as G
+    from oracle import oracle as O
+    c = _big_case(2, 256, 900, 41)
+    cat, cos, zr = c['cat'], c['cosmo'], c['redshift']
+    bg = G.grid_background(cos)
+
+    class PlainDisplacement(object):
+        epsilon_max = 7.0
+        calls = 0
+
+        def displacement(self, r, M, a):
+            type(self).calls += 1
+            Rc = bg.get_radius(np.atleast_1d(M), a)[0] / a
+            x = np.asarray(r) / Rc
+            return np.where(x < self.epsilon_max, -0.08 * Rc * x * np.exp(-x) / (1 + x * x), 0.0)
+
+    class PlainProfile(object):
+        def _f(self, r, M, a, s):
+            Rc = bg.get_radius(np.atleast_1d(M), a) / a
+            x = np.asarray(r)[None, :] / Rc[:, None]
+            out = s * (np.atleast_1d(M)[:, None] / 1e14) * np.exp(-x) / (1 + x) ** 2
+            return out if np.ndim(M) else out[0]
+
+        def projected(self, cosmo, r, M, a):
+            return self._f(r, M, a, 1.0)
+
+        def real(self, cosmo, r, M, a):
+            return self._f(r, M, a, 3.0)
+
+    def table_of(holder, values, eps=None):
+        axes = [holder.raw_input_z_range, holder.raw_input_M_range, holder.raw_input_r_range]
+        if eps is not None:
+            return O.Table(axes, values, False, eps)
+        with np.errstate(divide='ignore'):
+            return O.Table(axes, np.log(values))
+
+    HCat2 = bfg.utils.HaloNDCatalog(x=cat['x'], y=cat['y'], z=None, M=cat['M'], redshift=zr, cosmo=cos)
+    GMap2 = bfg.utils.GriddedMap(map=c['map'], redshift=zr, bins=c['bins'], cosmo=cos)
+    model = PlainDisplacement()
+    runner = bfg.Runners.BaryonifyGrid(HCat2, GMap2, 5.0, model, verbose=False)
+    out = runner.process()
+    assert PlainDisplacement.calls == 2 * RM.BRIDGE_N_M
+    hold = model._bfgx_tabulated[1]
+    assert hold.raw_input_z_range[0] < np.log(1 + zr) < hold.raw_input_z_range[-1]
+    ora = G.regrid_offsets(c['map'], G.baryonify_grid_offsets(c['map'].shape, c['bins'], cat, zr, table_of(hold, hold.raw_input_d, 7.0), 5.0, bg))
+    assert np.abs(out - c['map']).max() > 0 and np.abs(out - ora).max() <= 1e-10 * np.abs(ora).max()
+    runner.process()
+    assert PlainDisplacement.calls == 2 * RM.BRIDGE_N_M                               # tabulated once
+
+    prof = PlainProfile()
+    zero2 = bfg.utils.GriddedMap(map=np.zeros_like(c['map']), redshift=zr, bins=c['bins'], cosmo=cos)
+    p2 = bfg.Runners.PaintProfilesGrid(HCat2, zero2, 4.0, prof, verbose=False).process()
+    hp2 = prof._bfgx_tabulated[1]
+    ora2 = G.paint_grid(c['map'].shape, c['bins'], cat, zr, table_of(hp2, hp2.raw_input_2D), 4.0, bg)
+    assert p2.max() > 0 and np.abs(p2 - ora2).max() <= 1e-10 * np.abs(ora2).max()
+
+    c3 = _big_case(3, 64, 400, 42)
+    cat3 = c3['cat']
+    HCat3 = bfg.utils.HaloNDCatalog(x=cat3['x'], y=cat3['y'], z=cat3['z'], M=cat3['M'], redshift=zr, cosmo=cos)
+    zero3 = bfg.utils.GriddedMap(map=np.zeros((64,) * 3), redshift=zr, bins=c3['bins'], cosmo=cos)
+    prof3 = PlainProfile()
+    p3 = bfg.Runners.PaintProfilesGrid(HCat3, zero3, 4.0, prof3, verbose=False).process()
+    hp3 = prof3._bfgx_tabulated[1]
+    ora3 = G.paint_grid((64,) * 3, c3['bins'], cat3, zr, table_of(hp3, hp3.raw_input_3D), 4.0, bg)
+    assert p3.max() > 0 and np.abs(p3 - ora3).max() <= 1e-10 * np.abs(ora3).max()
+    # the 3D table holds real(), not projected(): three times larger in this model
+    j = int(np.argmax(cat3['M']))
+    rr = np.geomspace(0.05, 3.0, 5)
+    assert np.abs(hp3.real(None, rr, cat3['M'][j], 1 / (1 + zr)) / prof3.real(None, rr, cat3['M'][j], 1 / (1 + zr)) - 1).max() < 2e-3
+
+    rng = np.random.default_rng(43)
+    L, npart = c3['L'], 60_000
+    part = rng.uniform(0, L, (npart, 3))
+    Snap = bfg.utils.ParticleSnapshot(x=part[:, 0], y=part[:, 1], z=part[:, 2], M=np.ones(npart), L=L, redshift=zr, cosmo=cos)
+    smodel = PlainDisplacement()
+    new = bfg.Runners.BaryonifySnapshot(HCat3, Snap, 5.0, smodel, verbose=False).process()
+    sh = smodel._bfgx_tabulated[1]
+    oras = G.baryonify_snapshot([part[:, k] for k in range(3)], L, cat3, zr, table_of(sh, sh.raw_input_d, 7.0), 5.0, bg)
+    got = np.stack([new[k] for k in 'xyz'], axis=1)
+    oras = np.stack(oras, axis=1)
+    scale = np.abs(oras - part).max()
+    assert scale > 1e-3 and np.abs(got - oras).max() <= max(1e-10 * scale, 1e-13 * L)
+    with pytest.raises(TypeError):
+        bfg.Runners.BaryonifyGrid(HCat2, GMap2, 5.0, object(), verbose=False).process()
