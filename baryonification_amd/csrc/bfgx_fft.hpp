@@ -6,9 +6,10 @@
 // Every 1-D transform runs in LDS: decimation in time, bit-reversed on the way in, two radix-2 stages fused per
 // barrier (radix-4 data movement), twiddles from a host-built fp64 table (copied to LDS in the strided passes); the r2c
 // pass packs two real lines into one complex transform.  Rows of the half spectrum are padded to whole 128-byte lines
-// (fft_pitch); the strided passes move tiles of 4 (or 8) lines that are adjacent in memory, so that global accesses stay
-// contiguous and LDS accesses conflict-free (line index fastest).  The LAST pass writes nothing back: the transformed tile is
-// binned from LDS (|F|^2, |k|, counts per linear k-bin), so the spectrum crosses HBM 5 times instead of 8.
+// (fft_pitch); the strided passes move tiles of 8 (or 4) lines that are adjacent in memory, so that global accesses are whole
+// 128-byte lines, do their first radix-4 pass on the way into LDS and their last pass on the way out (fft_c2c_strided_kernel).
+// The LAST strided pass writes nothing back: its results are binned as they leave the butterflies (|F|^2, |k|, counts per linear
+// k-bin), so the spectrum crosses HBM 5 times instead of 8.
 // N must be a power of two, 8 <= N <= 1024.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,7 +19,7 @@
 namespace bfgx {
 
 constexpr int kFftBlock = 256;
-constexpr int kFftTileLog2 = 2;       // 1 << this = lines per workgroup in the strided passes (BFGX_FFT_TILE = 4 | 8 overrides)
+constexpr int kFftTileLog2 = 3;       // 1 << this = lines per workgroup in the strided passes (BFGX_FFT_TILE = 4 | 8 overrides)
 
 __device__ inline int bit_reverse(int i, int log2n) { return (int)(__brev((unsigned)i) >> (32 - log2n)); }
 
@@ -135,8 +136,7 @@ __global__ void __launch_bounds__(kFftBlock)
 pk_table_build_kernel(PkBins pb, int N, int nz, int lt, int nzt, uint8_t *__restrict__ tab, double *__restrict__ ksum_b,
                       unsigned long long *__restrict__ cnt_b)
 {
-    // layout = the order in which the last pass reads it: [b][kz tile][i][l], i the (permuted) row slot of the tile: a wave's 64 look-ups
-    // are 64 consecutive bytes
+    // layout [b][kz tile][row a][line l]: the slice of a tile is contiguous (the last pass copies it into LDS with the tile)
     extern __shared__ double2 fbuf[];
     double *hk = reinterpret_cast<double *>(fbuf);
     unsigned long long *hc = reinterpret_cast<unsigned long long *>(hk + pb.nk);
@@ -147,7 +147,7 @@ pk_table_build_kernel(PkBins pb, int N, int nz, int lt, int nzt, uint8_t *__rest
     for (int t = threadIdx.x; t < nzt * per_tile; t += kFftBlock) {
         const int kzt = t / per_tile, r = t - kzt * per_tile;
         const int l = r & ((1 << lt) - 1), i = r >> lt;
-        const int a = (i * 37) & (N - 1), c = (kzt << lt) + l;
+        const int a = i, c = (kzt << lt) + l;
         int bin = -1;
         if (c < nz) {
             double k;
@@ -188,62 +188,36 @@ pk_table_sums_kernel(int nk, int b0, int nb, const double *__restrict__ ksum_b, 
     }
 }
 
-// passes 2 and 3: complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
-// data[o * outer_stride + i * stride + kz0 + l]; the workgroups stride over the nzt * nouter tiles (kz tile fastest).
-// BIN = false: in place.  BIN = true (last pass of the power spectrum): nothing is written back -- the transformed tile goes
-// straight from LDS into the workgroup's k-bin histogram (the spectrum itself is not an output), which is flushed once at the
-// end; the line index i is then the FIRST array axis and o the column b0 + o of the middle axis.
-// the butterflies of lds_fft_stages for a compile-time number of interleaved lines (1 << LT) and twiddles held in LDS: the index
-// arithmetic is shifts and masks (with a run-time line count it was three quarters of the strided passes' instructions)
-template <int LT>
-__device__ inline void lds_fft_stages_t(double2 *buf, int N, const double2 *tw)
+// LDS position of row p of a tile: the low two bits are XORed with the next two, so that the four rows p, p+1, p+2, p+3 of every
+// aligned group of 4 -- 64 or 128 bytes each, the chunks one wave instruction of the first pass writes at a stride of four rows --
+// fall into four different quarters of the banks; groups of 4 and of 16 consecutive rows (the later passes) stay permutations of themselves
+__device__ inline int fft_swz(int p) { return p ^ ((p >> 2) & 3); }
+
+// LDS of one workgroup of the strided passes: the tile, the twiddles, then the histogram (BIN 1: |F|^2, |k|, counts; BIN 2: |F|^2 and
+// the tile's slice of the bin table)
+__host__ __device__ inline size_t fft_c2c_lds_bytes(int N, int lt, int nk, int bin)
 {
-    constexpr int NL = 1 << LT;
-    int m = 1;
-    const int nq = (N >> 2) << LT;
-    for (; 4 * m <= N; m <<= 2) {
-        __syncthreads();
-        const int ts1 = (N >> 1) / m, ts2 = (N >> 2) / m;
-        for (int t = threadIdx.x; t < nq; t += kFftBlock) {
-            const int l = t & (NL - 1), b = t >> LT;
-            const int pos = b & (m - 1);
-            const int p = ((b - pos) << 2) + pos;
-            const double2 w1 = tw[pos * ts1], w2 = tw[pos * ts2];
-            const double2 w3 = make_double2(w2.y, -w2.x);
-            double2 *q = buf + (p << LT) + l;
-            const double2 a0 = q[0], a1 = q[m << LT], a2 = q[(2 * m) << LT], a3 = q[(3 * m) << LT];
-            const double2 t1 = cmul(w1, a1), t3 = cmul(w1, a3);
-            const double2 b0 = make_double2(a0.x + t1.x, a0.y + t1.y), b1 = make_double2(a0.x - t1.x, a0.y - t1.y);
-            const double2 b2 = make_double2(a2.x + t3.x, a2.y + t3.y), b3 = make_double2(a2.x - t3.x, a2.y - t3.y);
-            const double2 u2 = cmul(w2, b2), u3 = cmul(w3, b3);
-            q[0] = make_double2(b0.x + u2.x, b0.y + u2.y);
-            q[(2 * m) << LT] = make_double2(b0.x - u2.x, b0.y - u2.y);
-            q[m << LT] = make_double2(b1.x + u3.x, b1.y + u3.y);
-            q[(3 * m) << LT] = make_double2(b1.x - u3.x, b1.y - u3.y);
-        }
-    }
-    if (m < N) {
-        __syncthreads();
-        const int nb = (N >> 1) << LT;
-        const int tstep = (N >> 1) / m;
-        for (int t = threadIdx.x; t < nb; t += kFftBlock) {
-            const int l = t & (NL - 1), b = t >> LT;
-            const int pos = b & (m - 1);
-            double2 *q = buf + ((((b - pos) << 1) + pos) << LT) + l;
-            const double2 u = q[0], v = cmul(tw[pos * tstep], q[m << LT]);
-            q[0] = make_double2(u.x + v.x, u.y + v.y);
-            q[m << LT] = make_double2(u.x - v.x, u.y - v.y);
-        }
-    }
-    __syncthreads();
+    size_t a = sizeof(double2) * (((size_t)N << lt) + (size_t)(N >> 1));
+    if (bin == 1) a += sizeof(double) * 3 * (size_t)nk;
+    if (bin == 2) a += sizeof(double) * (size_t)nk + ((size_t)N << lt);
+    return a;
 }
 
-// LDS of one workgroup of the strided passes: the tile, the twiddles, (BIN) the histogram
-__host__ __device__ inline size_t fft_c2c_lds_bytes(int N, int lt, int nk) { return sizeof(double2) * (((size_t)N << lt) + (size_t)(N >> 1)) + sizeof(double) * 3 * (size_t)nk; }
-
-// BIN: 0 = in place; 1 = binned from LDS, bins computed per mode; 2 = binned from LDS, bins from the table (PkBins::tab)
-template <int BIN, int LT>
-__global__ void __launch_bounds__(kFftBlock)
+// passes 2 and 3: complex transforms along a strided axis.  Element i of line l of tile (o, kz0) sits at
+// data[o * outer_stride + i * stride + kz0 + l]; the workgroups stride over the nzt * nouter tiles (kz tile fastest).
+// Decimation in time over a tile of (1 << LT) adjacent lines held in LDS as buf[row][line]:
+//   * the FIRST radix-4 pass is done on the way in: a thread loads the rows j, j + N/2, j + N/4, j + 3N/4 (the bit-reversed positions
+//     4b .. 4b + 3, j = bitrev(b)), combines them in registers (the twiddles are 1 and -i) and writes the four results;
+//   * radix-4 passes (two radix-2 stages per barrier) in LDS for the middle bits;
+//   * the LAST pass (radix-2 when an odd number of bits is left, radix-4 otherwise) is done on the way out: its results go straight to
+//     memory (BIN 0) or into the k-bin histogram (BIN 1, 2) and never back to LDS.
+// N = 512: one write, three read+write passes and one read of the tile instead of one write, five read+write passes and one read,
+// and four barriers per tile instead of seven.
+// BIN: 0 = in place; 1 = binned, bins computed per mode; 2 = binned, bins from the table (PkBins::tab, [b][kz tile][row][line], whose
+// slice for the tile is fetched into LDS together with the tile).  Binned passes write nothing back: the spectrum itself is not an
+// output; the histogram is flushed once at the end; the line index is then the FIRST array axis and o the column b0 + o of the middle axis.
+template <int BIN, int LT, int NT>
+__global__ void __launch_bounds__(NT)
 fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
                        const double2 *__restrict__ tw, int nzt, int nouter, PkBins pb)
 {
@@ -254,40 +228,110 @@ fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int
     double2 *twl = fbuf + ((size_t)N << LT);
     double *hp = reinterpret_cast<double *>(twl + (N >> 1)), *hk = hp + pb.nk;
     unsigned long long *hc = reinterpret_cast<unsigned long long *>(hk + pb.nk);
-    for (int i = threadIdx.x; i < (N >> 1); i += kFftBlock) twl[i] = tw[i];
+    uint8_t *tb8 = reinterpret_cast<uint8_t *>(hp + pb.nk);           // (BIN 2; BIN 1 has hk there)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (N >> 1); i += NT) twl[i] = tw[i];
     if (BIN) {
-        for (int i = threadIdx.x; i < pb.nk; i += kFftBlock) { hp[i] = 0.0; hk[i] = 0.0; hc[i] = 0ull; }
+        for (int i = tid; i < pb.nk; i += NT) { hp[i] = 0.0; if (BIN == 1) { hk[i] = 0.0; hc[i] = 0ull; } }
     }
+    const int rem = log2n - 2;                                       // bits left after the first pass (N >= 8)
+    const int last_bits = (rem & 1) ? 1 : 2;
+    const int nmid = (rem - last_bits) >> 1;
+    const int nq = (N >> 2) << LT;
+    const int64_t qs = (int64_t)(N >> 2) * stride;
     const int64_t ntiles = (int64_t)nzt * nouter;
     for (int64_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int kz0 = (int)(tl % nzt) << LT, o = (int)(tl / nzt);
         double2 *base = data + (int64_t)o * outer_stride + kz0;
-        __syncthreads();                                             // (the previous tile's readers are done with fbuf)
-        for (int t = threadIdx.x; t < (N << LT); t += kFftBlock) {
-            const int l = t & (NL - 1), i = t >> LT;
-            fbuf[(bit_reverse(i, log2n) << LT) + l] = base[(int64_t)i * stride + l];
+        __syncthreads();                                             // (the previous tile's readers are done with fbuf and tb8)
+        if (BIN == 2) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(pb.tab + ((((size_t)(pb.b0 + o) * nzt + (kz0 >> LT)) * N) << LT));
+            for (int t = tid; t < (N << LT) / 4; t += NT) reinterpret_cast<uint32_t *>(tb8)[t] = src[t];
         }
-        lds_fft_stages_t<LT>(fbuf, N, twl);
-        for (int t = threadIdx.x; t < (N << LT); t += kFftBlock) {
-            const int l = t & (NL - 1), i = t >> LT;
-            if (BIN) {
-                // neighbouring lanes take rows 37 apart (an odd multiplier permutes the rows): rows next to each other have
+        // ---- in: four rows per thread, first radix-4 pass in registers
+        for (int t = tid; t < nq; t += NT) {
+            const int l = t & (NL - 1), b = t >> LT;
+            const double2 *src = base + (int64_t)bit_reverse(b, rem) * stride + l;
+            const double2 a0 = src[0], a2 = src[qs], a1 = src[2 * qs], a3 = src[3 * qs];
+            const double2 b0 = make_double2(a0.x + a1.x, a0.y + a1.y), b1 = make_double2(a0.x - a1.x, a0.y - a1.y);
+            const double2 b2 = make_double2(a2.x + a3.x, a2.y + a3.y), b3 = make_double2(a2.x - a3.x, a2.y - a3.y);
+            double2 *q = fbuf + ((4 * b) << LT) + l;
+            const int sw = b & 3;                                    // fft_swz(4 b + k) = 4 b + (k ^ (b & 3))
+            q[(0 ^ sw) << LT] = make_double2(b0.x + b2.x, b0.y + b2.y);
+            q[(2 ^ sw) << LT] = make_double2(b0.x - b2.x, b0.y - b2.y);
+            q[(1 ^ sw) << LT] = make_double2(b1.x + b3.y, b1.y - b3.x);           // b1 + (-i) b3
+            q[(3 ^ sw) << LT] = make_double2(b1.x - b3.y, b1.y + b3.x);
+        }
+        // ---- middle: radix-4 passes in LDS (half sizes m and 2m per barrier)
+        int m = 4;
+        for (int sgi = 0; sgi < nmid; ++sgi, m <<= 2) {
+            __syncthreads();
+            const int ts1 = (N >> 1) / m, ts2 = (N >> 2) / m;
+            for (int t = tid; t < nq; t += NT) {
+                const int l = t & (NL - 1), b = t >> LT;
+                const int pos = b & (m - 1);
+                const int p = ((b - pos) << 2) + pos;
+                const double2 w1 = twl[pos * ts1], w2 = twl[pos * ts2];
+                const double2 w3 = make_double2(w2.y, -w2.x);
+                double2 *q0 = fbuf + (fft_swz(p) << LT) + l, *q1 = fbuf + (fft_swz(p + m) << LT) + l;
+                double2 *q2 = fbuf + (fft_swz(p + 2 * m) << LT) + l, *q3 = fbuf + (fft_swz(p + 3 * m) << LT) + l;
+                const double2 a0 = *q0, a1 = *q1, a2 = *q2, a3 = *q3;
+                const double2 t1 = cmul(w1, a1), t3 = cmul(w1, a3);
+                const double2 b0 = make_double2(a0.x + t1.x, a0.y + t1.y), b1 = make_double2(a0.x - t1.x, a0.y - t1.y);
+                const double2 b2 = make_double2(a2.x + t3.x, a2.y + t3.y), b3 = make_double2(a2.x - t3.x, a2.y - t3.y);
+                const double2 u2 = cmul(w2, b2), u3 = cmul(w3, b3);
+                *q0 = make_double2(b0.x + u2.x, b0.y + u2.y);
+                *q2 = make_double2(b0.x - u2.x, b0.y - u2.y);
+                *q1 = make_double2(b1.x + u3.x, b1.y + u3.y);
+                *q3 = make_double2(b1.x - u3.x, b1.y - u3.y);
+            }
+        }
+        __syncthreads();
+        // ---- out: the last pass; row `row` of line l of the transform leaves through `emit`
+        auto emit = [&](int row, int l, double2 f) {
+            if (BIN == 0) base[(int64_t)row * stride + l] = f;
+            else if (BIN == 2) {
+                const int bin = tb8[(row << LT) + l];                              // (pad columns carry 255)
+                if (bin != 255) {
+                    const int cc = kz0 + l;
+                    atomicAdd(hp + bin, ((cc > 0 && cc < (N >> 1)) ? 2.0 : 1.0) * (f.x * f.x + f.y * f.y));
+                }
+            } else if (kz0 + l < nz) pk_bin_sample(pb, N, row, pb.b0 + o, kz0 + l, f, hp, hk, hc);
+        };
+        if (last_bits == 1) {
+            const int h = N >> 1;
+            for (int t = tid; t < (h << LT); t += NT) {
+                const int l = t & (NL - 1), i0 = t >> LT;
+                // binned: neighbouring lanes take rows 37 apart (an odd multiplier permutes the rows): rows next to each other have
                 // almost the same |k| and would serialise on one histogram cell
-                const int a = (i * 37) & (N - 1);
-                if (BIN == 2) {
-                    const int bin = pb.tab[(((size_t)(pb.b0 + o) * nzt + (kz0 >> LT)) * N << LT) + t];  // (pad columns carry 255)
-                    if (bin != 255) {
-                        const double2 f = fbuf[(a << LT) + l];
-                        const int c = kz0 + l;
-                        atomicAdd(hp + bin, ((c > 0 && c < (N >> 1)) ? 2.0 : 1.0) * (f.x * f.x + f.y * f.y));
-                    }
-                } else if (kz0 + l < nz) pk_bin_sample(pb, N, a, pb.b0 + o, kz0 + l, fbuf[(a << LT) + l], hp, hk, hc);
-            } else base[(int64_t)i * stride + l] = fbuf[t];
+                const int i = BIN ? ((i0 * 37) & (h - 1)) : i0;
+                const double2 u = fbuf[(fft_swz(i) << LT) + l], v = cmul(twl[i], fbuf[(fft_swz(i + h) << LT) + l]);
+                emit(i, l, make_double2(u.x + v.x, u.y + v.y));
+                emit(i + h, l, make_double2(u.x - v.x, u.y - v.y));
+            }
+        } else {
+            const int mq = N >> 2;
+            for (int t = tid; t < (mq << LT); t += NT) {
+                const int l = t & (NL - 1), b0_ = t >> LT;
+                const int p = BIN ? ((b0_ * 37) & (mq - 1)) : b0_;
+                const double2 w1 = twl[p * 2], w2 = twl[p];
+                const double2 w3 = make_double2(w2.y, -w2.x);
+                const double2 a0 = fbuf[(fft_swz(p) << LT) + l], a1 = fbuf[(fft_swz(p + mq) << LT) + l];
+                const double2 a2 = fbuf[(fft_swz(p + 2 * mq) << LT) + l], a3 = fbuf[(fft_swz(p + 3 * mq) << LT) + l];
+                const double2 t1 = cmul(w1, a1), t3 = cmul(w1, a3);
+                const double2 b0 = make_double2(a0.x + t1.x, a0.y + t1.y), b1 = make_double2(a0.x - t1.x, a0.y - t1.y);
+                const double2 b2 = make_double2(a2.x + t3.x, a2.y + t3.y), b3 = make_double2(a2.x - t3.x, a2.y - t3.y);
+                const double2 u2 = cmul(w2, b2), u3 = cmul(w3, b3);
+                emit(p, l, make_double2(b0.x + u2.x, b0.y + u2.y));
+                emit(p + 2 * mq, l, make_double2(b0.x - u2.x, b0.y - u2.y));
+                emit(p + mq, l, make_double2(b1.x + u3.x, b1.y + u3.y));
+                emit(p + 3 * mq, l, make_double2(b1.x - u3.x, b1.y - u3.y));
+            }
         }
     }
     if (BIN) {
         __syncthreads();
-        for (int i = threadIdx.x; i < pb.nk; i += kFftBlock) {
+        for (int i = tid; i < pb.nk; i += NT) {
             if (BIN == 2) { if (hp[i] != 0.0) atomicAdd(pb.pk_sum + i, hp[i]); }
             else if (hc[i]) { atomicAdd(pb.pk_sum + i, hp[i]); atomicAdd(pb.k_sum + i, hk[i]); atomicAdd(pb.counts + i, hc[i]); }
         }
