@@ -29,14 +29,14 @@ __device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x *
 // bit-reversed order).  Two radix-2 stages (half sizes m and 2m) are fused per barrier: a thread takes the four elements
 // p, p+m, p+2m, p+3m of a 4m-block, so every element crosses LDS once per TWO stages; a last single stage follows when
 // log2(N) is odd.  tw[k] = exp(-2 pi i k / N), k < N/2.
-__device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2 *__restrict__ tw)
+__device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2 *__restrict__ tw, int tid, int nthr)
 {
     int m = 1;
     const int nq = (N >> 2) * nl;
     for (; 4 * m <= N; m <<= 2) {
         __syncthreads();
         const int ts1 = (N >> 1) / m, ts2 = (N >> 2) / m;           // twiddle strides of the stages m and 2m
-        for (int t = threadIdx.x; t < nq; t += kFftBlock) {
+        for (int t = tid; t < nq; t += nthr) {
             const int l = t % nl, b = t / nl;                       // b: butterfly quad index
             const int pos = b & (m - 1);
             const int p = ((b - pos) << 2) + pos;
@@ -57,7 +57,7 @@ __device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2
         __syncthreads();
         const int nb = (N >> 1) * nl;
         const int tstep = (N >> 1) / m;
-        for (int t = threadIdx.x; t < nb; t += kFftBlock) {
+        for (int t = tid; t < nb; t += nthr) {
             const int l = t % nl, b = t / nl;
             const int pos = b & (m - 1);
             const int i = ((b - pos) << 1) + pos, j = i + m;
@@ -72,18 +72,23 @@ __device__ inline void lds_fft_stages(double2 *buf, int N, int nl, const double2
 // pass 1: real lines along the contiguous axis -> first N/2 + 1 coefficients.  One workgroup transforms TWO adjacent
 // lines a, b as the single complex sequence a + i b and separates the spectra afterwards:
 //   A_k = (Z_k + conj(Z_{N-k})) / 2,   B_k = (Z_k - conj(Z_{N-k})) / (2i).
-__global__ void __launch_bounds__(kFftBlock)
+template <int PAIRS, int TPP>
+__global__ void __launch_bounds__(PAIRS * TPP)
 fft_r2c_lines_kernel(const double *__restrict__ map, double2 *__restrict__ out, int N, int log2n, const double2 *__restrict__ tw, int pitch)
 {
     extern __shared__ double2 fbuf[];
-    const int64_t line = 2 * (int64_t)blockIdx.x;
+    // PAIRS line pairs per workgroup, TPP threads each (the barriers are shared): a workgroup per pair is launch-bound at N <= 512
+    constexpr int H = TPP;
+    const int sub = threadIdx.x / H, tid = threadIdx.x % H;
+    const int64_t line = 2 * (PAIRS * (int64_t)blockIdx.x + sub);
     const double *sa = map + line * N, *sb = sa + N;
-    for (int i = threadIdx.x; i < N; i += kFftBlock) fbuf[bit_reverse(i, log2n)] = make_double2(sa[i], sb[i]);
-    lds_fft_stages(fbuf, N, 1, tw);
+    double2 *fb = fbuf + (size_t)sub * N;
+    for (int i = tid; i < N; i += H) fb[bit_reverse(i, log2n)] = make_double2(sa[i], sb[i]);
+    lds_fft_stages(fb, N, 1, tw, tid, H);
     const int nz = (N >> 1) + 1;
     double2 *da = out + line * pitch, *db = da + pitch;                  // rows of `pitch` >= nz complex values
-    for (int k = threadIdx.x; k < nz; k += kFftBlock) {
-        const double2 z = fbuf[k], zc = fbuf[(N - k) & (N - 1)];    // Z_{N-k}, with Z_N = Z_0
+    for (int k = tid; k < nz; k += H) {
+        const double2 z = fb[k], zc = fb[(N - k) & (N - 1)];        // Z_{N-k}, with Z_N = Z_0
         da[k] = make_double2(0.5 * (z.x + zc.x), 0.5 * (z.y - zc.y));
         db[k] = make_double2(0.5 * (z.y + zc.y), 0.5 * (zc.x - z.x));
     }
@@ -217,7 +222,7 @@ __host__ __device__ inline size_t fft_c2c_lds_bytes(int N, int lt, int nk, int b
 // slice for the tile is fetched into LDS together with the tile).  Binned passes write nothing back: the spectrum itself is not an
 // output; the histogram is flushed once at the end; the line index is then the FIRST array axis and o the column b0 + o of the middle axis.
 template <int BIN, int LT, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4)       // (1024 threads: 64 VGPRs, so that the two workgroups LDS holds both run)
 fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int64_t stride, int64_t outer_stride,
                        const double2 *__restrict__ tw, int nzt, int nouter, PkBins pb)
 {
