@@ -91,7 +91,7 @@ def test_make_map_tiled_and_atomic_forms(gpu, monkeypatch, mode, ndim, N, npart,
     assert np.abs(Map - ora).max() <= 1e-12 * ora.max()
 
 
-@pytest.mark.parametrize('N,Nk', [(8, 3), (16, 5), (32, 12), (64, 180), (128, 60)])
+@pytest.mark.parametrize('N,Nk', [(8, 3), (16, 5), (32, 12), (64, 180), (128, 60), (32, 300), (256, 180)])      # (Nk > 254: bins computed per mode, no table)
 def test_power_spectrum_vs_numpy_restatement(gpu, N, Nk):
     from baryonification_amd.engine import power_spectrum
     from oracle import grid as G
