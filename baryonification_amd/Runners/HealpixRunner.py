@@ -77,6 +77,8 @@ class DefaultRunner(object):
             cached = self._catalog_rebuild(cat, names)
         cols = cached[1]
         c, keep = _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], cols[4:], coords=cached[2])
+        # bfgx_opts.catalog_token: the columns stay on the device between calls under the hash of the bytes they were made from
+        self._catalog_token = 0 if cached[0] is None else ((cached[0][3] ^ (hash(cached[0][2]) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF) | 1
         return c, keep, verify
 
     def _catalog_rebuild(self, cat, names):
@@ -146,6 +148,7 @@ class BaryonifyShell(DefaultRunner):
         stats = _lib.bfgx_stats()
 
         def call(cat):
+            opts.catalog_token = self._catalog_token
             _lib.check(_lib.load().bfgx_baryonify_shell(C.byref(cat), C.byref(model), nside, orig_map.ctypes.data,
                                                         new_map.ctypes.data, C.byref(opts), C.byref(stats)))
         self._call_with_catalog(p_keys, call)
@@ -172,6 +175,7 @@ class PaintProfilesShell(DefaultRunner):
         stats = _lib.bfgx_stats()
 
         def call(cat):
+            opts.catalog_token = self._catalog_token
             _lib.check(_lib.load().bfgx_paint_shell(C.byref(cat), C.byref(model), nside, new_map.ctypes.data, C.byref(opts), C.byref(stats)))
         self._call_with_catalog(p_keys, call)
         self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}

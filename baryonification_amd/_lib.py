@@ -49,7 +49,7 @@ class bfgx_model(C.Structure):
 
 class bfgx_opts(C.Structure):
     _fields_ = [('device', C.c_int32), ('acc_offsets_f64', C.c_int32), ('acc_paint_f64', C.c_int32),
-                ('check_mass', C.c_int32), ('algo', C.c_int32), ('_pad', C.c_int32)]
+                ('check_mass', C.c_int32), ('algo', C.c_int32), ('_pad', C.c_int32), ('catalog_token', C.c_uint64)]
 
 
 class bfgx_grid(C.Structure):
@@ -92,6 +92,7 @@ SYMBOLS = {
                                          _P(bfgx_opts), _P(bfgx_stats)]),
     'bfgx_cache_clear': (None, []),
     'bfgx_debug_alloc_count': (C.c_longlong, []),
+    'bfgx_debug_catalog_uploads': (C.c_longlong, []),
     'bfgx_host_alloc': (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     'bfgx_host_free': (None, [C.c_void_p]),
     'bfgx_plan_create': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, _P(bfgx_model), _P(C.c_void_p)]),

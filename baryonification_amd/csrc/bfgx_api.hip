@@ -812,8 +812,10 @@ int bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings)
     return BFGX_OK;
 }
 
-int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
-                             int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev)
+// reset_far = false: the far-deposit list keeps what earlier calls have listed (the one-shot host entry regrids the sphere in several
+// band ranges while the map is still arriving, and applies one list at the end)
+static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
+                             int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev, bool reset_far)
 {
     if (!p) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "banded regrid needs the tiled algorithm (algo 1)");
@@ -822,7 +824,7 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
     if (band0 == band1) {
         // a rank that owns no band (more ranks than bands): empty buffers, whose data pointers are NULL, are fine
         HIP_TRY(hipSetDevice(p->device));
-        HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
+        if (reset_far) HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
         if (sums_dev) HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
         return BFGX_OK;
     }
@@ -831,7 +833,7 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
         return fail(BFGX_ERR_INVALID, "pix_offsets range [%lld, %lld) does not cover the bands and %d ring(s) either side [%lld, %lld)",
                     (long long)olo, (long long)ohi, p->band_reach, (long long)need_lo, (long long)need_hi);
     HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
+    if (reset_far) HIP_TRY(hipMemsetAsync(p->far.count, 0, sizeof(unsigned long long), p->stream));
     const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * band0);
     const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
     {
@@ -871,6 +873,12 @@ int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const d
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;
+}
+
+int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
+                             int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev)
+{
+    return regrid_bands_impl(p, band0, band1, map_in_dev, offsets_dev, olo, ohi, acc_f64, out_slice_dev, sums_dev, true);
 }
 
 int bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0, int64_t p1, unsigned long long *foreign_dev)
@@ -1330,7 +1338,13 @@ struct CacheEntry {
     bfgx_plan *plan = nullptr;
     PoolBuf cols[kCatCols], in, out, off, sums;
     hipStream_t copy_stream = nullptr;       // the map travels to the device while K0 / K1 run on the plan's stream
+    hipStream_t out_stream = nullptr;        // the regridded band ranges travel back while the rest of the map is still arriving
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_in, ev_k2;    // per band range: its part of the map has arrived / has been regridded
+    // the catalog columns of the last call stay on the device under the caller's token (bfgx_opts.catalog_token)
+    uint64_t cat_token = 0;
+    int64_t cat_n = -1;
+    bfgx_catalog cat_dev;
 };
 
 std::mutex g_cache_mu;
@@ -1381,7 +1395,10 @@ void cache_drop(CacheEntry *e)
     for (auto &c : e->cols) c.release();
     e->in.release(); e->out.release(); e->off.release(); e->sums.release();
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->out_stream) (void)hipStreamDestroy(e->out_stream);
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->ev_in) (void)hipEventDestroy(v);
+    for (auto &v : e->ev_k2) (void)hipEventDestroy(v);
     delete e;
 }
 
@@ -1425,9 +1442,17 @@ int cache_acquire(int device, int64_t nside, const bfgx_model *model, int64_t n,
     return BFGX_OK;
 }
 
-int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d, std::vector<double> &hostlog)
+std::atomic<long long> g_catalog_uploads{0};
+
+int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d, std::vector<double> &hostlog, uint64_t token)
 {
     bfgx_plan *p = e->plan;
+    if (token != 0 && token == e->cat_token && h->n == e->cat_n) {      // the same catalog as last time: its columns are still there
+        *d = e->cat_dev;
+        return BFGX_OK;
+    }
+    e->cat_token = 0;
+    g_catalog_uploads.fetch_add(1);
     const int nex = p->model.tab.ndim - 3;
     const double *lnz = h->ln1pz, *lnm = h->lnM;
     if (h->n > 0 && (!lnz || !lnm)) {                        // see upload_catalog
@@ -1456,10 +1481,14 @@ int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d,
     d->M = dp[0]; d->z = dp[1]; d->ra = dp[2]; d->dec = dp[3];
     for (int k = 0; k < nex; ++k) d->extra[k] = dp[4 + k];
     d->ln1pz = dp[4 + BFGX_MAX_EXTRA]; d->lnM = dp[5 + BFGX_MAX_EXTRA];
+    // (the copies above are from pageable memory: they have left the host buffers when hipMemcpyAsync returns)
+    e->cat_token = token; e->cat_n = h->n; e->cat_dev = *d;
     return BFGX_OK;
 }
 
 }  // namespace
+
+long long bfgx_debug_catalog_uploads(void) { return g_catalog_uploads.load(); }
 
 void bfgx_cache_clear(void)
 {
@@ -1514,8 +1543,8 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     // phases: catalog -> device, K0 + K1 launched (enqueue-only), THEN the map -> device on a second stream (a copy from
     // pageable memory occupies the host, the kernels run meanwhile), K2 after both, map -> host
     HIP_TRY(hipEventRecord(e->ev[0], p->stream));
-    if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog)) return rc;
-    if (e->in.need(npix * sizeof(double)) || e->out.need(npix * sizeof(double)) || e->off.need(acc_bytes) || e->sums.need(2 * sizeof(double)))
+    if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog, o.catalog_token)) return rc;
+    if (e->in.need(npix * sizeof(double)) || e->out.need(npix * sizeof(double)) || e->off.need(acc_bytes) || e->sums.need(40 * sizeof(double)))
         return fail(BFGX_ERR_HIP, "hipMalloc(map buffers) failed");
     if (o.algo == 0) {                                       // global-atomic kernels accumulate; the tiled ones store every element once
         HIP_TRY(hipMemsetAsync(e->off.p, 0, acc_bytes, p->stream));
@@ -1525,16 +1554,138 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     const int rc_off = bfgx_offsets_device(p, &dcat, e->off.p, o.acc_offsets_f64);
     p->omax_from_k1 = false;
     if (rc_off) return rc_off;
-    HIP_TRY(hipMemcpyAsync(e->in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(hipEventRecord(e->ev[1], e->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(p->stream, e->ev[1], 0));
-    if (int rc = regrid_impl(p, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p, o.algo == 1)) return rc;
-    HIP_TRY(hipEventRecord(e->ev[2], p->stream));
     double sums[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipMemcpyAsync(sums, e->sums.p, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipEventRecord(e->ev[3], p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    // Large maps travel in band ranges (contiguous RING pixel ranges): a range is regridded as soon as it and its apron have arrived
+    // and goes back to the host while the next ones are still coming in, so that the two directions of the link work at the same
+    // time.  The gathering regrid stores
+    // every pixel of a range exactly once; the few deposits it cannot gather (next to a pole) are listed and added on the host.
+    // Range size: copies below ~16 MB take a slower path here (8 ranges of 12.6 MB: 4.0 ms per call, 6 of 16.8 MB: 3.3 ms), so a map is cut
+    // into ranges of at least that, at most 16 of them; both host buffers are page-locked for the duration of the call (hipHostRegister:
+    // 2 us here) -- from pageable memory the copies in and out take turns on the host thread and the one-pass route below is faster
+    // (4.3 against 4.5 ms), which is also where a map goes that cannot be registered.
+    constexpr int kChunksMax = 16;
+    int kChunks = (int)std::min<size_t>(kChunksMax, npix * sizeof(double) / ((size_t)16 << 20));
+    if (const char *ce = std::getenv("BFGX_PIPE_CHUNKS")) kChunks = std::max(2, std::min(kChunksMax, std::atoi(ce)));       // (tests: small maps)
+    bool piped = o.algo == 1 && kChunks >= 2 && p->tiling.nbands >= 2 * kChunks && !std::getenv("BFGX_NO_PIPELINE");
+    bool whole_map_sent = false;
+    struct Pin {
+        void *p = nullptr;
+        ~Pin() { if (p) (void)hipHostUnregister(p); }
+        // true if [q, q + bytes) is page-locked afterwards (registered here, or already by the caller: bfgx_host_alloc)
+        bool lock(const void *q, size_t bytes)
+        {
+            if (hipHostRegister((void *)q, bytes, hipHostRegisterDefault) == hipSuccess) { p = (void *)q; return true; }
+            (void)hipGetLastError();
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, q) == hipSuccess && at.type == hipMemoryTypeHost) return true;
+            (void)hipGetLastError();
+            return false;
+        }
+    } pin_in, pin_out;
+    if (piped) piped = pin_in.lock(map_in, npix * sizeof(double)) && pin_out.lock(map_out, npix * sizeof(double));
+    if (piped) {
+        int nb = 0;
+        std::vector<int64_t> bfp((size_t)p->tiling.nbands + 1);
+        if (int rc = bfgx_plan_bands(p, &nb, bfp.data())) return rc;
+        int cb[kChunksMax + 1];
+        cb[0] = 0; cb[kChunks] = nb;
+        for (int c = 1; c < kChunks; ++c) {
+            const int64_t target = (int64_t)(npix * (size_t)c / kChunks);
+            int b = (int)(std::lower_bound(bfp.begin(), bfp.end(), target) - bfp.begin());
+            cb[c] = std::min(std::max(b, cb[c - 1] + 1), nb - (kChunks - c));
+        }
+        if (!e->out_stream) HIP_TRY(hipStreamCreateWithFlags(&e->out_stream, hipStreamNonBlocking));
+        while ((int)e->ev_in.size() < kChunks) { hipEvent_t v; HIP_TRY(hipEventCreateWithFlags(&v, hipEventDisableTiming)); e->ev_in.push_back(v); }
+        while ((int)e->ev_k2.size() < kChunks) { hipEvent_t v; HIP_TRY(hipEventCreateWithFlags(&v, hipEventDisableTiming)); e->ev_k2.push_back(v); }
+        if (e->sums.need((2 * kChunks + 2) * sizeof(double))) return fail(BFGX_ERR_HIP, "hipMalloc(sums) failed");
+        double *dsums = (double *)e->sums.p;
+        float *domax = (float *)(dsums + 2 * kChunks);
+        auto send = [&](int c) -> int {
+            const int64_t lo = bfp[cb[c]], n = bfp[cb[c + 1]] - lo;
+            HIP_TRY(hipMemcpyAsync((double *)e->in.p + lo, map_in + lo, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+            HIP_TRY(hipEventRecord(e->ev_in[c], e->copy_stream));
+            return BFGX_OK;
+        };
+        if (int rc = send(0)) return rc;
+        if (int rc = send(1)) return rc;
+        // how many rings a deposit travels: from the largest displacement K1 has seen (by now K1 has finished underneath the two copies)
+        float m2 = 0.0f;
+        if (int rc = bfgx_bands_max_offset2_device(p, 0, nb, domax)) return rc;
+        HIP_TRY(hipMemcpyAsync(&m2, domax, sizeof(float), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        int32_t rings = kReachMax;
+        if (std::isfinite(m2)) { if (int rc = bfgx_plan_reach_rings(p, std::sqrt((double)m2), &rings)) return rc; }
+        const int32_t reach_before = p->band_reach;
+        if (rings > 4) piped = false;                        // large displacements: the data-sized aprons and the in-stream repair of regrid_impl
+        int sent = 2;
+        if (piped) {
+            p->band_reach = rings;
+            int next = 0;
+            int rc_run = BFGX_OK;
+            auto run_ready = [&]() -> int {                  // regrid every range whose apron lies within the ranges sent so far
+                while (next < kChunks) {
+                    int64_t olo = 0, ohi = 0;
+                    if (int rc = bfgx_plan_band_apron(p, cb[next], cb[next + 1], &olo, &ohi)) return rc;
+                    int need = next;
+                    while (need < kChunks - 1 && bfp[cb[need + 1]] < ohi) ++need;
+                    if (need >= sent) break;
+                    HIP_TRY(hipStreamWaitEvent(p->stream, e->ev_in[need], 0));
+                    const int64_t lo = bfp[cb[next]], n = bfp[cb[next + 1]] - lo;
+                    if (int rc = regrid_bands_impl(p, cb[next], cb[next + 1], (const double *)e->in.p, e->off.p, 0, (int64_t)npix, o.acc_offsets_f64,
+                                                   (double *)e->out.p + lo, dsums + 2 * next, next == 0)) return rc;
+                    HIP_TRY(hipEventRecord(e->ev_k2[next], p->stream));
+                    HIP_TRY(hipStreamWaitEvent(e->out_stream, e->ev_k2[next], 0));
+                    HIP_TRY(hipMemcpyAsync(map_out + lo, (double *)e->out.p + lo, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+                    ++next;
+                }
+                return BFGX_OK;
+            };
+            rc_run = run_ready();
+            for (; rc_run == BFGX_OK && sent < kChunks; ) {
+                rc_run = send(sent);
+                ++sent;
+                if (rc_run == BFGX_OK) rc_run = run_ready();
+            }
+            p->band_reach = reach_before;
+            if (rc_run) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamSynchronize(p->stream); (void)hipStreamSynchronize(e->out_stream); return rc_run; }
+            HIP_TRY(hipEventRecord(e->ev[1], e->copy_stream));
+            HIP_TRY(hipEventRecord(e->ev[2], p->stream));
+            double hs[2 * kChunksMax];
+            HIP_TRY(hipMemcpyAsync(hs, dsums, sizeof(double) * 2 * (size_t)kChunks, hipMemcpyDeviceToHost, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            HIP_TRY(hipStreamSynchronize(e->out_stream));
+            HIP_TRY(hipEventRecord(e->ev[3], p->stream));
+            for (int c = 0; c < kChunks; ++c) { sums[0] += hs[2 * c]; sums[1] += hs[2 * c + 1]; }
+            // the listed deposits (pixels next to a pole): added on the host; an overflowing list sends the call down the one-pass route
+            int64_t nfar = 0;
+            if (bfgx_plan_far_fetch(p, 0, nullptr, nullptr, &nfar) != BFGX_OK) piped = false;
+            else if (nfar > 0) {
+                std::vector<int64_t> fp((size_t)nfar);
+                std::vector<double> fv((size_t)nfar);
+                if (int rc = bfgx_plan_far_fetch(p, nfar, fp.data(), fv.data(), &nfar)) return rc;
+                for (int64_t i = 0; i < nfar; ++i) if (fp[(size_t)i] >= 0 && fp[(size_t)i] < (int64_t)npix) map_out[fp[(size_t)i]] += fv[(size_t)i];
+            }
+            whole_map_sent = true;
+        }
+        if (!piped) {                                        // the rest of the map in one piece, then the one-pass route below
+            if (!whole_map_sent && sent < kChunks) {
+                const int64_t lo = bfp[cb[sent]];
+                HIP_TRY(hipMemcpyAsync((double *)e->in.p + lo, map_in + lo, (npix - (size_t)lo) * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+            }
+            whole_map_sent = true;
+        }
+    }
+    if (!piped) {
+        if (!whole_map_sent) HIP_TRY(hipMemcpyAsync(e->in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipEventRecord(e->ev[1], e->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(p->stream, e->ev[1], 0));
+        if (int rc = regrid_impl(p, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p, o.algo == 1)) return rc;
+        HIP_TRY(hipEventRecord(e->ev[2], p->stream));
+        HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(sums, e->sums.p, sizeof(sums), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipEventRecord(e->ev[3], p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     float f_h2d = 0, f_k = 0, f_d2h = 0;
     (void)hipEventElapsedTime(&f_h2d, e->ev[0], e->ev[1]);   // both uploads (K0 + K1 run underneath the second one)
     (void)hipEventElapsedTime(&f_k, e->ev[1], e->ev[2]);     // what the kernels add after the last byte has arrived
@@ -1578,7 +1729,7 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     bfgx_catalog dcat;
     Timer t;
     t.start(p->stream);
-    if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog)) return rc;
+    if (int rc = upload_catalog_pooled(e, cat, &dcat, hostlog, o.catalog_token)) return rc;
     if (e->out.need(npix * sizeof(double))) return fail(BFGX_ERR_HIP, "hipMalloc(map) failed");
     const double ms_h2d = t.stop(p->stream);
     t.start(p->stream);

@@ -103,6 +103,11 @@ typedef struct bfgx_opts {
     int32_t check_mass;                   /* 1: enforce np.isclose(sum(new), sum(old)) like the reference */
     int32_t algo;                         /* 1 = LDS tiles (default), 0 = per-halo global atomics */
     int32_t _pad;
+    uint64_t catalog_token;               /* 0: the catalog columns are copied to the device on every call.  Non-zero: the caller's name for
+                                             the CONTENT of the catalog (e.g. a hash of its bytes); the one-shot entries keep the columns of
+                                             the last call on the device and skip the copy when the same token and size come again.  The
+                                             caller vouches that equal tokens mean equal columns (HealpixRunner.py re-reads `cat` on every
+                                             call: the Python runner hashes every byte of the catalog) */
 } bfgx_opts;
 
 typedef struct bfgx_stats {
@@ -160,6 +165,8 @@ int bfgx_paint_shell_multi(const bfgx_catalog *cat_host, const bfgx_model *model
  * bfgx_host_alloc / bfgx_host_free: page-locked host memory for map_out (D2H at full PCIe rate; plain memory works too). */
 void      bfgx_cache_clear(void);
 long long bfgx_debug_alloc_count(void);
+/* catalog copies host -> device made by the one-shot entries so far (tests: a call that repeats bfgx_opts.catalog_token makes none) */
+long long bfgx_debug_catalog_uploads(void);
 int       bfgx_host_alloc(size_t bytes, void **out);
 void      bfgx_host_free(void *p);
 

@@ -241,3 +241,83 @@ def test_in_place_catalog_edit_between_calls_is_seen(gpu):
     out2 = runner.process()
     assert np.abs(out2 - oracle()).max() <= 1e-10 * hmap.max() and np.abs(out2 - out1).max() > 0
     assert np.array_equal(runner.process(), out2) or np.abs(runner.process() - out2).max() <= 1e-13 * hmap.max()      # unchanged catalog: cached
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['subpixel', 'polar', 'several_rings', 'many_rings'])
+def test_host_entry_in_band_ranges_equals_one_pass(gpu, case, monkeypatch):
+    """bfgx_baryonify_shell moves large maps in band ranges (a range is regridded and sent back while the next ones are still arriving).
+    Its result against the one-pass route of the same entry (BFGX_NO_PIPELINE) and the oracle: sub-pixel displacements (one ring of
+    apron), halos on the poles (deposits the gathering regrid lists and the host adds), displacements of a few rings (wider aprons) and
+    of many rings (falls back to the one-pass route by itself)"""
+    import baryonification_amd as bfg
+    from baryonification_amd import _lib, synthetic as syn
+    from oracle import oracle as O
+    nside, N = 512, 30_000
+    cat = syn.make_catalog(N, seed=11, logM_lo=13.0, logM_hi=15.0)
+    if case == 'polar':
+        cat['dec'][:400] = np.where(np.arange(400) % 2 == 0, 89.97, -89.95) + np.linspace(0, 0.02, 400)
+    z, M, r = syn.table_grid(cat, pad=1e-3)
+    scale = {'subpixel': 1.0, 'polar': 1.0, 'several_rings': 60.0, 'many_rings': 400.0}[case]
+    d = scale * syn.displacement_table(z, M, r)
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO), epsilon_max=10.0)
+    model.set_table(z, M, r, d)
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    hmap = syn.make_map(nside)
+    hmap[::23] = 0.0
+    runner = bfg.Runners.BaryonifyShell(Catalog, bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO), 10.0, model, verbose=False)
+    runner.acc_f64 = True
+    monkeypatch.setenv('BFGX_PIPE_CHUNKS', '5')               # (a 25 MB map would go in one piece)
+    piped = runner.process()
+    st = dict(runner.last_stats)
+    monkeypatch.setenv('BFGX_NO_PIPELINE', '1')
+    whole = runner.process()
+    monkeypatch.delenv('BFGX_NO_PIPELINE')
+    assert np.isfinite(piped).all() and np.isclose(piped.sum(), hmap.sum(), rtol=1e-12) and np.isclose(st['sum_out'], st['sum_in'], rtol=1e-12)
+    assert np.abs(piped - hmap).max() > 0
+    assert np.abs(piped - whole).max() <= 1e-12 * hmap.max()
+    if case in ('subpixel', 'polar'):
+        used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}
+        ora = O.baryonify_shell(nside, hmap, used, O.Table([np.log(1 + z), np.log(M), np.log(r)], d, False, 10.0), 10.0, O.Background.from_dict(syn.COSMO))
+        assert np.abs(piped - ora).max() <= 1e-10 * hmap.max()
+    # fp32 accumulators (the default) through the same route
+    runner.acc_f64 = False
+    p32 = runner.process()
+    assert np.abs(p32 - piped).max() <= 1e-5 * max(1.0, scale) * hmap.mean() and np.isclose(p32.sum(), hmap.sum(), rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_catalog_columns_stay_on_the_device_between_calls(gpu):
+    """bfgx_opts.catalog_token: a process() call on an unchanged catalog copies no catalog column; an edited catalog is copied again"""
+    import baryonification_amd as bfg
+    from baryonification_amd import _lib, synthetic as syn
+    nside, N = 64, 5000
+    cat = syn.make_catalog(N, seed=5, logM_lo=13.0, logM_hi=14.5)
+    z, M, r = syn.table_grid(cat, pad=1e-3)
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO), epsilon_max=10.0)
+    model.set_table(z, M, r, syn.displacement_table(z, M, r))
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    runner = bfg.Runners.BaryonifyShell(Catalog, bfg.utils.LightconeShell(map=syn.make_map(nside), cosmo=syn.COSMO), 10.0, model, verbose=False)
+    runner.acc_f64 = True
+    lib = _lib.load()
+    out0 = runner.process()
+    n0 = lib.bfgx_debug_catalog_uploads()
+    out1 = runner.process()
+    close = lambda a, b: np.abs(a - b).max() <= 1e-11             # (the order of the LDS adds is not fixed)
+    assert lib.bfgx_debug_catalog_uploads() == n0 and close(out0, out1)
+    j = int(np.argmax(Catalog.cat['M']))
+    Catalog.cat['M'][j] *= 0.8
+    out2 = runner.process()
+    assert lib.bfgx_debug_catalog_uploads() == n0 + 1
+    assert np.abs(out2 - out1).max() > 1e-6
+    # the raw entry without a token copies every time
+    c, keep, _ = runner._catalog([])
+    from baryonification_amd.Runners._model import build_model
+    m, _, mkeep = build_model(runner, 'displacement')
+    import ctypes as C
+    o = _lib.bfgx_opts(0, 1, 1, 1, 1, 0)
+    res = _lib.pinned_empty(12 * nside * nside)
+    hmap = _lib.f8(runner.LightconeShell.map)
+    for _ in range(2):
+        _lib.check(lib.bfgx_baryonify_shell(C.byref(c), C.byref(m), nside, hmap.ctypes.data, res.ctypes.data, C.byref(o), None))
+    assert lib.bfgx_debug_catalog_uploads() == n0 + 3 and close(res, out2)
