@@ -1733,9 +1733,61 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     if (e->out.need(npix * sizeof(double))) return fail(BFGX_ERR_HIP, "hipMalloc(map) failed");
     const double ms_h2d = t.stop(p->stream);
     t.start(p->stream);
+    // Large fp64 maps are painted in band ranges, each copied back while the next ones are painted (as in bfgx_baryonify_shell: ranges of
+    // at least 16 MB, at most 16, map_out page-locked for the call); K0 runs once, K3 on the tiles of each range
+    constexpr int kChunksMax = 16;
+    int kChunks = (int)std::min<size_t>(kChunksMax, npix * sizeof(double) / ((size_t)16 << 20));
+    if (const char *ce = std::getenv("BFGX_PIPE_CHUNKS")) kChunks = std::max(2, std::min(kChunksMax, std::atoi(ce)));       // (tests: small maps)
+    bool piped = o.algo == 1 && o.acc_paint_f64 != 0 && kChunks >= 2 && p->tiling.nbands >= 2 * kChunks && !std::getenv("BFGX_NO_PIPELINE");
+    struct Pin { void *p = nullptr; ~Pin() { if (p) (void)hipHostUnregister(p); } } pin_out;
+    if (piped) {
+        if (hipHostRegister((void *)map_out, npix * sizeof(double), hipHostRegisterDefault) == hipSuccess) pin_out.p = (void *)map_out;
+        else {
+            (void)hipGetLastError();
+            hipPointerAttribute_t at;
+            if (!(hipPointerGetAttributes(&at, map_out) == hipSuccess && at.type == hipMemoryTypeHost)) { (void)hipGetLastError(); piped = false; }
+        }
+    }
+    double ms_k = 0.0;
+    if (piped) {
+        if (int rc = check_catalog(p, &dcat)) return rc;
+        if (!p->model.tab.logv) return fail(BFGX_ERR_INVALID, "profile painting needs a table with log_values = 1");
+        if (o.acc_paint_f64 < 0 || o.acc_paint_f64 > 2) return fail(BFGX_ERR_INVALID, "acc_f64 must be 0, 1 or 2");
+        int nb = 0;
+        std::vector<int64_t> bfp((size_t)p->tiling.nbands + 1);
+        if (int rc = bfgx_plan_bands(p, &nb, bfp.data())) return rc;
+        int cb[kChunksMax + 1];
+        cb[0] = 0; cb[kChunks] = nb;
+        for (int c = 1; c < kChunks; ++c) {
+            const int64_t target = (int64_t)(npix * (size_t)c / kChunks);
+            const int b = (int)(std::lower_bound(bfp.begin(), bfp.end(), target) - bfp.begin());
+            cb[c] = std::min(std::max(b, cb[c - 1] + 1), nb - (kChunks - c));
+        }
+        if (!e->out_stream) HIP_TRY(hipStreamCreateWithFlags(&e->out_stream, hipStreamNonBlocking));
+        while ((int)e->ev_k2.size() < kChunks) { hipEvent_t v; HIP_TRY(hipEventCreateWithFlags(&v, hipEventDisableTiming)); e->ev_k2.push_back(v); }
+        const bool mixed = o.acc_paint_f64 == 2 && use_fast(p);      // (tables the fast kernel cannot take: fp64 throughout)
+        if (int rc = launch_prep_and_bin(p, &dcat, 0, !mixed)) return rc;
+        if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, &dcat)) return rc;
+        p->paint_pair_f32 = mixed;
+        struct Reset { bfgx_plan *p; ~Reset() { p->paint_pair_f32 = false; p->k1_tile_lo = 0; p->k1_tile_n = -1; } } reset{p};
+        for (int c = 0; c < kChunks; ++c) {
+            p->k1_tile_lo = p->band_tile0_host[cb[c]];
+            p->k1_tile_n = p->band_tile0_host[cb[c + 1]] - p->k1_tile_lo;
+            // (the persistent kernel draws its tiles from a counter that the binning step zeroes: once more for every further launch)
+            if (c > 0) HIP_TRY(hipMemsetAsync(p->tile_count + 5 * ((size_t)p->tiling.ntiles + 1), 0, sizeof(unsigned int), p->stream));
+            if (int rc = launch_tile_scatter<MODE_PAINT, double>(p, (double *)e->out.p)) return rc;      // (indexed by global pixel number)
+            HIP_TRY(hipEventRecord(e->ev_k2[c], p->stream));
+            HIP_TRY(hipStreamWaitEvent(e->out_stream, e->ev_k2[c], 0));
+            const int64_t lo = bfp[cb[c]], n = bfp[cb[c + 1]] - lo;
+            HIP_TRY(hipMemcpyAsync(map_out + lo, (double *)e->out.p + lo, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
+        }
+        ms_k = t.stop(p->stream);
+        t.start(p->stream);
+        HIP_TRY(hipStreamSynchronize(e->out_stream));
+    } else {
     if (o.algo == 0) HIP_TRY(hipMemsetAsync(e->out.p, 0, npix * sizeof(double), p->stream));
     if (int rc = bfgx_paint_device(p, &dcat, e->out.p, o.acc_paint_f64)) return rc;
-    const double ms_k = t.stop(p->stream);
+    ms_k = t.stop(p->stream);
     t.start(p->stream);
     if (o.acc_paint_f64) {
         HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
@@ -1745,6 +1797,7 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
         HIP_TRY(hipMemcpyAsync(tmp.data(), e->out.p, npix * sizeof(float), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
         for (size_t i = 0; i < npix; ++i) map_out[i] = (double)tmp[i];
+    }
     }
     const double ms_d2h = t.stop(p->stream);
     if (int rc = bfgx_plan_status(p)) return rc;

@@ -1,3 +1,4 @@
+"""GPU box: wall time of BaryonifyShell.process() at config 2 (1e6 halos, NSIDE 1024), numpy in / numpy out (BFGX_NO_PIPELINE=1: one-pass route)"""
 import sys, time, os
 import numpy as np
 sys.path.insert(0, '.')

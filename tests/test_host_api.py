@@ -321,3 +321,30 @@ def test_catalog_columns_stay_on_the_device_between_calls(gpu):
     for _ in range(2):
         _lib.check(lib.bfgx_baryonify_shell(C.byref(c), C.byref(m), nside, hmap.ctypes.data, res.ctypes.data, C.byref(o), None))
     assert lib.bfgx_debug_catalog_uploads() == n0 + 3 and close(res, out2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [True, 'mixed'])
+def test_paint_host_entry_in_band_ranges_equals_one_pass(gpu, mode, monkeypatch):
+    """bfgx_paint_shell paints large fp64 maps band range by band range, copying each back while the next is painted: against the one-pass
+    route of the same entry and the oracle, with halos on the poles (the generic kernel's tiles) in the catalog"""
+    from oracle import oracle as O
+    nside, N = 512, 20_000
+    cat = syn.make_catalog(N, seed=12, logM_lo=13.0, logM_hi=15.0)
+    cat['dec'][:300] = np.where(np.arange(300) % 2 == 0, 89.9, -89.8) + np.linspace(0, 0.05, 300)
+    z, M, r = syn.table_grid(cat, pad=1e-3)
+    P = syn.paint_table(z, M, r)
+    prof = bfg.utils.TabulatedProfile(None, bfg.utils.Cosmology.from_dict(syn.COSMO))
+    prof.set_table(z, M, r, P)
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    runner = bfg.Runners.PaintProfilesShell(Catalog, bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=syn.COSMO), 10.0, prof, verbose=False)
+    runner.acc_f64 = mode
+    monkeypatch.setenv('BFGX_PIPE_CHUNKS', '6')
+    piped = runner.process()
+    monkeypatch.setenv('BFGX_NO_PIPELINE', '1')
+    whole = runner.process()
+    assert piped.max() > 0 and np.isfinite(piped).all()
+    assert np.abs(piped - whole).max() <= 1e-12 * np.abs(whole).max()
+    used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}
+    ora = O.paint_shell(nside, used, O.Table([np.log(1 + z), np.log(M), np.log(r)], np.log(P)), 10.0, O.Background.from_dict(syn.COSMO))
+    assert np.abs(piped - ora).max() <= (1e-10 if mode is True else 5e-5) * np.abs(ora).max()
