@@ -38,7 +38,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.bfgx_massdef) == 16
     assert C.sizeof(_lib.bfgx_table) == 4 + 4 * 5 + 8 * 5 + 8 + 4 + 4 + 8
     assert C.sizeof(_lib.bfgx_catalog) == 8 + 4 * 8 + 2 * 8 + 2 * 8       # n, M z ra dec, extra[2], ln1pz lnM
-    assert C.sizeof(_lib.bfgx_opts) == 24
+    assert C.sizeof(_lib.bfgx_opts) == 24 + 8                           # 6 x int32, catalog_token
 
 
 def test_compute_fails_loudly_without_gpu():
