@@ -928,8 +928,10 @@ def end_to_end(args, cat, hmap, z, M, r, table, calls=5):
         ts.append(time.perf_counter() - t0)
         st = runner.last_stats
     med = float(np.median(ts[1:]))
-    return {"what": "BaryonifyShell.process() from numpy arrays, PCIe-inclusive (never `value`); phases: ms_h2d = catalog + map uploads (K0 + K1 "
-                    "run underneath the map upload), ms_kernels = what is left of the kernels after the last byte has arrived, ms_d2h = map download",
+    return {"what": "BaryonifyShell.process() from numpy arrays, PCIe-inclusive (never `value`); the catalog stays on the device between calls "
+                    "(bfgx_opts.catalog_token), the map goes up / is regridded / comes back in band ranges; phases: ms_h2d = until the last byte of "
+                    "the map has arrived (K0 + K1 and the first ranges' regrid and download run underneath), ms_kernels = what is left of the "
+                    "kernels after that, ms_d2h = until the last range is back",
             "ms_per_call": med * 1e3,
             "ms_first_call": ts[0] * 1e3, "halos_per_s": cat['M'].size / med, "mass_conserved": bool(np.isclose(out.sum(), hmap.sum())),
             "phases_ms": {k: st[k] for k in ('ms_h2d', 'ms_kernels', 'ms_d2h')} if st else None}
