@@ -110,6 +110,7 @@ SYMBOLS = {
     'bfgx_max_offset2_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'bfgx_plan_tile_shape': (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
     'bfgx_disc_rings_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p]),
+    'bfgx_plan_set_route_margin': (C.c_int, [C.c_void_p, C.c_int32]),
     'bfgx_offsets_bands_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int32, C.c_int32, C.c_void_p, C.c_int]),
     'bfgx_paint_bands_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_int32, C.c_int32, C.c_void_p, C.c_int]),
     'bfgx_plan_reach_rings': (C.c_int, [C.c_void_p, C.c_double, _P(C.c_int32)]),

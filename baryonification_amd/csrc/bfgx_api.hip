@@ -119,6 +119,7 @@ struct bfgx_plan {
     int k1_tile_lo = 0, k1_tile_n = -1;   // tiles K1 / K3 process (-1: the whole sphere); set by the *_bands_device entries
     int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
     int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
+    int route_margin = 0;            // rings by which bfgx_disc_rings_device widens every halo's range (bfgx_plan_set_route_margin)
     int32_t *wide_tiles = nullptr;   // [1 + ntiles]: number of tiles with wide entries, then those tiles (tile_scan_kernel)
     // fast tiled scatter (bfgx_scatter2.hpp): slim per-halo records + interleaved copies of the table
     bool fast_ok = false;            // 3-axis table with a uniform ln r axis, small enough to interleave
@@ -875,6 +876,14 @@ static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const d
     return BFGX_OK;
 }
 
+int bfgx_plan_set_route_margin(bfgx_plan *p, int32_t rings)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    if (rings < 0 || rings > 4 * p->hpx.nside) return fail(BFGX_ERR_INVALID, "route margin must be 0 .. 4 nside rings");
+    p->route_margin = rings;
+    return BFGX_OK;
+}
+
 int bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
                              int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev)
 {
@@ -1100,7 +1109,7 @@ int bfgx_disc_rings_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t *rings
     HIP_TRY(hipSetDevice(p->device));
     if (cat->n > 0) {
         hipLaunchKernelGGL(disc_rings_kernel, dim3((unsigned)((cat->n + 255) / 256)), dim3(256), 0, p->stream, p->model, p->hpx, cat->n, cat->M, cat->z,
-                           cat->dec, rings_dev);
+                           cat->dec, rings_dev, p->route_margin);
         HIP_TRY(hipGetLastError());
     }
     return BFGX_OK;

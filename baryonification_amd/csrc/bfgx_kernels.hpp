@@ -768,7 +768,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
 // sharded multi-GPU runs).  Same arithmetic as halo_prep_kernel for a, R, D_A and the colatitude band of the disc.
 __global__ void __launch_bounds__(256)
 disc_rings_kernel(DevModel m, Hpx h, int64_t nhalo, const double *__restrict__ M, const double *__restrict__ z,
-                  const double *__restrict__ dec, int32_t *__restrict__ rings)
+                  const double *__restrict__ dec, int32_t *__restrict__ rings, int margin)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nhalo) return;
@@ -796,6 +796,8 @@ disc_rings_kernel(DevModel m, Hpx h, int64_t nhalo, const double *__restrict__ M
             last = (int)ring_above(h, cos(hi)) + 2;
             first = max(1, first - 1); last = min(nl4 - 1, last + 1);
         }
+        // (a rank that also computes the bands next to its own -- the aprons of its regrid -- takes the halos of those too)
+        first = max(1, first - margin); last = min(nl4 - 1, last + margin);
     }
     rings[2 * j] = first; rings[2 * j + 1] = last;
 }

@@ -94,6 +94,10 @@ class ShellPlan(object):
         """per halo the ring range [first, last] (1-based, inclusive, 2 rings of margin) its disc can touch -> int32 [n][2]"""
         _lib.check(_lib.load().bfgx_disc_rings_device(self._h, C.byref(cat_dev), C.c_void_p(int(rings_ptr) or None)))
 
+    def set_route_margin(self, rings):
+        """disc_rings widens every halo's ring range by `rings` from now on (a rank that computes the bands next to its own as well)"""
+        _lib.check(_lib.load().bfgx_plan_set_route_margin(self._h, int(rings)))
+
     def offsets_bands(self, cat_dev, band0, band1, offsets_slice_ptr, acc_f64=False):
         """K0 + K1 for the tiles of bands [band0, band1) only; the slice starts at the first pixel of band0 ([p1 - p0][3])"""
         _lib.check(_lib.load().bfgx_offsets_bands_device(self._h, C.byref(cat_dev), int(band0), int(band1), C.c_void_p(int(offsets_slice_ptr)),

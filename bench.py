@@ -526,9 +526,10 @@ def shell_line(args, ctx, scaling, brief):
         rb = band_ring_bounds(cuts, plan.tile_shape()[0], nside)
         # fixed-capacity routing: every (source, destination) pair owns a block of `blockcap` rows, the equal splits of ONE all_to_all, so
         # that no count is read back by the host inside a step (the catalog is shuffled, Parallelize.py:255: a destination receives about
-        # nh / world halos from every source; 1.5 x that + 2048 is > 40 sigma).  An overflow is detected on the device, checked after the
+        # nh / world halos from every source; 1.75 x that + 2048 leaves room for the halos of the two neighbouring bands too).  An overflow is detected on the device, checked after the
         # untimed trial step and answered with the variable-split routing (route_halos: one read-back per step)
-        blockcap = int(1.5 * np.ceil(np.ceil(total_halos / world) / world)) + 2048      # (the same on every rank: shards differ by one halo)
+        blockcap = int((1.75 if world > 1 else 1.5) * np.ceil(np.ceil(total_halos / world) / world)) + 2048     # (the same on every rank: shards differ by one halo;
+        #                                                                                  1.75: a rank also takes the halos of the bands next to its own)
         cap = max(world * blockcap, 2 * int(np.ceil(total_halos / world)) + 4096)
         plan_sp = engine.ShellPlan(model, keep, nside, cap, device=local_rank, stream=stream)
         d_rings = torch.empty((nh, 2), dtype=torch.int32, device=dev)
@@ -590,6 +591,30 @@ def shell_line(args, ctx, scaling, brief):
                 gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
                 mark('gather')
                 return
+            if sp_state.get('local_apron'):
+                # the bands next to mine are computed here as well (their halos were routed along: set_route_margin), so the apron rows of
+                # the regrid need no exchange with the neighbours: one collective less per step
+                B0, B1, wlo, whi = sp_state['wide']
+                if sp_state.get('full') is None or sp_state['full'].dtype != acc_dtype or sp_state['full'].numel() != (whi - wlo) * 3:
+                    sp_state['full'] = torch.empty((whi - wlo) * 3, dtype=acc_dtype, device=dev)
+                plan_sp.offsets_bands(cd, B0, B1, sp_state['full'].data_ptr(), acc_f64=acc_f64)
+                mark('K0+K1')
+                plan_sp.regrid_bands(b0, b1, d_map.data_ptr(), sp_state['full'].data_ptr(), wlo, whi, d_slice.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
+                mark('K2')
+                if route_far[0]:
+                    fp, fv = plan_sp.far_fetch()
+                    lists = [None] * world
+                    dist.all_gather_object(lists, (fp, fv))
+                    for qp, qv in lists:
+                        m = (qp >= p0) & (qp < p1)
+                        if m.any():
+                            d_slice.index_add_(0, torch.from_numpy(qp[m] - p0).to(dev), torch.from_numpy(qv[m]).to(dev))
+                else:
+                    plan_sp.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
+                mark('far')
+                gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
+                mark('gather')
+                return
             # once the reach is known the slice is computed in place inside the buffer that also holds the apron rings
             if sp_state['reach_known']:
                 lo_, hi_ = sp_state['nd'][rank]
@@ -609,6 +634,20 @@ def shell_line(args, ctx, scaling, brief):
                     _hip_reach(None, plan_sp, my_off, bands=(b0, b1))
                 sp_state['nd'] = [plan_sp.band_apron(int(cuts[j]), int(cuts[j + 1])) for j in range(world)]
                 sp_state['reach_known'] = True
+                # do the apron rows fit into ONE band either side of every rank's own (reach <= 16 rings, a band is 32 at NSIDE 1024)?  Then
+                # the timed steps route every halo one band further and compute those bands locally instead of exchanging apron rows
+                nbands = len(first) - 1
+                B0, B1 = (max(b0 - 1, 0), min(b1 + 1, nbands)) if b1 > b0 else (b0, b0)
+                fits = (b1 == b0) or (int(first[B0]) <= sp_state['nd'][rank][0] and int(first[B1]) >= sp_state['nd'][rank][1])
+                flag = torch.tensor([1 if fits and os.environ.get('BFGX_BENCH_APRON_EXCHANGE') != '1' else 0], dtype=torch.int32,
+                                    device=dev if backend == 'nccl' else 'cpu')
+                if dist.is_initialized():
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()):
+                    sp_state['local_apron'] = True
+                    sp_state['wide'] = (B0, B1, int(first[B0]), int(first[B1]))
+                    plan_sp.set_route_margin(plan_sp.tile_shape()[0])
+                    sp_state['cd'] = None
             nd = sp_state['nd']
             off_apron = halo_exchange(my_off, pb, nd, 3, full=sp_state.get('full') if my_off.data_ptr() != d_off.data_ptr() else None)
             mark('apron exchange')
@@ -687,10 +726,19 @@ def shell_line(args, ctx, scaling, brief):
         tp = plan_sp if spatial else plan            # the plan whose kernels run in the step
         tp.timing_enable(events)
         fence()
+        prof = None
+        if os.environ.get('BFGX_BENCH_HOST_PROFILE') == '1' and rank == 0:     # where the host time of a step goes (cProfile, stderr)
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         t_enq = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(25)
         fence()
         el = time.perf_counter() - t0
         if os.environ.get('BFGX_BENCH_ENQUEUE_TIME') == '1' and rank == 0:        # how much of a step is host-side enqueue time
@@ -837,7 +885,9 @@ def shell_line(args, ctx, scaling, brief):
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
                        "parallelism": ("single GPU" if world == 1 else
                                        "spatial sharding x%d: halos routed (RCCL all_to_all of catalog columns) to the ranks whose ring bands their discs "
-                                       "touch, every rank computes and regrids its own pixels (apron rings exchanged), disjoint slices -> rank 0" % world
+                                       "touch, every rank computes and regrids its own pixels (%s), disjoint slices -> rank 0"
+                                       % (world, "apron rows computed locally: halos routed one band further, no exchange with the neighbours"
+                                          if (not paint and sp_state.get('local_apron')) else ("no aprons" if paint else "apron rings exchanged"))
                                        if spatial else
                                        "halo shards x%d + RCCL all_to_all reduce-scatter by pixel slices, apron-ring exchange, banded gathering regrid on "
                                        "every rank, disjoint slices -> rank 0" % world

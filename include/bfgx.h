@@ -232,6 +232,11 @@ int  bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0,
  * clipped.  No accumulator travels between the ranks; the regrid then needs the neighbours' apron rings as above. */
 int  bfgx_plan_tile_shape(bfgx_plan *p, int32_t *rings_per_band, int32_t *max_columns);     /* band b = rings [1 + b R, 1 + (b + 1) R) */
 int  bfgx_disc_rings_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t *rings_dev /* [n][2]; n may exceed the plan's max_halos */);
+/* rings by which bfgx_disc_rings_device widens every (non-empty) range from now on (default 0).  With a margin of one band
+ * (bfgx_plan_tile_shape) a rank receives the halos of the bands next to its own as well and can compute the apron rows of its regrid
+ * itself (bfgx_offsets_bands_device over [band0 - 1, band1 + 1)) instead of exchanging them with its neighbours: one collective less
+ * per pass for ~2 bands of extra K1 work (valid while the reach, at most 16 rings, fits into a band). */
+int  bfgx_plan_set_route_margin(bfgx_plan *p, int32_t rings);
 /* Routing of halos that start out scattered over the ranks: ring_bounds[j] (host, world + 1 ascending entries) = first ring of rank
  * j's run of bands; a halo goes to every rank whose rings its range [first, last] (rings_dev, bfgx_disc_rings_device) touches.
  * Pass 1 counts the halos per destination (counts_dev[world]); the caller forms the exclusive prefix `start` (host) and exchanges the
