@@ -1566,8 +1566,8 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     double sums[2] = {0, 0};
     // Large maps travel in band ranges (contiguous RING pixel ranges): a range is regridded as soon as it and its apron have arrived
     // and goes back to the host while the next ones are still coming in, so that the two directions of the link work at the same
-    // time.  The gathering regrid stores
-    // every pixel of a range exactly once; the few deposits it cannot gather (next to a pole) are listed and added on the host.
+    // time.  The gathering regrid stores every pixel of a range exactly once; the few deposits it cannot gather (next to a pole) are
+    // listed and added on the host.
     // Range size: copies below ~16 MB take a slower path here (8 ranges of 12.6 MB: 4.0 ms per call, 6 of 16.8 MB: 3.3 ms), so a map is cut
     // into ranges of at least that, at most 16 of them; both host buffers are page-locked for the duration of the call (hipHostRegister:
     // 2 us here) -- from pageable memory the copies in and out take turns on the host thread and the one-pass route below is faster
