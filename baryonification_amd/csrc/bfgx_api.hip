@@ -839,7 +839,7 @@ static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const d
     const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
     {
         KernelTimer kt(p, BFGX_K_REGRID);
-        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float));
+        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float), p->band_reach > 1);
         // virtual bases: the kernel indexes every array by global pixel number
         double *out_base = out_slice_dev - p0;
         // every rank gathers with the same fixed reach (so that all of them classify a source pixel the same way)
@@ -1144,7 +1144,7 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
 template <typename ACC, typename real>
 static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const ACC *o, double *map_out_dev, double *ts, bool from_k1, double *sums_dev)
 {
-    const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real));
+    const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real)), lds_walk = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real), true);
     FarList far = p->far;
     far.overflow = p->far_overflow_full;
     const int nt = p->tiling.ntiles, nfix = std::min(nt, 2 * p->num_cus), nwalk = std::min(nt, 4 * p->num_cus);
@@ -1155,7 +1155,7 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
                        reach.cap, 0, nt, p->tile_apron, p->regrid_todo);
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0>), dim3(nt), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
-    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2>), dim3(nwalk), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2>), dim3(nwalk), dim3(256), lds_walk, p->stream, p->hpx, p->tiling, map_in_dev, o,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
     // the two sums of the mass check: added up by the last launch, or -- above 16384 tiles, where that single workgroup's loop
     // takes 0.2 - 0.6 ms -- by 64 workgroups afterwards

@@ -181,9 +181,16 @@ struct ReachArgs {
     double theta_first, theta_last;   // colatitude of the first / last ring
 };
 
-__host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size)
+// the walking kernel (PASS 2) compacts its source pixels: per wave a queue of kWalkQ survivors {position, offset, value}, per
+// workgroup a list of kWalkFar own pixels that take the generic route, per ring of the window two thresholds of the scan
+constexpr int kWalkQ = 128;         // entries per wave: a wave pushes at most 64 onto fewer than 64
+constexpr int kWalkFar = 256;       // far pixels listed per tile before the rest is evaluated in place
+__host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size, bool walk = false)
 {
-    return (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + 8 * real_size) + 16;
+    const size_t base = (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + 8 * real_size) + 16;
+    if (!walk) return base;
+    return base + (size_t)(BR + 2 * kReachMax + 2) * 2 * sizeof(float) + (size_t)(256 / kWave) * kWalkQ * (sizeof(double) + sizeof(int32_t) + 3 * real_size)
+           + (size_t)(kWalkFar + 4) * sizeof(int32_t);
 }
 
 // largest |o|^2 of the pixels of every tile (offsets that did not come from this plan's K1, which leaves it as a by-product)
@@ -357,9 +364,13 @@ __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<r
     if (!WALK || near) {                                                    // (!WALK: the tile's reach is one ring, the move is shorter)
         wtheta = down ? wq : (real)1 - wq;
     } else {                                                                // more than one ring: walk the table
+        // (the ring spacing changes by a few per cent over the reach: start from the move in units of the local spacing, then correct)
         const double d = (double)dth, th0 = rw.theta;
-        if (down) { while (t1 + 2 < NT && d >= rows[t1 + 1].theta - th0) ++t1; }
-        else      { while (t1 > 0 && d < rows[t1].theta - th0) --t1; }
+        const int stp = (int)(wq < (real)(2 * kReachMax) ? wq : (real)(2 * kReachMax));
+        t1 = down ? ti + stp : ti - 1 - stp;
+        t1 = t1 < 0 ? 0 : (t1 > NT - 2 ? NT - 2 : t1);
+        while (t1 + 2 < NT && d >= rows[t1 + 1].theta - th0) ++t1;
+        while (t1 > 0 && d < rows[t1].theta - th0) --t1;
         const double lo = rows[t1].theta - th0, hi = rows[t1 + 1].theta - th0;
         if (!(d >= lo && d < hi) || rows[t1].nr == 0 || rows[t1 + 1].nr == 0) return false;
         wtheta = (real)((d - lo) * fast_rcp(hi - lo));
@@ -531,7 +542,24 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             if (tid < NT - 1 && rows[tid + 1].nr > 0) rc.inv_dth_dn = (real)(1.0 / (rows[tid + 1].theta - rw.theta));
         }
         rowc[tid] = rc;
+        if (PASS == 2) {
+            // thresholds of the scan (below): a pixel of this ring reaches the tile only if it moves (a) beyond the ring next to the
+            // tile's first / last own ring -- |o| >= the colatitude it has to cross (the angle moved is at most asin |o|) -- and
+            // (b), from c columns outside the tile's span on its own ring, by more than c - 2.5 - nmax / nmin columns: a move of
+            // |o| is at most |o| / (sth - lim) nr / 2 pi columns (the arithmetic of tile_apron_kernel, per pixel instead of per tile)
+            float *rneed2 = reinterpret_cast<float *>(rowc + NTmax), *rcf2 = rneed2 + NTmax;
+            const int T0 = R + 1, T1 = R + (i1 - i0);                          // first / last own ring of the tile in the ring tables
+            double need = 0.0;
+            if (tid < T0 - 1 && rows[T0 - 1].nr > 0) need = rows[T0 - 1].theta - rw.theta;
+            else if (tid > T1 + 1 && rows[T1 + 1].nr > 0) need = rw.theta - rows[T1 + 1].theta;
+            const float nf = (rw.nr > 0 && need > 0.0) ? (float)(0.999 * need) : 0.0f;
+            rneed2[tid] = nf * nf;
+            const double den = rw.sth - fast_sqrt(rw.lim2);
+            const float cf = (rw.nr > 0 && den > 0.0) ? (float)(1.02 * rw.inv_dphi / den) : 3.0e18f;
+            rcf2[tid] = cf * cf;
+        }
     }
+    if (PASS == 2 && tid == 0) reinterpret_cast<int32_t *>(reinterpret_cast<float *>(rowc + NTmax) + 2 * NTmax)[0] = 0;       // far pixels listed by this tile
     __syncthreads();
     auto far_add = [&](int64_t p, double v) {
         if (PASS != 1) {
@@ -547,8 +575,11 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     // (in a short ring the apron is what is left of the ring, split between the two sides, so that no pixel is visited twice)
     const int NR = T.BR + 2 * R;
     const real reach_sp = (real)(0.999 * 2.0 / (3.0 * (double)h.nside));      // a lower bound of every ring spacing
-    int maxspan = 0;
-    for (int i = 1; i <= NR; ++i) maxspan = max(maxspan, rows[i].ke - rows[i].ks);
+    int maxspan = 0, nrmin = 0x7fffffff, nrmax = 1;
+    for (int i = 1; i <= NR; ++i) {
+        maxspan = max(maxspan, rows[i].ke - rows[i].ks);
+        if (PASS == 2 && rows[i].nr > 0) { nrmin = min(nrmin, rows[i].nr); nrmax = max(nrmax, rows[i].nr); }
+    }
     const int LWs = maxspan + 2 * kap;
     const unsigned inv_lws = (unsigned)((0x100000000ull + (unsigned)LWs - 1u) / (unsigned)LWs);      // idx / LWs for idx < 2^16
     struct Src { int ti, x; bool ok, own; double val; ACC o0, o1, o2; };
@@ -575,6 +606,120 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         }
         return sx;
     };
+    if constexpr (PASS == 2) {
+        // ---- the tile's window with a reach of several rings holds 2 - 3 source pixels per stored one, most of which cannot reach the
+        // tile.  SCAN: every wave tests 64 window pixels at a time with two comparisons of |o|^2 (thresholds above) and pushes the
+        // survivors {position, offset, value} onto its own LDS queue; whenever 64 have come together they are taken off the top and
+        // EVALUATED one per lane (the displaced position, the ring walk, four LDS adds): the costly half runs on full waves and on
+        // ~1.3 pixels per stored one.  Own pixels that take the generic route are listed per tile and evaluated together at the end.
+        const int lane = tid & (kWave - 1), wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+        const float *rneed2 = reinterpret_cast<const float *>(rowc + NTmax), *rcf2 = rneed2 + NTmax;
+        int32_t *nfar = reinterpret_cast<int32_t *>(const_cast<float *>(rcf2) + NTmax), *farq = nfar + 4;
+        double *qval = reinterpret_cast<double *>(farq + kWalkFar) + wid * kWalkQ;
+        real *qo = reinterpret_cast<real *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ) + wid * 3 * kWalkQ;
+        int32_t *qpos = reinterpret_cast<int32_t *>(reinterpret_cast<real *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ)
+                                                    + (256 / kWave) * 3 * kWalkQ) + wid * kWalkQ;
+        const float colslack = 2.5f + (float)nrmax / (float)nrmin;
+        const int nown = i1 - i0, total = NR * LWs;
+        auto deposit = [&](int ti, int x, real o0, real o1, real o2, double val) {
+            int tt[4], tk[4];
+            real w[4];
+            if (!regrid_gather_targets<real, true>(rows, rowc, NT, ti, x, o0, o1, o2, tt, tk, w)) return;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
+                const int rr = tt[q4] - (R + 1);
+                if (rr >= 0 && rr < nown) {
+                    const RegRow &rt = rows[tt[q4]];
+                    if (tk[q4] >= rt.ks && tk[q4] < rt.ke) {
+                        const double v = (double)w[q4] * val;
+                        atomicAdd(acc + rr * T.W + (tk[q4] - rt.ks), v);
+                        sum_out += v;
+                    }
+                }
+            }
+        };
+        auto far_eval = [&](int ti, int x, double f0, double f1, double f2, double val) {      // the owner of the source pixel lists its deposits
+            int tr[4], tk[4];
+            double w[4];
+            regrid_targets_generic(h, rows, NT - 2, rth0, ti, x, f0, f1, f2, tr, tk, w);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                int64_t st_t, nr64; bool sh_t;
+                ring_info_small(h, tr[q4], st_t, nr64, sh_t);
+                far_add(st_t + tk[q4], w[q4] * val);
+            }
+        };
+        int qn = 0;                                                            // entries in this wave's queue (wave-uniform)
+        for (int base = wid * kWave; base < total; base += 256) {
+            const int idx = base + lane;
+            bool push = false;
+            int pos = 0;
+            real o0 = (real)0, o1 = (real)0, o2 = (real)0;
+            double val = 0.0;
+            if (idx < total) {
+                const int r = (int)__umulhi((unsigned)idx, inv_lws), x = idx - r * LWs - kap;
+                const RegRow &rw = rows[r + 1];
+                const int span = rw.ke - rw.ks, rest = rw.nr - span;
+                const int kl = min(kap, rest >> 1), kr = min(kap, rest - kl);
+                if (rw.nr > 0 && x >= -kl && x < span + kr) {
+                    int k = rw.ks + x;
+                    if (k < 0) k += rw.nr;
+                    if (k >= rw.nr) k -= rw.nr;
+                    const int64_t p = rw.start + k;
+                    const bool own = (r >= R) && (r < R + nown) && (x >= 0) && (x < span);
+                    val = map_in[p];
+                    const ACC a0 = offsets[3 * p + 0], a1 = offsets[3 * p + 1], a2 = offsets[3 * p + 2];
+                    if (own) sum_in += val;
+                    if (val > 0.0) {                                           // HealpixRunner.py:335
+                        o0 = (real)a0; o1 = (real)a1; o2 = (real)a2;
+                        const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
+                        if ((double)osq < rw.lim2) {                           // a gathered pixel
+                            bool reaches = own;
+                            if (!own) {
+                                const int dc = x < 0 ? -x : (x >= span ? x - span + 1 : 0);
+                                const float g = (float)dc - colslack, of = (float)osq;
+                                reaches = of >= rneed2[r + 1] && (g <= 0.0f || of * rcf2[r + 1] >= g * g);
+                            }
+                            push = reaches;
+                            pos = ((r + 1) << 16) | (x + kap);
+                        } else if (own) {
+                            const int slot = atomicAdd(nfar, 1);
+                            if (slot < kWalkFar) farq[slot] = ((r + 1) << 16) | (x + kap);
+                            else far_eval(r + 1, x, (double)a0, (double)a1, (double)a2, val);
+                        }
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(push);
+            if (m == 0ull) continue;                                           // (wave-uniform)
+            if (push) {
+                const int sl = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                qval[sl] = val; qo[sl] = o0; qo[kWalkQ + sl] = o1; qo[2 * kWalkQ + sl] = o2; qpos[sl] = pos;
+            }
+            qn += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= kWave) {
+                qn -= kWave;
+                const int sl = qn + lane, pk = qpos[sl];
+                deposit(pk >> 16, (pk & 0xffff) - kap, qo[sl], qo[kWalkQ + sl], qo[2 * kWalkQ + sl], qval[sl]);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane < qn) {
+            const int pk = qpos[lane];
+            deposit(pk >> 16, (pk & 0xffff) - kap, qo[lane], qo[kWalkQ + lane], qo[2 * kWalkQ + lane], qval[lane]);
+        }
+        __syncthreads();
+        const int nlisted = min(*nfar, kWalkFar);
+        for (int e = tid; e < nlisted; e += 256) {
+            const int pk = farq[e], ti = pk >> 16, x = (pk & 0xffff) - kap;
+            const RegRow &rw = rows[ti];
+            int k = rw.ks + x;
+            if (k < 0) k += rw.nr;
+            if (k >= rw.nr) k -= rw.nr;
+            const int64_t p = rw.start + k;
+            far_eval(ti, x, (double)offsets[3 * p + 0], (double)offsets[3 * p + 1], (double)offsets[3 * p + 2], map_in[p]);
+        }
+    } else
     for (int idx = tid; idx < NR * LWs; idx += 256) {
         const Src cur = fetch(idx);
         if (cur.ok && cur.own) sum_in += cur.val;
