@@ -15,6 +15,7 @@ BFGX_MAX_DIM = 3 + BFGX_MAX_EXTRA
 KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin', 'wide')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 3        # include/bfgx.h BFGX_ABI_VERSION: 3 since bfgx_opts carries catalog_token (32 bytes)
 LIB_PATH = os.environ.get('BFGX_LIB', os.path.join(_HERE, 'csrc', 'libbfgx.so'))   # BFGX_LIB: ablation builds only
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS, ERR_ASSERT = 0, -1, -2, -3, -4, -5, -6
@@ -123,6 +124,7 @@ SYMBOLS = {
     'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_plan_set_algo': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_status': (C.c_int, [C.c_void_p]),
+    'bfgx_plan_regrid_stats': (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     'bfgx_plan_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_timing_read': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_project_profile': (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p]),
@@ -217,8 +219,8 @@ def load():
             fn = getattr(L, name)        # AttributeError here = ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
-        if L.bfgx_abi_version() != 2:
-            raise ImportError("libbfgx.so ABI version %d != 2" % L.bfgx_abi_version())
+        if L.bfgx_abi_version() != ABI_VERSION:
+            raise ImportError("libbfgx.so ABI version %d != %d (a stale build? run `make -C baryonification_amd/csrc`)" % (L.bfgx_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -916,6 +916,32 @@ int bfgx_plan_far_fetch(bfgx_plan *p, int64_t cap, int64_t *pix_host, double *va
     return BFGX_OK;
 }
 
+int bfgx_plan_regrid_stats(bfgx_plan *p, int64_t *far_listed, int32_t *far_overflowed, int32_t *tiles_walked, int32_t *max_reach_rings)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "regrid statistics exist for the tiled algorithm (algo 1) only");
+    HIP_TRY(hipSetDevice(p->device));
+    int32_t ctrl[4] = {0, 0, 0, 0};                          // far count (64 bits), overflow of the full-map list, tiles left to the walking kernel
+    HIP_TRY(hipMemcpyAsync(ctrl, p->far.count, sizeof(ctrl), hipMemcpyDeviceToHost, p->stream));
+    std::vector<int32_t> apron;
+    if (max_reach_rings) {
+        apron.resize(2 * (size_t)p->tiling.ntiles);
+        HIP_TRY(hipMemcpyAsync(apron.data(), p->tile_apron, sizeof(int32_t) * apron.size(), hipMemcpyDeviceToHost, p->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    unsigned long long n = 0;
+    std::memcpy(&n, ctrl, sizeof(n));
+    if (far_listed) *far_listed = (int64_t)n;
+    if (far_overflowed) *far_overflowed = ctrl[2];
+    if (tiles_walked) *tiles_walked = ctrl[3];
+    if (max_reach_rings) {
+        int32_t m = 0;
+        for (int t = 0; t < p->tiling.ntiles; ++t) m = std::max(m, apron[2 * (size_t)t]);
+        *max_reach_rings = m;
+    }
+    return BFGX_OK;
+}
+
 int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev, int acc_f64)
 {
     if (int rc = check_catalog(p, cat)) return rc;

@@ -145,6 +145,12 @@ template <> struct RMath<double> {
 // The apron of a tile follows the data: tile_reach_kernel leaves the largest |o| of every tile, a tile takes the maximum m
 // over the tiles around it and evaluates R = regrid_reach_rings(m) rings and K columns beyond its own pixels -- 1 ring and
 // 4 columns (1.2x the evaluations) for sub-pixel displacements, more only where the map really moves that far.
+#ifndef BFGX_ABLK2
+#define BFGX_ABLK2 0                // timing-only ablation builds of the walking kernel (scripts/k2_variants.sh)
+#endif
+#ifndef BFGX_K2U
+#define BFGX_K2U 2
+#endif
 constexpr int kReachMax = 16;       // most rings a gathered deposit travels; the ring tables hold BR + 2 kReachMax + 2 rings
 constexpr int kReachColsMax = 256;  // most apron columns per side
 
@@ -166,6 +172,13 @@ __host__ __device__ inline double regrid_cap_for_rings(int64_t nside, int R)
     const double c = 0.999 * (double)R / (1.5 * (double)nside), cap = regrid_cap(nside);
     return (R >= kReachMax || c > cap) ? cap : c;
 }
+
+// what the scan of the walking kernel needs of one ring of the window (one 32-byte LDS read)
+struct alignas(16) RowScan {
+    int32_t start, nr, ks, span;          // first pixel of the ring, its length, the tile's first column and width in it (nr == 0: no such ring)
+    float need2, cf2, lim2;               // thresholds on |o|^2: (colatitude to cross)^2, (columns per radian moved)^2, gathered iff |o|^2 < lim2
+    int32_t klr;                          // columns scanned left | right << 10 of the span, | 1 << 20 for the tile's own rings
+};
 
 struct FarList {
     unsigned long long *count;    // entries appended (may exceed cap: overflow)
@@ -189,7 +202,7 @@ __host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_s
 {
     const size_t base = (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + 8 * real_size) + 16;
     if (!walk) return base;
-    return base + (size_t)(BR + 2 * kReachMax + 2) * 2 * sizeof(float) + (size_t)(256 / kWave) * kWalkQ * (sizeof(double) + sizeof(int32_t) + 3 * real_size)
+    return base + (size_t)(BR + 2 * kReachMax + 2) * sizeof(RowScan) + (size_t)(256 / kWave) * kWalkQ * (sizeof(double) + sizeof(int32_t) + 3 * real_size)
            + (size_t)(kWalkFar + 4) * sizeof(int32_t);
 }
 
@@ -526,7 +539,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             sincos_bounded(((double)rw.ks + (shf_ ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
             // gathered <=> |o|^2 < lim2
             const double lim = fmin(fmin(reach.cap, 0.09 * rw.sth), 0.999 * fmin(rw.theta - reach.theta_first, reach.theta_last - rw.theta));
-            rw.lim2 = (lim > 0.0 && ring > 1 && ring < nl4 - 1) ? lim * lim : 0.0;
+            rw.lim2 = (lim > 0.0 && ring > 1 && ring < nl4 - 1) ? (double)(float)(lim * lim) : 0.0;      // (a float: the walking kernel's scan compares in fp32)
         }
         rows[tid] = rw;
     }
@@ -547,19 +560,24 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             // tile's first / last own ring -- |o| >= the colatitude it has to cross (the angle moved is at most asin |o|) -- and
             // (b), from c columns outside the tile's span on its own ring, by more than c - 2.5 - nmax / nmin columns: a move of
             // |o| is at most |o| / (sth - lim) nr / 2 pi columns (the arithmetic of tile_apron_kernel, per pixel instead of per tile)
-            float *rneed2 = reinterpret_cast<float *>(rowc + NTmax), *rcf2 = rneed2 + NTmax;
+            RowScan *scan = reinterpret_cast<RowScan *>(rowc + NTmax);
             const int T0 = R + 1, T1 = R + (i1 - i0);                          // first / last own ring of the tile in the ring tables
             double need = 0.0;
             if (tid < T0 - 1 && rows[T0 - 1].nr > 0) need = rows[T0 - 1].theta - rw.theta;
             else if (tid > T1 + 1 && rows[T1 + 1].nr > 0) need = rw.theta - rows[T1 + 1].theta;
             const float nf = (rw.nr > 0 && need > 0.0) ? (float)(0.999 * need) : 0.0f;
-            rneed2[tid] = nf * nf;
             const double den = rw.sth - fast_sqrt(rw.lim2);
             const float cf = (rw.nr > 0 && den > 0.0) ? (float)(1.02 * rw.inv_dphi / den) : 3.0e18f;
-            rcf2[tid] = cf * cf;
+            const int span = rw.ke - rw.ks, rest = rw.nr - span;
+            const int kl = min(kap, rest >> 1), kr = min(kap, rest - kl);     // (a short ring: what is left of it, split between the two sides)
+            RowScan rs;
+            rs.start = (int32_t)rw.start; rs.nr = rw.nr; rs.ks = rw.ks; rs.span = span;
+            rs.need2 = nf * nf; rs.cf2 = cf * cf; rs.lim2 = (float)rw.lim2;
+            rs.klr = kl | (kr << 10) | ((tid >= T0 && tid <= T1) ? (1 << 20) : 0);
+            scan[tid] = rs;
         }
     }
-    if (PASS == 2 && tid == 0) reinterpret_cast<int32_t *>(reinterpret_cast<float *>(rowc + NTmax) + 2 * NTmax)[0] = 0;       // far pixels listed by this tile
+    if (PASS == 2 && tid == 0) reinterpret_cast<int32_t *>(reinterpret_cast<RowScan *>(rowc + NTmax) + NTmax)[0] = 0;       // far pixels listed by this tile
     __syncthreads();
     auto far_add = [&](int64_t p, double v) {
         if (PASS != 1) {
@@ -574,7 +592,6 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     // source pixels: the tile's rings +- R, its columns +- K (a tile that spans whole rings has no column apron)
     // (in a short ring the apron is what is left of the ring, split between the two sides, so that no pixel is visited twice)
     const int NR = T.BR + 2 * R;
-    const real reach_sp = (real)(0.999 * 2.0 / (3.0 * (double)h.nside));      // a lower bound of every ring spacing
     int maxspan = 0, nrmin = 0x7fffffff, nrmax = 1;
     for (int i = 1; i <= NR; ++i) {
         maxspan = max(maxspan, rows[i].ke - rows[i].ks);
@@ -613,8 +630,8 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         // EVALUATED one per lane (the displaced position, the ring walk, four LDS adds): the costly half runs on full waves and on
         // ~1.3 pixels per stored one.  Own pixels that take the generic route are listed per tile and evaluated together at the end.
         const int lane = tid & (kWave - 1), wid = __builtin_amdgcn_readfirstlane(tid / kWave);
-        const float *rneed2 = reinterpret_cast<const float *>(rowc + NTmax), *rcf2 = rneed2 + NTmax;
-        int32_t *nfar = reinterpret_cast<int32_t *>(const_cast<float *>(rcf2) + NTmax), *farq = nfar + 4;
+        const RowScan *scan = reinterpret_cast<const RowScan *>(rowc + NTmax);
+        int32_t *nfar = reinterpret_cast<int32_t *>(const_cast<RowScan *>(scan) + NTmax), *farq = nfar + 4;
         double *qval = reinterpret_cast<double *>(farq + kWalkFar) + wid * kWalkQ;
         real *qo = reinterpret_cast<real *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ) + wid * 3 * kWalkQ;
         int32_t *qpos = reinterpret_cast<int32_t *>(reinterpret_cast<real *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ)
@@ -624,6 +641,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         auto deposit = [&](int ti, int x, real o0, real o1, real o2, double val) {
             int tt[4], tk[4];
             real w[4];
+            if (BFGX_ABLK2 == 1) return;
             if (!regrid_gather_targets<real, true>(rows, rowc, NT, ti, x, o0, o1, o2, tt, tk, w)) return;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
@@ -633,7 +651,6 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                     if (tk[q4] >= rt.ks && tk[q4] < rt.ke) {
                         const double v = (double)w[q4] * val;
                         atomicAdd(acc + rr * T.W + (tk[q4] - rt.ks), v);
-                        sum_out += v;
                     }
                 }
             }
@@ -649,59 +666,64 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             }
         };
         int qn = 0;                                                            // entries in this wave's queue (wave-uniform)
-        for (int base = wid * kWave; base < total; base += 256) {
-            const int idx = base + lane;
-            bool push = false;
-            int pos = 0;
-            real o0 = (real)0, o1 = (real)0, o2 = (real)0;
-            double val = 0.0;
-            if (idx < total) {
-                const int r = (int)__umulhi((unsigned)idx, inv_lws), x = idx - r * LWs - kap;
-                const RegRow &rw = rows[r + 1];
-                const int span = rw.ke - rw.ks, rest = rw.nr - span;
-                const int kl = min(kap, rest >> 1), kr = min(kap, rest - kl);
-                if (rw.nr > 0 && x >= -kl && x < span + kr) {
-                    int k = rw.ks + x;
-                    if (k < 0) k += rw.nr;
-                    if (k >= rw.nr) k -= rw.nr;
-                    const int64_t p = rw.start + k;
-                    const bool own = (r >= R) && (r < R + nown) && (x >= 0) && (x < span);
-                    val = map_in[p];
-                    const ACC a0 = offsets[3 * p + 0], a1 = offsets[3 * p + 1], a2 = offsets[3 * p + 2];
-                    if (own) sum_in += val;
-                    if (val > 0.0) {                                           // HealpixRunner.py:335
-                        o0 = (real)a0; o1 = (real)a1; o2 = (real)a2;
-                        const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
-                        if ((double)osq < rw.lim2) {                           // a gathered pixel
-                            bool reaches = own;
-                            if (!own) {
-                                const int dc = x < 0 ? -x : (x >= span ? x - span + 1 : 0);
-                                const float g = (float)dc - colslack, of = (float)osq;
-                                reaches = of >= rneed2[r + 1] && (g <= 0.0f || of * rcf2[r + 1] >= g * g);
-                            }
-                            push = reaches;
-                            pos = ((r + 1) << 16) | (x + kap);
-                        } else if (own) {
-                            const int slot = atomicAdd(nfar, 1);
-                            if (slot < kWalkFar) farq[slot] = ((r + 1) << 16) | (x + kap);
-                            else far_eval(r + 1, x, (double)a0, (double)a1, (double)a2, val);
-                        }
-                    }
+        constexpr int U = BFGX_K2U;                                                   // window pixels per lane and trip: 2 U loads in flight
+        const int64_t pdummy = rows[R + 1].start + rows[R + 1].ks;             // (a pixel this tile may read, for the lanes without one)
+        for (int base = wid * kWave; base < total; base += 256 * U) {
+            int cpos[U], cx[U], cspan[U];
+            bool cin[U], cown[U];
+            float cneed2[U], ccf2[U], clim2[U];
+            ACC ca0[U], ca1[U], ca2[U];
+            double cval[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                      // positions, all loads issued
+                const int idx = base + u * 256 + lane, idc = min(idx, total - 1);
+                const int r = (int)__umulhi((unsigned)idc, inv_lws), x = idc - r * LWs - kap;
+                const RowScan rs = scan[r + 1];
+                cx[u] = x; cpos[u] = ((r + 1) << 16) | (x + kap); cspan[u] = rs.span;
+                cneed2[u] = rs.need2; ccf2[u] = rs.cf2; clim2[u] = rs.lim2;
+                cin[u] = idx < total && rs.nr > 0 && x >= -(rs.klr & 1023) && x < rs.span + ((rs.klr >> 10) & 1023);
+                cown[u] = cin[u] && (rs.klr >> 20) && x >= 0 && x < rs.span;
+                int k = rs.ks + x;
+                k += (k < 0) ? rs.nr : 0;
+                k -= (k >= rs.nr) ? rs.nr : 0;
+                const int64_t p = cin[u] ? (int64_t)(rs.start + k) : pdummy;
+                ca0[u] = offsets[3 * p + 0]; ca1[u] = offsets[3 * p + 1]; ca2[u] = offsets[3 * p + 2];
+                cval[u] = map_in[p];
+            }
+            bool cpush[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                      // the two thresholds
+                const int x = cx[u];
+                if (cown[u]) sum_in += cval[u];
+                const real o0 = (real)ca0[u], o1 = (real)ca1[u], o2 = (real)ca2[u];
+                const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
+                const bool live = cin[u] && cval[u] > 0.0;                     // HealpixRunner.py:335
+                const bool gathered = osq < (real)clim2[u];
+                const int dc = x < 0 ? -x : (x >= cspan[u] ? x - cspan[u] + 1 : 0);
+                const float g = (float)dc - colslack, of = (float)osq;
+                const bool reaches = cown[u] || (of >= cneed2[u] && (g <= 0.0f || of * ccf2[u] >= g * g));
+                cpush[u] = live && gathered && reaches;
+                if (live && !gathered && cown[u]) {                            // rare: the generic route, listed per tile
+                    const int slot = atomicAdd(nfar, 1);
+                    if (slot < kWalkFar) farq[slot] = cpos[u];
                 }
             }
-            const unsigned long long m = __ballot(push);
-            if (m == 0ull) continue;                                           // (wave-uniform)
-            if (push) {
-                const int sl = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                qval[sl] = val; qo[sl] = o0; qo[kWalkQ + sl] = o1; qo[2 * kWalkQ + sl] = o2; qpos[sl] = pos;
-            }
-            qn += __popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            if (qn >= kWave) {
-                qn -= kWave;
-                const int sl = qn + lane, pk = qpos[sl];
-                deposit(pk >> 16, (pk & 0xffff) - kap, qo[sl], qo[kWalkQ + sl], qo[2 * kWalkQ + sl], qval[sl]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                      // survivors onto the queue; a full wave of them evaluated
+                const unsigned long long m = __ballot(cpush[u]);
+                if (m == 0ull) continue;                                       // (wave-uniform)
+                if (cpush[u]) {
+                    const int sl = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    qval[sl] = cval[u]; qo[sl] = (real)ca0[u]; qo[kWalkQ + sl] = (real)ca1[u]; qo[2 * kWalkQ + sl] = (real)ca2[u]; qpos[sl] = cpos[u];
+                }
+                qn += __popcll(m);
                 __builtin_amdgcn_wave_barrier();
+                if (qn >= kWave) {
+                    qn -= kWave;
+                    const int sl = qn + lane, pk = qpos[sl];
+                    deposit(pk >> 16, (pk & 0xffff) - kap, qo[sl], qo[kWalkQ + sl], qo[2 * kWalkQ + sl], qval[sl]);
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         if (lane < qn) {
@@ -709,15 +731,32 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             deposit(pk >> 16, (pk & 0xffff) - kap, qo[lane], qo[kWalkQ + lane], qo[2 * kWalkQ + lane], qval[lane]);
         }
         __syncthreads();
-        const int nlisted = min(*nfar, kWalkFar);
-        for (int e = tid; e < nlisted; e += 256) {
-            const int pk = farq[e], ti = pk >> 16, x = (pk & 0xffff) - kap;
+        // the far pixels of the tile: from the list, or -- more of them than it holds -- by a sweep over the tile's own pixels
+        const int nf = *nfar;
+        const bool sweep = nf > kWalkFar;
+        const int ncand = sweep ? nown * maxspan : nf;
+        for (int e = tid; e < ncand; e += 256) {
+            int ti, x;
+            if (sweep) {
+                const int rr = e / maxspan;
+                ti = R + 1 + rr; x = e - rr * maxspan;
+                if (x >= rows[ti].ke - rows[ti].ks) continue;
+            } else {
+                const int pk = farq[e];
+                ti = pk >> 16; x = (pk & 0xffff) - kap;
+            }
             const RegRow &rw = rows[ti];
             int k = rw.ks + x;
             if (k < 0) k += rw.nr;
             if (k >= rw.nr) k -= rw.nr;
             const int64_t p = rw.start + k;
-            far_eval(ti, x, (double)offsets[3 * p + 0], (double)offsets[3 * p + 1], (double)offsets[3 * p + 2], map_in[p]);
+            const double val = map_in[p];
+            const ACC a0 = offsets[3 * p + 0], a1 = offsets[3 * p + 1], a2 = offsets[3 * p + 2];
+            if (sweep) {
+                const real o0 = (real)a0, o1 = (real)a1, o2 = (real)a2;
+                if (!(val > 0.0) || (double)fma_(o0, o0, fma_(o1, o1, o2 * o2)) < rw.lim2) continue;
+            }
+            far_eval(ti, x, (double)a0, (double)a1, (double)a2, val);
         }
     } else
     for (int idx = tid; idx < NR * LWs; idx += 256) {
@@ -730,18 +769,9 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         const bool gathered = (double)osq < rows[cur.ti].lim2;
         if (gathered) {
             if (PASS == 1) continue;
-            if (PASS == 2) {
-                // an apron pixel d rings above / below the tile reaches it only by moving at least d - 1 ring spacings
-                // (>= 2 / (3 nside) each): most pixels of a deep apron are dismissed by this comparison
-                const int rt = cur.ti - (R + 1), dr = rt < 0 ? -rt : (rt >= i1 - i0 ? rt - (i1 - i0) + 1 : 0);
-                if (dr > 1) {
-                    const real need = (real)(dr - 1) * reach_sp;
-                    if (osq < need * need) continue;
-                }
-            }
             int tt[4], tk[4];
             real w[4];
-            if (!regrid_gather_targets<real, PASS == 2>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) continue;
+            if (!regrid_gather_targets<real, false>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) continue;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
                 const int rr = tt[q4] - (R + 1);
@@ -750,7 +780,6 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                     if (tk[q4] >= rt.ks && tk[q4] < rt.ke) {
                         const double v = (double)w[q4] * val;
                         atomicAdd(acc + rr * T.W + (tk[q4] - rt.ks), v);
-                        sum_out += v;
                     }
                 }
             }
@@ -774,7 +803,11 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         const RegRow &rt = rows[rr + R + 1];
         double *dst = map_out + rt.start + rt.ks;
         const int n = rt.ke - rt.ks;
-        for (int xx = lane; xx < n; xx += kWave) dst[xx] = acc[rr * T.W + xx];
+        for (int xx = lane; xx < n; xx += kWave) {
+            const double v = acc[rr * T.W + xx];
+            dst[xx] = v;
+            sum_out += v;                                   // (the deposits that landed in this tile: summed here, once per pixel)
+        }
     }
     if (tile_sums) {
         __syncthreads();                                   // acc is free again: reuse its first words for the block reduction

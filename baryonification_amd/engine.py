@@ -173,6 +173,12 @@ class ShellPlan(object):
     def status(self):
         _lib.check(_lib.load().bfgx_plan_status(self._h))
 
+    def regrid_stats(self):
+        """what the last full-map regrid did (blocking): far deposits listed, list overflowed, tiles run by the walking kernel, largest reach"""
+        far, ovf, walked, reach = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.load().bfgx_plan_regrid_stats(self._h, C.byref(far), C.byref(ovf), C.byref(walked), C.byref(reach)))
+        return {"far_listed": int(far.value), "far_overflowed": bool(ovf.value), "tiles_walked": int(walked.value), "max_reach_rings": int(reach.value)}
+
     def timing_enable(self, on=True):
         _lib.check(_lib.load().bfgx_plan_timing_enable(self._h, int(on)))
 

@@ -78,6 +78,9 @@ def parse():
                     help="N > 1: 'spatial' (default) = halos routed to the owners of the ring bands their discs touch, no accumulator "
                          "crosses a link; 'slices' = halo shards + all_to_all reduce-scatter of pix_offsets by pixel slices + banded regrid; "
                          "'reduce' = halo shards + one reduce(sum) of the whole accumulator to rank 0")
+    ap.add_argument('--no-check', action='store_true',
+                    help="N > 1 (strong scaling): skip the comparison of the assembled map with ONE single-GPU pass over the whole catalog "
+                         "(outside the timed region; the line's `check` object, non-zero exit above 2e-6 of the map's scale)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket the kernels with HIP events in the timed region (no roofline object)')
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='halos in the CPU-oracle sample (single-thread baseline)')
@@ -441,10 +444,17 @@ def main():
         if rank == 0:
             out["value_weak"] = {k: w[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling", "mass_conserved")}
             out["value_weak"]["workload"] = w["config"]["workload"]
+    rc = 0
     if rank == 0:
         print(json.dumps(out), flush=True)
+        if out.get("check") is not None and not out["check"]["ok"]:
+            print("bench: the assembled map differs from the single-GPU pass by %.3e (> %.3e): exit 4" % (
+                out["check"]["max_abs_diff_vs_single_gpu"], out["check"]["tolerance"]), file=sys.stderr, flush=True)
+            rc = 4
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 def shell_line(args, ctx, scaling, brief):
@@ -528,9 +538,28 @@ def shell_line(args, ctx, scaling, brief):
         # that no count is read back by the host inside a step (the catalog is shuffled, Parallelize.py:255: a destination receives about
         # nh / world halos from every source; 1.75 x that + 2048 leaves room for the halos of the two neighbouring bands too).  An overflow is detected on the device, checked after the
         # untimed trial step and answered with the variable-split routing (route_halos: one read-back per step)
-        blockcap = int((1.75 if world > 1 else 1.5) * np.ceil(np.ceil(total_halos / world) / world)) + 2048     # (the same on every rank: shards differ by one halo;
-        #                                                                                  1.75: a rank also takes the halos of the bands next to its own)
-        cap = max(world * blockcap, 2 * int(np.ceil(total_halos / world)) + 4096)
+        # The capacity comes from ONE untimed count pass (bfgx_route_count_device) with the widest routing a step may use (every halo one
+        # band further: the bands next to a rank's own are computed locally when the reach fits, below): the largest (source,
+        # destination) count over all ranks, rounded up -- round 3 guessed 1.75 x the mean and K0 ran over 1.9 padded rows per real one
+        d_probe = torch.empty((nh, 2), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(world, dtype=torch.int32, device=dev)
+        plan.set_route_margin(0 if paint else plan.tile_shape()[0])
+        plan.disc_rings(cat_dev, d_probe.data_ptr())
+        plan.route_count(nh, d_probe.data_ptr(), rb, cnt.data_ptr())
+        plan.set_route_margin(0)
+        cnt64 = cnt.to(torch.int64) if backend == 'nccl' else cnt.to(torch.int64).cpu()
+        rows_mat = [torch.zeros_like(cnt64) for _ in range(world)]
+        if dist.is_initialized():
+            dist.all_gather(rows_mat, cnt64)
+        else:
+            rows_mat = [cnt64]
+        rows_mat = torch.stack(rows_mat).cpu().numpy()                       # [source][destination], the same on every rank
+        blockcap = (int(rows_mat.max()) + 255) // 256 * 256 + 256
+        routing_rows = {"real_rank0": int(rows_mat[:, 0].sum()), "padded_per_rank": world * blockcap,
+                        "real_max_rank": int(rows_mat.sum(axis=0).max()), "blockcap": blockcap,
+                        "sized_by": "one untimed count pass (route margin of one band), max over (source, destination) + 256, in 256s"}
+        del d_probe
+        cap = max(world * blockcap, int(rows_mat.sum(axis=0).max()) + 4096)
         plan_sp = engine.ShellPlan(model, keep, nside, cap, device=local_rank, stream=stream)
         d_rings = torch.empty((nh, 2), dtype=torch.int32, device=dev)
         cols_local = [t[k] for k in ('M', 'z', 'ra', 'dec', 'lnz', 'lnM')]
@@ -722,8 +751,8 @@ def shell_line(args, ctx, scaling, brief):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, steps, events):
-        tp = plan_sp if spatial else plan            # the plan whose kernels run in the step
+    def timed(step, steps, events, tp=None):
+        tp = tp if tp is not None else (plan_sp if spatial else plan)            # the plan whose kernels run in the step
         tp.timing_enable(events)
         fence()
         prof = None
@@ -768,6 +797,11 @@ def shell_line(args, ctx, scaling, brief):
             sys.stderr.flush()
             os._exit(3)
         if spatial:
+            if sp_state.get('local_apron'):
+                # the trial step routed with margin 0 and switched the wider routing on afterwards: one more untimed step so that the
+                # overflow flag below has seen the routing the timed steps use (the flag is sticky)
+                step()
+                fence()
             # did a routing block overflow on any rank (a catalog that is not shuffled, a sky patch)?  then route with variable splits
             ovf = route_work['overflow'].clone() if backend == 'nccl' else route_work['overflow'].cpu()
             if dist.is_initialized():
@@ -803,10 +837,21 @@ def shell_line(args, ctx, scaling, brief):
             print("bench: stage times of one synchronised step [ms]: %s" % json.dumps({k: round(v, 3) for k, v in stage_t.items()}), file=sys.stderr, flush=True)
     if os.environ.get('BFGX_BENCH_NOSTATUS') != '1':   # (timing-only ablation builds produce meaningless offsets)
         (plan_sp if spatial else plan).status()   # entry-list capacity, far-deposit list
+    if spatial and sp_state['fixed']:
+        # the overflow flag is sticky: a block that overflowed in ANY warm-up or timed step dropped halos silently (the map would still
+        # conserve mass): never report a number from such a run
+        ovf = route_work['overflow'].clone() if backend == 'nccl' else route_work['overflow'].cpu()
+        if dist.is_initialized():
+            dist.all_reduce(ovf, op=dist.ReduceOp.MAX)
+        if int(ovf.item()):
+            print("bench[rank %d]: a fixed-capacity routing block overflowed inside the timed steps: halos were dropped, no number reported" % rank,
+                  file=sys.stderr, flush=True)
+            os._exit(5)
     if (slices or spatial) and not paint:
         assert int(d_foreign.item()) == 0, "far deposits crossed a band boundary: use distributed_process(), which routes them"
     check = None
-    if os.environ.get('BFGX_BENCH_CHECK') == '1' and strong and (slices or spatial) and rank == 0:
+    want_check = (world > 1 and not args.no_check and not brief) or os.environ.get('BFGX_BENCH_CHECK') == '1'
+    if want_check and strong and (slices or spatial) and rank == 0:
         # self-check (tests): the map the ranks assembled on rank 0 against ONE single-GPU pass over the whole catalog (fp32 pair math
         # on both sides: they agree to the stated fp32 tolerance, most pixels exactly)
         full = syn.make_catalog(total_halos)
@@ -826,8 +871,11 @@ def shell_line(args, ctx, scaling, brief):
         pf.status()
         got = d_fin if (slices or spatial) else d_out
         scale = float(ref.abs().max().item()) if paint else float(ref.mean().item())
-        check = {"max_abs_diff_vs_single_gpu": float((got - ref).abs().max().item()), "scale": scale,
-                 "scale_is": "max |map|" if paint else "mean(map)"}
+        diff = float((got - ref).abs().max().item())
+        check = {"max_abs_diff_vs_single_gpu": diff, "scale": scale, "scale_is": "max |map|" if paint else "mean(map)",
+                 "tolerance": 2e-6 * scale, "ok": bool(diff <= 2e-6 * scale),
+                 "what": "the map the ranks assembled on rank 0 against ONE single-GPU pass over the whole catalog on rank 0's GPU (same "
+                         "arithmetic on both sides; outside the timed region)"}
         pf.close()
         del tf, ref
 
@@ -852,6 +900,57 @@ def shell_line(args, ctx, scaling, brief):
                                   "dtype": "f64 throughout (fp64 pair math, fp64 pix_offsets, fp64 regrid)"}
         del step64
         torch.cuda.empty_cache()
+        if args.table == 'closed-form':
+            # SURVEY 8(d) table (ii), the BENCHMARK table: the same step on the displacement table the GPU table builders (K4-K6) make from
+            # the Schneider19 one-halo profiles (default_config parameters, cdelta = 7, proj_cutoff = 50).  Its displacements are 1.9 pixels on
+            # average and 20 at most (the closed-form table's: < 0.2), so every tile of K2 runs in the walking kernel and 0.2 % of the
+            # pixels take the far list.  `value` stays the closed-form line so that rounds stay comparable.
+            table2 = syn.s19_displacement_table(z, M, r)
+            model2, keep2 = engine.model_from_tables(axes, table2, syn.COSMO, args.eps, args.eps)
+            plan2 = engine.ShellPlan(model2, keep2, nside, nh, device=local_rank, stream=stream)
+            plan2.set_algo(1)
+            d_off2 = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+
+            def step_s19():
+                plan2.baryonify(cat_dev, d_map.data_ptr(), d_off2.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=False)
+            for _ in range(5):
+                step_s19()
+            n19 = max(20, args.steps // 2)
+            el19, _ = timed(step_s19, n19, False, tp=plan2)
+            el19e, kt19 = timed(step_s19, n19, True, tp=plan2)
+            plan2.status()
+            st19 = plan2.regrid_stats()
+            d_off2 = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+
+            def step_s19_f64():
+                plan2.baryonify(cat_dev, d_map.data_ptr(), d_off2.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=True)
+            for _ in range(3):
+                step_s19_f64()
+            n19d = max(20, args.steps // 4)
+            el19d, _ = timed(step_s19_f64, n19d, False, tp=plan2)
+            plan2.status()
+            step_s19()
+            torch.cuda.synchronize()
+            s19 = d_sums.cpu().numpy()
+            k19 = {k: (ms / n if n else None) for k, (ms, n) in kt19.items() if n}
+            extra["value_s19"] = {
+                "value": total_halos / el19 * n19, "unit": "halos/s", "ms_per_step": el19 / n19 * 1e3, "steps": n19,
+                "workload": "the same catalog, shell and step with the 10x10x500 Schneider19 one-halo displacement table built by K4-K6 "
+                            "(SURVEY 8d table (ii): default_config parameters, cdelta = 7, proj_cutoff = 50)",
+                "table_abs_max_mpc": float(np.abs(table2).max()), "kernel_ms": k19, "ms_per_step_with_kernel_events": el19e / n19 * 1e3,
+                "mass_conserved": bool(np.isclose(s19[1], s19[0])), "regrid": st19,
+                "acc_f64": {"value": total_halos / el19d * n19d, "unit": "halos/s", "ms_per_step": el19d / n19d * 1e3, "steps": n19d,
+                            "dtype": "f64 throughout (the 1e-10 parity path)"},
+                "tolerance_note": "default mode (f32 pair math, f32 pix_offsets) against the fp64 oracle on this table: 2.6e-5 mean(map) measured, "
+                                  "5e-5 stated (tests/test_gpu_fullsize.py::test_config2_s19_benchmark_table_full_size_vs_oracle): the error of a "
+                                  "bilinear deposit grows with displacement / pixel (20 pixels here, < 0.2 on the closed-form table: 1e-6); "
+                                  "acc_f64 meets 1e-10",
+                "roofline": roofline(args, k19, n_pairs, nh, npix, paint, table='s19'),
+                "roofline_regrid": roofline(args, k19, n_pairs, nh, npix, paint, table='s19', force='regrid')}
+            plan2.close()
+            del d_off2, plan2
+            step()                                   # (d_out / d_sums hold the closed-form result again)
+            torch.cuda.synchronize()
         # the drop-in call from numpy arrays (BaryonifyShell.process(): PCIe both ways, plan cache warm after the first call)
         extra["end_to_end"] = end_to_end(args, cat, hmap, z, M, r, table)
 
@@ -865,8 +964,8 @@ def shell_line(args, ctx, scaling, brief):
         sums = d_sums.cpu().numpy()
         ms_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "halos/sec for %s NSIDE=%d (1e6-halo synthetic catalog%s)" % (
-                "PaintProfilesShell" if paint else "BaryonifyShell", nside,
+            "metric": "halos/sec for %s NSIDE=%d (%d-halo synthetic catalog%s)" % (
+                "PaintProfilesShell" if paint else "BaryonifyShell", nside, total_halos if strong else args.halos,
                 "" if world == 1 else (", ONE catalog split over the GPUs" if strong else " per GPU")),
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -875,13 +974,13 @@ def shell_line(args, ctx, scaling, brief):
                       "f64 ring-row geometry + f64 LDS accumulation + f64 map; f32 pair math (chord, ln r, read-out, exp)" if paint else
                       "f64 ring-row geometry + f64 LDS accumulation / map; f32 pair math, f32 pix_offsets, f32 regrid geometry"),
             "data": "synthetic",
-            "config": {"workload": "BASELINE config %d: %d-halo synthetic catalog %s (SURVEY 8d seeds), %s, "
+            "config": {"workload": "%s: %d-halo synthetic catalog %s (SURVEY 8d seeds), %s, "
                                    "NSIDE=%d shell, epsilon_max=%g, 10x10x500 %s %s table (edges = catalog min/max)" % (
-                                       4 if args.config == 4 else (3 if paint else 2), total_halos if strong else args.halos,
+                                       config_label(args, paint, nside, total_halos if strong else args.halos), total_halos if strong else args.halos,
                                        "split over the GPUs" if strong else "per GPU", "PaintProfilesShell" if paint else "BaryonifyShell", nside, args.eps,
                                        "Schneider19 (K4-K6 built)" if (args.table == 's19' and not paint) else "closed-form",
                                        "profile" if paint else "displacement"),
-                       "halos_per_gpu": nh, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs,
+                       "halos_per_gpu": nh, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs, "table": ("closed-form" if paint else args.table),
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
                        "parallelism": ("single GPU" if world == 1 else
                                        "spatial sharding x%d: halos routed (RCCL all_to_all of catalog columns) to the ranks whose ring bands their discs "
@@ -894,7 +993,10 @@ def shell_line(args, ctx, scaling, brief):
                                        if slices else "halo shards x%d + RCCL reduce(accumulator) -> rank 0" % world)},
             "map_pixels_per_s": npix / elapsed * args.steps,
             "mass_conserved": None if paint else bool(np.isclose(sums[1], sums[0])),
+            "backend": (backend if dist.is_initialized() else None), "world_size_seen": (dist.get_world_size() if dist.is_initialized() else 1),
         }
+        if spatial:
+            out["routing_rows"] = routing_rows
         if kt is not None:
             kernels = {k: (ms / n if n else None) for k, (ms, n) in kt.items() if n}
             out["ms_per_step_with_kernel_events"] = elapsed_ev / args.steps * 1e3
@@ -911,6 +1013,19 @@ def shell_line(args, ctx, scaling, brief):
     return out if rank == 0 else None
 
 
+def config_label(args, paint, nside, halos):
+    """which BASELINE.json config a line is -- only when the sizes ARE that config's"""
+    if args.config == 4 or (not paint and nside == 2048 and halos == 10_000_000):
+        return "BASELINE config 4"
+    if paint and nside == 2048 and halos == 1_000_000:
+        return "BASELINE config 3"
+    if not paint and nside == 1024 and halos == 1_000_000:
+        return "BASELINE config 2"
+    if not paint and nside == 2048 and halos == 1_250_000:
+        return "one GPU's share of BASELINE config 4 (1e7 halos / 8)"
+    return "not a BASELINE config (%s sizes)" % ("paint" if paint else "baryonify")
+
+
 def committed_traffic(match, key, metric_has=None):
     """HBM bytes per launch (and SQ_INSTS_VALU) of kernel group `key` from the committed rocprofv3 --pmc passes of THIS configuration:
     profiles/traffic_<tag>.json, written by scripts/traffic_pmc.sh (one counter per pass, FETCH_SIZE doubled as the gfx950 guide
@@ -922,29 +1037,31 @@ def committed_traffic(match, key, metric_has=None):
             c = tj.get('config', {})
             if metric_has is not None and metric_has not in (tj.get('metric') or ''):
                 continue
-            if all(c.get(k) == v for k, v in match.items()) and key in tj.get('kernels', {}):
+            if all(c.get(k, 'closed-form' if k == 'table' else None) == v for k, v in match.items()) and key in tj.get('kernels', {}):
                 return tj['kernels'][key], tj.get('valu_wave_insts', {}).get(key), os.path.basename(f)
         except Exception:        # noqa: BLE001
             continue
     return None, None, None
 
 
-def roofline(args, kernels, n_pairs, nh, npix, paint):
+def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None):
     """The dominant kernel (by measured time) against the HBM roof SURVEY 8(d) defines: algorithmic bytes per launch / average
     launch duration (HIP events on the launch stream over K steps).  traffic / VALU counts come from the committed rocprofv3 --pmc
     passes of this same configuration (profiles/traffic_latest.json)."""
     acc_b = 8 if args.acc_f64 else 4
     # SURVEY 8d: K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo; K2 60 B per map pixel (3 acc + 8 + 4 x 8 + 8); K3 8 B/pair
     alg = {'offsets': n_pairs * 3 * acc_b + nh * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8), 'paint': n_pairs * 8 + nh * 32 + npix * 8}
-    dom = 'paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0)
+    table = table or args.table
+    dom = force or ('paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0))
     real = 'double' if args.acc_f64 else 'float'
     names = {"offsets": ("tile_scatter2_kernel<OFFSETS, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
-             "regrid": ("tile_regrid3_kernel<%s, %s, 0>" % (real, real)) if args.algo == 1 else "regrid_kernel",
+             # (<.., 0>: the lean gather, reach of one ring; <.., 2>: the walking kernel -- every tile on the S19 table)
+             "regrid": ("tile_regrid3_kernel<%s, %s, %d>" % (real, real, 2 if table == 's19' else 0)) if args.algo == 1 else "regrid_kernel",
              "paint": ("tile_scatter2_kernel<PAINT, double, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
     ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
     traffic = valu = src = None
-    if not args.acc_f64 and args.algo == 1 and args.table == 'closed-form':
-        traffic, valu, src = committed_traffic({"halos_per_gpu": nh, "nside": args.nside, "pairs_per_gpu": n_pairs}, dom,
+    if not args.acc_f64 and args.algo == 1:
+        traffic, valu, src = committed_traffic({"halos_per_gpu": nh, "nside": args.nside, "pairs_per_gpu": n_pairs, "table": table}, dom,
                                                metric_has="PaintProfilesShell" if paint else "BaryonifyShell")
     r = {"kernel": names[dom], "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg[dom],
@@ -954,6 +1071,11 @@ def roofline(args, kernels, n_pairs, nh, npix, paint):
         # one wave64 fp32 instruction per ~1.0 ns per SIMD with >= 2 waves resident, fp64 / packed fp32 2.0 ns; 1024 SIMDs
         r["valu_issue"] = {"wave_insts_per_launch": valu, "achieved_per_s": valu / (kernels[dom] * 1e-3),
                            "peak_per_s": 1024 / 1.0e-9, "frac": valu / (kernels[dom] * 1e-3) / (1024 / 1.0e-9)}
+    if dom == 'regrid' and args.algo == 1:
+        r["note"] = ("gathering regrid: every output pixel owned by one workgroup, deposits summed in LDS, the tile stored once; on the S19 table "
+                     "the walking kernel scans 2.7 window pixels per stored one (two |o|^2 thresholds each) and evaluates the ~1.3 that can "
+                     "reach the tile on full waves: bounded by the scan's loads and vector issue, not by HBM (DESIGN.md section 4)")
+        return r
     r["note"] = ("tile-owned LDS accumulation, no global atomics, every output element stored once: the algorithmic HBM traffic is 12 B per "
                  "(halo, pixel) pair against ~115 vector instructions per pair (fp32 pair math; the fp64 ring-row phase adds ~350 per 64 rows), so the "
                  "kernel sits below the HBM roof and is bounded by vector issue + latency at 4 waves/SIMD (DESIGN.md section 4)") if args.algo == 1 else \

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BFGX_ABI_VERSION 2
+#define BFGX_ABI_VERSION 3
 #define BFGX_MAX_EXTRA 2          /* extra (per-halo parameter) table axes, model.p_keys */
 #define BFGX_MAX_DIM (3 + BFGX_MAX_EXTRA)
 
@@ -222,6 +222,11 @@ int  bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *o
 int  bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev,
                               const void *offsets_dev, int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev);
 int  bfgx_plan_far_fetch(bfgx_plan *p, int64_t cap, int64_t *pix_host, double *val_host, int64_t *n_host);
+/* What the LAST full-map regrid (bfgx_regrid_device / bfgx_baryonify_device) did, read back from its control words (blocking;
+ * diagnostics for tests and bench lines -- regrid_pixels_hpix, HealpixRunner.py:13-67, has no counterpart): deposits listed for the
+ * generic route, whether that list overflowed (then repaired in-stream), tiles whose reach exceeded one ring (run by the walking
+ * kernel), the largest reach of any tile in rings.  Any pointer may be NULL. */
+int  bfgx_plan_regrid_stats(bfgx_plan *p, int64_t *far_listed, int32_t *far_overflowed, int32_t *tiles_walked, int32_t *max_reach_rings);
 /* enqueue-only alternative: adds the listed deposits whose pixel lies in [p0, p1) to out_slice_dev (which starts at pixel
  * p0) and adds the number of the others to *foreign_dev (optional device counter the caller inspects later) */
 int  bfgx_plan_far_apply_device(bfgx_plan *p, double *out_slice_dev, int64_t p0, int64_t p1, unsigned long long *foreign_dev);

@@ -28,7 +28,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_device_count_callable_without_gpu():
     L = _lib.load()
-    assert L.bfgx_abi_version() == 2
+    assert L.bfgx_abi_version() == 3 == _lib.ABI_VERSION
     assert L.bfgx_device_count() >= 0
 
 

@@ -42,6 +42,13 @@ def test_default_mode_line_small(gpu):
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
     assert 'value_acc_f64' in d and 'end_to_end' in d and d['end_to_end']['mass_conserved'] is True
     assert set(d['kernel_ms']) >= {'prep', 'offsets', 'regrid'}
+    assert d['backend'] is None and d['world_size_seen'] == 1 and '20000-halo' in d['metric'] and d['config']['table'] == 'closed-form'
+    # SURVEY 8(d) table (ii) rides along: the same step on the Schneider19 table the GPU builders make
+    s19 = d['value_s19']
+    assert s19['value'] > 0 and s19['mass_conserved'] is True and s19['acc_f64']['value'] > 0 and s19['table_abs_max_mpc'] > 1.0
+    assert s19['regrid']['far_overflowed'] is False and s19['regrid']['max_reach_rings'] >= 1
+    for r in (s19['roofline'], s19['roofline_regrid']):
+        assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
 
 
 def test_paint_and_grid_lines_small(gpu):
@@ -62,7 +69,8 @@ def test_paint_and_grid_lines_small(gpu):
 def test_two_ranks_self_launched_strong_and_weak(gpu):
     """`python bench.py --gpus 2` as the driver types it (no launcher): the ranks are started as a child torch.distributed.run; both share
     device 0 over gloo (a one-GPU box), the product's HIP kernels + every exchange step of the spatial sharding run for real"""
-    env = dict(os.environ, BFGX_DIST_BACKEND='gloo', BFGX_BENCH_CHECK='1')
+    env = dict(os.environ, BFGX_DIST_BACKEND='gloo')          # (no BFGX_BENCH_CHECK: N > 1 checks itself by default)
+    env.pop('BFGX_BENCH_CHECK', None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--halos', '20001', '--nside', '128', '--steps', '3',
                           '--warmup', '1'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -76,4 +84,17 @@ def test_two_ranks_self_launched_strong_and_weak(gpu):
     # the map the two ranks assembled (fixed-capacity routing with NaN-padded rows, band-restricted K0 + K1, apron exchange, banded
     # regrid, gather) == one single-GPU pass over the whole catalog, to the stated fp32 tolerance
     c = d['check']
-    assert c['max_abs_diff_vs_single_gpu'] <= 2e-6 * c['scale'], c
+    assert c['ok'] is True and c['max_abs_diff_vs_single_gpu'] <= c['tolerance'] == 2e-6 * c['scale'], c
+    # the line says what ran: backend, the world size torch.distributed saw, the real halo count, and how much padding the
+    # fixed-capacity routing blocks carry (sized by one untimed count pass, not by a guess)
+    assert d['backend'] == 'gloo' and d['world_size_seen'] == 2
+    assert '20001-halo' in d['metric'] and 'not a BASELINE config' in d['config']['workload']
+    rr = d['routing_rows']
+    assert rr['padded_per_rank'] == 2 * rr['blockcap'] and 0 < rr['real_rank0'] <= rr['real_max_rank'] <= rr['padded_per_rank']
+    assert rr['padded_per_rank'] <= 1.3 * rr['real_max_rank'] + 4 * 512, rr
+    # --no-check skips the comparison
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--halos', '20001', '--nside', '128', '--steps', '2',
+                           '--warmup', '1', '--no-check', '--no-extras'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out2.returncode == 0, out2.stderr[-3000:]
+    d2 = json.loads([l for l in out2.stdout.strip().splitlines() if l.startswith('{')][0])
+    assert 'check' not in d2 and d2['world_size_seen'] == 2

@@ -104,6 +104,58 @@ def test_config2_full_size_vs_oracle_and_properties(gpu):
     plan.close()
 
 
+def test_config2_s19_benchmark_table_full_size_vs_oracle(gpu):
+    """SURVEY 8(d) table (ii), the BENCHMARK table (Schneider19 one-halo displacements built by K4-K6), at config 2's full size, exactly as
+    bench.py's `value_s19` runs it: K0 + K1 + K2 in one call against the CPU oracle on the same table.  Displacements of 1.9 pixels on
+    average and 20 at most: every tile takes the walking kernel (window scan + compaction) and the pixels beyond the cap the far list --
+    the path the closed-form table never enters."""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    from oracle import oracle as O
+    N, nside = 1_000_000, 1024
+    npix = 12 * nside * nside
+    cat = syn.make_catalog(N)
+    z, M, r = syn.table_grid(cat)                                  # edges == catalog min / max, as bench.py (README.md:78-80)
+    table = syn.s19_displacement_table(z, M, r)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    model, keep = engine.model_from_tables(axes, table, syn.COSMO, 10.0, 10.0)
+    dev = torch.device('cuda', 0)
+    plan = engine.ShellPlan(model, keep, nside, N, 0, torch.cuda.current_stream().cuda_stream)
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+    cdc, keepc = _cat_dev(torch, _lib, dev, cat, coords=True)
+    ora = O.baryonify_shell(nside, hmap, cat, O.Table(axes, table, False, 10.0), 10.0, O.Background.from_dict(syn.COSMO))
+    assert np.isclose(ora.sum(), hmap.sum())
+    res = {}
+    for acc_f64 in (True, False):
+        off = torch.zeros(npix * 3, dtype=torch.float64 if acc_f64 else torch.float32, device=dev)
+        out = torch.zeros(npix, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.baryonify(cdc, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=acc_f64)
+        torch.cuda.synchronize()
+        plan.status()
+        st = plan.regrid_stats()
+        got, sm = out.cpu().numpy(), sums.cpu().numpy()
+        assert np.isclose(sm[1], sm[0]) and np.isclose(got.sum(), hmap.sum())                   # HealpixRunner.py:344-346
+        # the tiles really walked and the far list was really used
+        assert st['max_reach_rings'] > 8 and st['tiles_walked'] > 5500 and st['far_listed'] > 1000 and not st['far_overflowed'], st
+        res[acc_f64] = np.abs(got - ora).max()
+        mag = torch.linalg.norm(off.view(-1, 3).double(), dim=1)
+        assert float(mag.max()) > 15 * np.sqrt(4 * np.pi / npix) and float(mag.mean()) > 1.5 * np.sqrt(4 * np.pi / npix)      # pixels move
+        del off, out, mag
+    print("S19 table, 1e6 / 1024: max |hip - oracle| fp64 %.3e (%.1e of max), fp32 pair math %.3e (%.2e of the mean)" % (
+        res[True], res[True] / np.abs(ora).max(), res[False], res[False] / ora.mean()))
+    assert res[True] <= 1e-10 * np.abs(ora).max()
+    # fp32 pair math: every (halo, pixel) contribution carries ~4e-7 of itself (v_log_f32, the fp32 table coordinate: 250 cells at a
+    # half-ulp of 1.5e-5), i.e. an offset of d radians is good to ~4e-7 d, (d / pixel) x 4e-7 of a pixel in the bilinear weights, times the
+    # pixel's value.  Sub-pixel displacements (the closed-form table, d < 0.2 pixels): the 1e-6 mean(map) of SURVEY 8(d) (measured 2.4e-7).
+    # This table moves pixels by up to 20: measured 2.6e-5 mean(map); STATED tolerance of the default mode on it: 5e-5 mean(map).
+    # (fp32 pix_offsets alone -- a half-ulp of 0.02 rad is 1e-9 rad = 1e-6 pixels -- would already cost 2.5e-6 mean(map): 1e-6 at 20
+    # pixels of displacement needs the fp64 mode above, which meets 1e-10.)
+    assert res[False] <= 5e-5 * ora.mean()
+    plan.close()
+
+
 def test_config3_paint_full_size_properties(gpu):
     N, nside = 1_000_000, 2048
     torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=True)
