@@ -668,7 +668,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         int qn = 0;                                                            // entries in this wave's queue (wave-uniform)
         constexpr int U = BFGX_K2U;                                                   // window pixels per lane and trip: 2 U loads in flight
         const int64_t pdummy = rows[R + 1].start + rows[R + 1].ks;             // (a pixel this tile may read, for the lanes without one)
-        for (int base = wid * kWave; base < total; base += 256 * U) {
+        for (int base = wid * kWave; base < (BFGX_ABLK2 == 2 ? 0 : total); base += 256 * U) {
             int cpos[U], cx[U], cspan[U];
             bool cin[U], cown[U];
             float cneed2[U], ccf2[U], clim2[U];
