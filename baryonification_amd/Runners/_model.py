@@ -37,26 +37,76 @@ def _support(runner):
     return z0, z1, float(M.min()) * (1 - 1e-6), float(M.max()) * (1 + 1e-6)
 
 
+def _fingerprint(model):
+    """the model's parameters as far as they can be read off the object (scalars, strings, arrays, nested dicts / lists of those): a
+    table tabulated from a callable is reused only while this has not changed"""
+    import hashlib
+
+    def enc(v, depth=0):
+        if isinstance(v, (bool, int, float, complex, str, bytes, type(None))):
+            return repr(v)
+        if isinstance(v, np.ndarray):
+            return 'nd%r%s' % (v.shape, hashlib.blake2b(np.ascontiguousarray(v).tobytes(), digest_size=8).hexdigest())
+        if isinstance(v, np.generic):
+            return repr(v.item())
+        if depth < 3 and isinstance(v, (list, tuple)):
+            return '[' + ','.join(enc(x, depth + 1) for x in v) + ']'
+        if depth < 3 and isinstance(v, dict):
+            return '{' + ','.join('%r:%s' % (k, enc(v[k], depth + 1)) for k in sorted(v, key=repr)) + '}'
+        if depth < 2 and hasattr(v, '__dict__') and not callable(v):
+            return type(v).__name__ + enc(vars(v), depth + 1)
+        return type(v).__name__ + '@%x' % id(v)
+    try:
+        items = {k: v for k, v in vars(model).items() if not k.startswith('_bfgx')}
+    except TypeError:
+        return None
+    return hashlib.blake2b(enc(items).encode(), digest_size=8).hexdigest()
+
+
+_WARNED = set()
+
+
 def tabulate_callable(runner, kind):
     """The reference's runners call `model.displacement(r, M, a)` / `model.projected(cosmo, r, M, a)` / `model.real(cosmo, r, M, a)`
     once per halo on ANY object (HealpixRunner.py:321, :441; Map2DRunner.py:534, :752, :781; SnapshotRunner.py:228).  A model that carries no table (no raw_input_*) and cannot build one itself (no
     setup_interpolator) is tabulated here, once, on the (z, M) support of the runner's catalog -- BRIDGE_N_Z x BRIDGE_N_M x
     BRIDGE_N_R samples, z linear, M and r logarithmic -- and the table holder is cached on the model (`_bfgx_tabulated`), keyed by
     the support.  Returns the holder (a Baryonification2D / TabulatedProfile of this package)."""
+    import warnings
     model = runner.model
     z0, z1, M0, M1 = _support(runner)
-    key = (kind, z0, z1, M0, M1)
+    shell = hasattr(runner, 'HaloLightConeCatalog')
+    # sampling: model.bfgx_table_grid = (Nz, NM, NR) [, (R_min, R_max)] overrides the default BRIDGE_* grid
+    grid = getattr(model, 'bfgx_table_grid', None)
+    nz, nm, nrad, rmin, rmax = (BRIDGE_N_Z if shell else 2), BRIDGE_N_M, BRIDGE_N_R, BRIDGE_R_MIN, BRIDGE_R_MAX
+    if grid is not None:
+        g = tuple(grid)
+        if len(g) == 2 and np.ndim(g[0]) == 1:
+            (nz, nm, nrad), (rmin, rmax) = (int(v) for v in g[0]), (float(v) for v in g[1])
+        else:
+            nz, nm, nrad = (int(v) for v in g)
+        if nz < 2 or nm < 2 or nrad < 2 or not (0 < rmin < rmax):
+            raise ValueError("model.bfgx_table_grid = (Nz, NM, NR)[, (R_min, R_max)] needs at least 2 samples per axis and 0 < R_min < R_max")
+    key = (kind, z0, z1, M0, M1, nz, nm, nrad, rmin, rmax, _fingerprint(model))
     cached = getattr(model, '_bfgx_tabulated', None)
     if cached is not None and cached[0] == key:
         return cached[1]
+    wkey = (type(model).__name__, kind, nz, nm, nrad)
+    if wkey not in _WARNED:
+        _WARNED.add(wkey)
+        warnings.warn("%s has no table: its %s() is tabulated once on %d x %d x %d samples (z linear in [%.4g, %.4g], M logarithmic in "
+                      "[%.3g, %.3g], r logarithmic in [%.3g, %.3g] Mpc) and the GPU reads that table out, where the reference calls the "
+                      "method per halo (HealpixRunner.py:321, :441): results differ by the interpolation error of the table (2e-3 for a "
+                      "smooth profile at the default sampling).  Set model.bfgx_table_grid = (Nz, NM, NR) for a finer one."
+                      % (type(model).__name__, kind, nz, nm, nrad, z0, z1, M0, M1, rmin, rmax), RuntimeWarning, stacklevel=3)
     from ..Profiles.BaryonCorrection import Baryonification2D
     from ..utils.Tabulate import TabulatedProfile
     from ..utils.cosmology import Cosmology, cosmo_to_dict
     cosmo = getattr(model, 'cosmo', None) or runner.cosmo
     cosmo_obj = cosmo if isinstance(cosmo, Cosmology) else Cosmology.from_dict(cosmo_to_dict(cosmo))
-    z = np.linspace(z0, z1, BRIDGE_N_Z if hasattr(runner, 'HaloLightConeCatalog') else 2)
-    Mg = np.geomspace(M0, M1, BRIDGE_N_M)
-    r = np.geomspace(BRIDGE_R_MIN, BRIDGE_R_MAX, BRIDGE_N_R)
+    z = np.linspace(z0, z1, nz)
+    Mg = np.geomspace(M0, M1, nm)
+    r = np.geomspace(rmin, rmax, nrad)
     if kind == 'displacement':
         d = np.zeros((z.size, Mg.size, r.size))
         for i, zi in enumerate(z):

@@ -271,7 +271,9 @@ def make_table(axes, values, rdelta_sampling=False, log_values=False, eps_model=
     axes = [f8(a) for a in axes]
     values = f8(values)
     if len(axes) > BFGX_MAX_DIM:
-        raise NotImplementedError("at most %d extra table parameters are supported" % BFGX_MAX_EXTRA)
+        raise NotImplementedError("a table with %d property axes (other_params): libbfgx reads out at most BFGX_MAX_EXTRA = %d of them "
+                                  "(3 + %d table axes; the reference's ParamTabulatedProfile / BaryonificationClass accept any number, "
+                                  "Tabulate.py:524-561, BaryonCorrection.py:205-221)" % (len(axes) - 3, BFGX_MAX_EXTRA, BFGX_MAX_EXTRA))
     if values.shape != tuple(a.size for a in axes):
         raise ValueError("table values shape %r does not match axes %r" % (values.shape, [a.size for a in axes]))
     t = bfgx_table()

@@ -193,6 +193,13 @@ def _centres_by_hand(nside):
     q = np.pi / 4
     if nside == 1:            # 3 rings of 4: z = 2/3 (phi = pi/4 + k pi/2), z = 0 (phi = k pi/2), z = -2/3 (phi = pi/4 + k pi/2)
         rings = [(2 / 3, [q, 3 * q, 5 * q, 7 * q]), (0.0, [0, 2 * q, 4 * q, 6 * q]), (-2 / 3, [q, 3 * q, 5 * q, 7 * q])]
+    elif nside == 4:
+        # NSIDE 4 (192 pixels, 15 rings).  Caps: ring i = 1, 2, 3 holds 4 i pixels at z = 1 - i^2 / 48 = 47/48, 11/12, 13/16, azimuths
+        # (k + 1/2) pi / (2 i).  Belt: rings 4 .. 12 hold 16 pixels at z = (8 - i) / 6 = 2/3, 1/2, 1/3, 1/6, 0, ..., -2/3; rings 4, 6, 8, 10, 12
+        # are offset by half a pixel (azimuths (k + 1/2) pi / 8), rings 5, 7, 9, 11 are not (k pi / 8).  South cap mirrors the north.
+        rings = [(1 - i * i / 48, [(k + 0.5) * np.pi / (2 * i) for k in range(4 * i)]) for i in (1, 2, 3)]
+        rings += [((8 - i) / 6, [(k + (0.5 if i % 2 == 0 else 0.0)) * np.pi / 8 for k in range(16)]) for i in range(4, 13)]
+        rings += [(-(1 - i * i / 48), [(k + 0.5) * np.pi / (2 * i) for k in range(4 * i)]) for i in (3, 2, 1)]
     else:                     # NSIDE 2: caps z = +-11/12 (4 pixels), then z = 2/3, 1/3, 0, -1/3, -2/3 (8 pixels, every other ring offset)
         assert nside == 2
         half = [q / 2 + k * q for k in range(8)]              # pi/8, 3 pi/8, ...
@@ -228,6 +235,21 @@ def test_query_disc_hand_enumerated_known_answers():
     c20 = np.array([np.cos(np.pi / 8), np.sin(np.pi / 8), 0.0])
     d29 = np.arccos(np.sqrt(8) / 3 * np.cos(np.pi / 8))
     cases += [(2, c20, 0.2, [20]), (2, c20, d29 - 1e-6, [20]), (2, c20, d29 + 1e-6, [12, 13, 20, 28, 29])]
+    # NSIDE 4, about the north pole: the cap's rings lie at arccos(47/48) = 11.72, arccos(11/12) = 23.56, arccos(13/16) = 35.66 deg (pixels
+    # 0-3, 4-11, 12-23), the first ring of the belt (z = 2/3, pixels 24-39) at 48.19 deg: a disc that crosses the cap / belt boundary
+    cases += [(4, n, 0.2, []), (4, n, 0.21, [0, 1, 2, 3]), (4, n, np.arccos(13 / 16) + 1e-6, list(range(24))),
+              (4, n, np.arccos(2 / 3) - 1e-6, list(range(24))), (4, n, np.arccos(2 / 3) + 1e-6, list(range(40))), (4, -n, 0.21, [188, 189, 190, 191])]
+    # NSIDE 4, about the centre of pixel 24 (the first pixel of the boundary ring z = 2/3, azimuth pi/16 = 11.25 deg).  By hand:
+    #   cap ring 3 (z = 13/16, azimuths 15, 45, ... 345 deg): pixel 12 at dphi = 3.75 deg: cos d = 2/3 13/16 + sqrt(5)/3 sqrt(87)/16 cos 3.75
+    #     = 0.541667 + 0.434520 x 0.997859 = 0.975257 -> 12.77 deg;  pixel 23 (345 deg, dphi 26.25): 0.541667 + 0.434520 x 0.896873 -> 21.35 deg
+    #   belt ring 5 (z = 1/2, azimuths 0, 22.5, ...): pixels 40, 41 at dphi = 11.25: cos d = 1/3 + sqrt(5)/3 sqrt(3)/2 cos 11.25 = 0.966428 -> 14.89 deg
+    #   own ring: pixels 25 and 39 at dphi = 22.5: cos d = 4/9 + 5/9 cos 22.5 = 0.957711 -> 16.72 deg
+    c24 = np.array([np.sqrt(5) / 3 * np.cos(np.pi / 16), np.sqrt(5) / 3 * np.sin(np.pi / 16), 2 / 3])
+    cases += [(4, c24, 0.2, [24]), (4, c24, np.radians(12.77) + 1e-3, [12, 24]), (4, c24, np.radians(14.89) + 1e-3, [12, 24, 40, 41]),
+              (4, c24, np.radians(16.72) + 1e-3, [12, 24, 25, 39, 40, 41]), (4, c24, np.radians(21.35) + 1e-3, [12, 23, 24, 25, 39, 40, 41])]
+    # NSIDE 4, a disc over phi = 0 on the equator, about (pi/2, 0): rings 7 and 9 (z = +-1/6, not offset) have pixels 72 and 104 at
+    # phi = 0, arcsin(1/6) = 9.594 deg away; ring 8 (z = 0, offset) has its FIRST pixel 88 at +11.25 deg and its LAST, 103, at -11.25 deg
+    cases += [(4, c, 0.16, []), (4, c, 0.17, [72, 104]), (4, c, np.radians(11.25) + 1e-3, [72, 88, 103, 104]), (4, c, 0.35, [72, 88, 103, 104])]
     for nside, vec, rad, want in cases:
         got_o = O.query_disc(nside, vec, rad).tolist()
         got_s = hp.query_disc(nside, vec, rad).tolist()
@@ -237,9 +259,9 @@ def test_query_disc_hand_enumerated_known_answers():
         assert np.where(v @ vec > np.cos(rad))[0].tolist() == want
 
 
-@pytest.mark.parametrize('nside', [1, 2])
+@pytest.mark.parametrize('nside', [1, 2, 4])
 def test_query_disc_random_discs_against_hand_typed_centres(nside):
-    """random discs at NSIDE 1 and 2: membership by brute force over the hand-typed centre table == both implementations"""
+    """random discs at NSIDE 1, 2 and 4: membership by brute force over the hand-typed centre table == both implementations"""
     v = _centres_by_hand(nside)
     assert v.shape == (12 * nside * nside, 3)
     rng = np.random.default_rng(100 + nside)
@@ -252,3 +274,52 @@ def test_query_disc_random_discs_against_hand_typed_centres(nside):
             continue
         want = np.where(dist < rad)[0].tolist()
         assert O.query_disc(nside, c, rad).tolist() == want and hp.query_disc(nside, c, rad).tolist() == want
+
+
+def test_pix2vec_equals_hand_typed_centres():
+    """both in-house pix2vec against the centre tables typed in from the published tessellation (NSIDE 1, 2, 4)"""
+    for nside in (1, 2, 4):
+        v = _centres_by_hand(nside)
+        assert np.abs(O.pix2vec(nside, np.arange(12 * nside * nside)) - v).max() < 1e-15
+        assert np.abs(np.stack(hp.pix2vec(nside, np.arange(12 * nside * nside)), axis=1) - v).max() < 1e-15
+
+
+def test_interp_weights_hand_worked_nside4():
+    """get_interp_weights at NSIDE 4 at two points worked by hand from the published rule (healpix_cxx get_interpol: the two rings that
+    bracket the colatitude, linear in azimuth within each -- wrapping --, linear in colatitude between them; above the first ring the
+    missing ring is the four polar pixels at 1/4 each)"""
+    def as_map(pix, w):
+        m = np.zeros(192)
+        np.add.at(m, np.asarray(pix).ravel(), np.asarray(w).ravel())
+        return m
+    fs = [lambda lon, lat: O.get_interp_weights_lonlat(4, np.atleast_1d(lon), np.atleast_1d(lat)),
+          lambda lon, lat: hp.get_interp_weights(4, np.atleast_1d(lon), np.atleast_1d(lat), lonlat=True)]
+    # (a) ABOVE the first ring: theta = 0.1 < theta_1 = arccos(47/48) = 0.204480, phi = 0.3.  Ring 1 has 4 pixels at pi/4 + k pi/2:
+    #     phi / (pi/2) - 1/2 = -0.309014 -> between pixel 3 (weight 0.309014) and pixel 0 (weight 0.690986); fraction of the way from
+    #     the pole to ring 1: wt = 0.1 / 0.204480 = 0.489045; the pole contributes (1 - wt) / 4 = 0.127739 to each of the 4 pixels
+    th1 = np.arccos(47 / 48)
+    wt = 0.1 / th1
+    u = 0.3 / (np.pi / 2) - 0.5 + 1.0                         # 0.690986: weight of pixel 0 within ring 1
+    want = np.zeros(192)
+    want[:4] = (1 - wt) / 4
+    want[0] += u * wt
+    want[3] += (1 - u) * wt
+    assert abs(wt - 0.489045) < 1e-6 and abs(u - 0.690986) < 1e-6 and abs(want.sum() - 1) < 1e-15
+    for f in fs:
+        pix, w = f(np.degrees(0.3), 90.0 - np.degrees(0.1))
+        assert np.abs(as_map(pix, w) - want).max() < 1e-14
+        assert sorted(np.asarray(pix).ravel().tolist()) == [0, 1, 2, 3]
+    # (b) across phi = 0 between belt rings 7 (z = 1/6, not offset, pixels 72 ..) and 8 (z = 0, offset, pixels 88 ..): z = 1/12, phi = -0.05.
+    #     In colatitude: (arccos(1/12) - arccos(1/6)) / (pi/2 - arccos(1/6)) = 0.084018 / 0.167448 = 0.501755 of the way down to ring 8.
+    #     Ring 7: phi / (pi/8) = 16 - 0.127324 = 15.872676 -> pixel 72 + 15 = 87 (weight 0.127324) and, wrapping, pixel 72 (0.872676).
+    #     Ring 8: 15.872676 - 1/2 = 15.372676 -> pixel 88 + 15 = 103 (weight 0.627324) and, wrapping, pixel 88 (0.372676)
+    t = (np.arccos(1 / 12) - np.arccos(1 / 6)) / (np.pi / 2 - np.arccos(1 / 6))
+    a7 = 16 - 0.05 / (np.pi / 8) - 15
+    a8 = a7 - 0.5
+    assert abs(t - 0.501755) < 1e-6 and abs(a7 - 0.872676) < 1e-6
+    want = np.zeros(192)
+    want[87], want[72], want[103], want[88] = (1 - a7) * (1 - t), a7 * (1 - t), (1 - a8) * t, a8 * t
+    for f in fs:
+        pix, w = f(np.degrees(2 * np.pi - 0.05), 90.0 - np.degrees(np.arccos(1 / 12)))
+        assert np.abs(as_map(pix, w) - want).max() < 1e-13
+        assert sorted(np.asarray(pix).ravel().tolist()) == [72, 87, 88, 103]
