@@ -96,8 +96,8 @@ def tabulate_callable(runner, kind):
         _WARNED.add(wkey)
         warnings.warn("%s has no table: its %s() is tabulated once on %d x %d x %d samples (z linear in [%.4g, %.4g], M logarithmic in "
                       "[%.3g, %.3g], r logarithmic in [%.3g, %.3g] Mpc) and the GPU reads that table out, where the reference calls the "
-                      "method per halo (HealpixRunner.py:321, :441): results differ by the interpolation error of the table (2e-3 for a "
-                      "smooth profile at the default sampling).  Set model.bfgx_table_grid = (Nz, NM, NR) for a finer one."
+                      "method per halo (HealpixRunner.py:321, :441): results differ by the interpolation error of the table (a few 1e-3 of the "
+                      "effect at the default sampling).  Set model.bfgx_table_grid = (Nz, NM, NR) for a finer one."
                       % (type(model).__name__, kind, nz, nm, nrad, z0, z1, M0, M1, rmin, rmax), RuntimeWarning, stacklevel=3)
     from ..Profiles.BaryonCorrection import Baryonification2D
     from ..utils.Tabulate import TabulatedProfile

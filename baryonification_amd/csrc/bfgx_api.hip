@@ -1605,7 +1605,14 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     bool whole_map_sent = false;
     struct Pin {
         void *p = nullptr;
-        ~Pin() { if (p) (void)hipHostUnregister(p); }
+        hipStream_t *streams[3] = {nullptr, nullptr, nullptr};     // copies of the pinned buffer may be in flight on these when an error returns early
+        ~Pin()
+        {
+            if (!p) return;
+            // never hand a buffer back to the caller (or unregister it) while an asynchronous copy still reads or writes it
+            for (hipStream_t *s : streams) if (s && *s) (void)hipStreamSynchronize(*s);
+            (void)hipHostUnregister(p);
+        }
         // true if [q, q + bytes) is page-locked afterwards (registered here, or already by the caller: bfgx_host_alloc)
         bool lock(const void *q, size_t bytes)
         {
@@ -1617,6 +1624,8 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
             return false;
         }
     } pin_in, pin_out;
+    pin_in.streams[0] = pin_out.streams[0] = &e->copy_stream; pin_in.streams[1] = pin_out.streams[1] = &p->stream;
+    pin_in.streams[2] = pin_out.streams[2] = &e->out_stream;
     if (piped) piped = pin_in.lock(map_in, npix * sizeof(double)) && pin_out.lock(map_out, npix * sizeof(double));
     if (piped) {
         int nb = 0;
@@ -1774,7 +1783,17 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     int kChunks = (int)std::min<size_t>(kChunksMax, npix * sizeof(double) / ((size_t)16 << 20));
     if (const char *ce = std::getenv("BFGX_PIPE_CHUNKS")) kChunks = std::max(2, std::min(kChunksMax, std::atoi(ce)));       // (tests: small maps)
     bool piped = o.algo == 1 && o.acc_paint_f64 != 0 && kChunks >= 2 && p->tiling.nbands >= 2 * kChunks && !std::getenv("BFGX_NO_PIPELINE");
-    struct Pin { void *p = nullptr; ~Pin() { if (p) (void)hipHostUnregister(p); } } pin_out;
+    struct Pin {
+        void *p = nullptr;
+        hipStream_t *streams[2] = {nullptr, nullptr};
+        ~Pin()
+        {
+            if (!p) return;
+            for (hipStream_t *s : streams) if (s && *s) (void)hipStreamSynchronize(*s);      // (an early error return: copies into map_out may be in flight)
+            (void)hipHostUnregister(p);
+        }
+    } pin_out;
+    pin_out.streams[0] = &p->stream; pin_out.streams[1] = &e->out_stream;
     if (piped) {
         if (hipHostRegister((void *)map_out, npix * sizeof(double), hipHostRegisterDefault) == hipSuccess) pin_out.p = (void *)map_out;
         else {

@@ -373,3 +373,20 @@ def test_more_than_two_property_axes_are_refused_loudly():
     R.model.__dict__['p_keys'] = ThreeParams.p_keys
     with pytest.raises(NotImplementedError, match="3 property axes"):
         RM.build_model(R(), 'displacement')
+
+
+def test_catalog_fingerprint_without_xxhash(monkeypatch):
+    """xxhash is optional: without it the fingerprint comes from hashlib.blake2b, and still sees a one-halo edit"""
+    import sys
+    from baryonification_amd.Runners import HealpixRunner as HR
+    cat = np.zeros(1000, dtype=[('M', 'f8'), ('z', 'f8'), ('ra', 'f8'), ('dec', 'f8')])
+    cat['M'] = np.arange(1000) + 1.0
+    names = ['M', 'z', 'ra', 'dec']
+    with_xx = HR._catalog_fingerprint(cat, names)
+    monkeypatch.setitem(sys.modules, 'xxhash', None)               # `import xxhash` now raises ImportError
+    f0 = HR._catalog_fingerprint(cat, names)
+    assert f0 is not None and f0[:3] == (1000, str(cat.dtype), tuple(names)) and f0 == HR._catalog_fingerprint(cat, names)
+    assert with_xx[:3] == f0[:3]
+    cat['M'][777] *= 1.0000001
+    assert HR._catalog_fingerprint(cat, names) != f0
+    assert HR._catalog_fingerprint(cat[:0], names)[3] == 0
