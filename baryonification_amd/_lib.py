@@ -162,6 +162,8 @@ SYMBOLS = {
     'bfgx_grid_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_void_p, _P(C.c_int64)]),
     'bfgx_grid_regrid_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_grid_baryonify_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
+    'bfgx_grid_deposit_baryonify_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     'bfgx_grid_plan_set_slab': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'bfgx_grid_regrid_slab_device': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_deposit_particles_slab_device': (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -240,8 +240,10 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
 template <bool MASS>
 __global__ void __launch_bounds__(kDepTileThreads)
 deposit_tiles_kernel(DepGeom g, const int32_t *__restrict__ start2, const uint32_t *__restrict__ keys, const double *__restrict__ mass,
-                     double *__restrict__ out)
+                     double *__restrict__ out, double *__restrict__ out2, double *__restrict__ tile_sums)
 {
+    // out2 / tile_sums (optional): a second copy of every cell and the tile's total -- what BaryonifyGrid's cell-owned pass starts from
+    // (map_out = map_in, sum(map_in)), written here while the cell is in a register instead of by a pass over the finished map
     __shared__ double acc[kDepTileCells];
     const int tile = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < kDepTileCells; i += kDepTileThreads) acc[i] = 0.0;
@@ -252,12 +254,28 @@ deposit_tiles_kernel(DepGeom g, const int32_t *__restrict__ start2, const uint32
     __syncthreads();
     const int tz = tile % g.ntz, ty = (tile / g.ntz) % g.nty, tx = tile / (g.ntz * g.nty);
     const int x0 = tx * g.sx, y0 = ty * g.sy, z0 = tz * g.sz;
+    double tsum = 0.0;
     for (int l = tid; l < g.sx * g.sy * g.sz; l += kDepTileThreads) {
         const int lz = l & (g.sz - 1), ly = (l >> g.lsz) & (g.sy - 1), lx = l >> (g.lsz + g.lsy);
         const int bx = x0 + lx, by = y0 + ly, bz = z0 + lz;
         if (bx >= g.plane_n || by >= g.nb || (g.dim == 3 && bz >= g.nb)) continue;
         const int64_t flat = (g.dim == 3) ? ((int64_t)bx * g.nb + by) * g.nb + bz : (int64_t)bx * g.nb + by;
-        out[flat] = acc[l];
+        const double v = acc[l];
+        out[flat] = v;
+        if (out2) out2[flat] = v;
+        tsum += v;
+    }
+    if (tile_sums) {
+        __syncthreads();                                   // acc is free: its first words hold the waves' partial sums
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) tsum += __shfl_down(tsum, sft, kWave);
+        if ((tid & (kWave - 1)) == 0) acc[tid / kWave] = tsum;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kDepTileThreads / kWave; ++w) t += acc[w];
+            tile_sums[tile] = t;
+        }
     }
 }
 

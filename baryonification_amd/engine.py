@@ -259,6 +259,17 @@ class GridPlan(object):
                                                          C.c_void_p(int(sums_ptr) or None), C.byref(n)))
         return int(n.value)
 
+    def deposit_baryonify(self, cat_dev, n_particles, x_ptr, y_ptr, z_ptr, mass_ptr, edges_ptr, map_in_ptr, map_out_ptr, sums_ptr=0):
+        """ParticleSnapshot.make_map + BaryonifyGrid.process() in one call (device arrays): the histogram of the particles goes to
+        map_in AND, as the start value of the cell-owned pass, to map_out while it is being stored -- the map is not read again to copy
+        and sum it.  Returns the number of contributing (halo, pixel) pairs."""
+        n = C.c_int64(0)
+        _lib.check(_lib.load().bfgx_grid_deposit_baryonify_device(
+            self._h, C.byref(cat_dev), int(n_particles), C.c_void_p(int(x_ptr)), C.c_void_p(int(y_ptr)), C.c_void_p(int(z_ptr) or None),
+            C.c_void_p(int(mass_ptr) or None), C.c_void_p(int(edges_ptr)), C.c_void_p(int(map_in_ptr)), C.c_void_p(int(map_out_ptr)),
+            C.c_void_p(int(sums_ptr) or None), C.byref(n)))
+        return int(n.value)
+
     def set_slab(self, plane_lo, plane_n):
         """slab decomposition over GPUs: this plan owns the planes [plane_lo, plane_lo + plane_n) of the first array axis;
         offsets() / paint() then fill plane_n x npix (x npix) cells (pass the whole catalog), regrid_slab() regrids them"""

@@ -68,6 +68,9 @@ def parse():
     ap.add_argument('--ngrid', type=int, default=512, help='grid3d: cells per side (power of two)')
     ap.add_argument('--particles', type=int, default=0, help='grid3d: particles in the snapshot (default ngrid^3 / 2)')
     ap.add_argument('--grid-halos', type=int, default=100_000, help='grid3d: halos per GPU')
+    ap.add_argument('--separate-deposit', action='store_true',
+                    help='grid3d, one GPU: deposit and BaryonifyGrid as two calls (the deposit then does not leave map_out / the sum behind and '
+                         'BaryonifyGrid copies and sums the map itself); default: the fused bfgx_grid_deposit_baryonify_device')
     ap.add_argument('--sorted-particles', action='store_true',
                     help='grid3d / snapshot: order the synthetic particles by coarse cell (as snapshot files stored along a space-filling '
                          'curve are) instead of uniformly random order')
@@ -269,7 +272,8 @@ def main_grid(args):
         assert world == 1, "--mode snapshot is single-GPU (particles are not sharded)"
         part_out = torch.empty_like(part)
         splan = engine.SnapshotPlan(model, keep, 3, L, zr, nh, device=local_rank, stream=stream)
-    ev = {k: [] for k in (('displace', 'deposit', 'pk') if snapshot else ('deposit', 'pk'))}
+    fused = world == 1 and not snapshot and not args.separate_deposit
+    ev = {k: [] for k in (('displace', 'deposit', 'pk') if snapshot else (('deposit+baryonify', 'pk') if fused else ('deposit', 'pk')))}
     pairs = [0]
 
     def timed(kind, fn):
@@ -291,6 +295,15 @@ def main_grid(args):
         if snapshot:
             return step_snapshot()
         d_sums.zero_()
+        if world == 1 and fused:
+            # make_map + BaryonifyGrid in one call: the deposit's last kernel also stores the start value of map_out and the map's sum
+            def both():
+                pairs[0] = plan.deposit_baryonify(cat_dev, npart, part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), 0, d_edges.data_ptr(),
+                                                  d_map.data_ptr(), d_out.data_ptr(), d_sums.data_ptr())
+            timed('deposit+baryonify', both)
+            timed('pk', lambda: engine.power_spectrum_device(d_out.data_ptr(), N, L, Nk, d_work.data_ptr(), d_pk.data_ptr(),
+                                                             d_ks.data_ptr(), d_cnt.data_ptr(), local_rank, stream))
+            return
         if rank == 0:
             timed('deposit', lambda: engine.deposit_particles_device(part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr(), 0, npart, N,
                                                                      d_edges.data_ptr(), d_map.data_ptr(), 3, local_rank, stream))
@@ -331,6 +344,8 @@ def main_grid(args):
         kernels = {k: ms / n for k, (ms, n) in kt.items() if n}
         for k, lst in ev.items():
             kernels[k] = float(np.mean([a.elapsed_time(b) for a, b in lst]))
+        if fused:        # the deposit's share of the fused call: what the plan's own kernel timers (prep, lists, gather, sums) do not cover
+            kernels['deposit'] = kernels['deposit+baryonify'] - sum(kernels.get(k, 0.0) for k in ('prep', 'bin', 'offsets', 'sum', 'regrid'))
         sums = d_sums.cpu().numpy()
         pk = (d_pk / d_cnt).cpu().numpy()
         # algorithmic bytes per launch.  world == 1: 'regrid' is the copy map_out = map_in (every cell deposits into itself unless it is
@@ -338,9 +353,9 @@ def main_grid(args):
         # map_out; no pix_offsets array); 'pk': the real map read, the padded half spectrum written by the r2c pass,
         # read + written by the middle pass and read by the last one (binned from LDS, nothing written back)
         spec = N * N * engine.fft_pitch(N) * 16
-        alg = {'regrid': N ** 3 * 16 if world == 1 else N ** 3 * (3 * 8 + 8 + 8 * 8 + 8),
+        alg = {'regrid': (0 if fused else N ** 3 * 16) if world == 1 else N ** 3 * (3 * 8 + 8 + 8 * 8 + 8),
                'offsets': (pairs[0] * (8 + 9 * 16) + nh * 8 * (4 + 344)) if world == 1 else pairs[0] * 3 * 8 + nh * 32,
-               'deposit': npart * (3 * 8 + 8) + N ** 3 * 8, 'pk': N ** 3 * 8 + 4 * spec, 'displace': npart * 48 + nh * 32}
+               'deposit': npart * (3 * 8 + 8) + N ** 3 * (16 if fused else 8), 'pk': N ** 3 * 8 + 4 * spec, 'displace': npart * 48 + nh * 32}
         dom = max(alg, key=lambda k: kernels.get(k) or 0.0)
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
         g_traffic, _, g_src = committed_traffic({"ngrid": N, "particles": npart, "particle_order": "coarse-cell raster" if args.sorted_particles else "random",
@@ -359,7 +374,12 @@ def main_grid(args):
                           "particle_order": "coarse-cell raster" if args.sorted_particles else "random", "ngrid": N, "particles": npart, "halos_per_gpu": nh, "contributing_pairs_per_gpu": pairs[0],
                           "parallelism": "halo shards x%d + RCCL reduce(pix_offsets) -> rank 0 regrid + P(k)" % world if world > 1 else "single GPU"},
                "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
-               "kernel_ms_note": ("single GPU: 'regrid' = grid_copy_sum_kernel (map_out = map_in: a cell that is not moved deposits into itself), "
+               "fused_deposit": bool(fused),
+               "kernel_ms_note": ("single GPU, fused call (bfgx_grid_deposit_baryonify_device): the deposit's last kernel stores map_in, the start value of "
+                                  "map_out and the map's sum together (no grid_copy_sum_kernel); 'deposit' = the fused call minus the plan-timed kernels, "
+                                  "'offsets' = grid_gather_regrid_kernel (halo loop AND the regrid of the moved cells in one cell-owned pass), "
+                                  "'bin' = the per-block halo lists (count, scan, fill)") if fused else
+                                 ("single GPU: 'regrid' = grid_copy_sum_kernel (map_out = map_in: a cell that is not moved deposits into itself), "
                                   "'offsets' = grid_gather_regrid_kernel (halo loop AND the regrid of the moved cells in one cell-owned pass), "
                                   "'bin' = the per-block halo lists (count, scan, fill)") if world == 1 and not snapshot else None,
                "mass_conserved": bool(np.isclose(sums[1], sums[0])), "pk_finite_bins": int(np.isfinite(pk).sum()),

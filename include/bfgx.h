@@ -391,6 +391,14 @@ int  bfgx_grid_regrid_slab_device(bfgx_grid_plan *p, const double *map_in_dev, c
  * {sum(map_in), sum(map_out)}.  Same result as bfgx_grid_offsets_device + bfgx_grid_regrid_device up to the order of fp64 sums. */
 int  bfgx_grid_baryonify_device(bfgx_grid_plan *p, const bfgx_grid_catalog *cat_dev, const double *map_in_dev, double *map_out_dev,
                                 double *sums_dev, int64_t *n_pairs_host);
+/* ParticleSnapshot.make_map (io.py:622-670) + BaryonifyGrid.process (Map2DRunner.py:431-607) in one call, all pointers device, the
+ * whole grid on one GPU: the particles (x, y[, z], optional mass; unit mass when NULL) are histogrammed on the plan's grid with
+ * np.histogramdd's bin rule against edges_dev [npix + 1] -> map_in_dev, and the cell-owned pass of bfgx_grid_baryonify_device turns it
+ * into map_out_dev.  Same results as bfgx_deposit_particles_device followed by bfgx_grid_baryonify_device; the deposit stores map_out's
+ * start value and the map's sum along with map_in, so the map is not read again to copy it.  sums_dev as above. */
+int  bfgx_grid_deposit_baryonify_device(bfgx_grid_plan *p, const bfgx_grid_catalog *cat_dev, int64_t n_particles, const double *x,
+                                        const double *y, const double *z, const double *mass, const double *edges_dev, double *map_in_dev,
+                                        double *map_out_dev, double *sums_dev, int64_t *n_pairs_host);
 int  bfgx_grid_plan_timing_enable(bfgx_grid_plan *p, int on);
 int  bfgx_grid_plan_timing_read(bfgx_grid_plan *p, double *ms_sum, int64_t *launches);
 /* device-resident variants of the two deposit kernels and the P(k) summary (all pointers device) */

@@ -292,6 +292,52 @@ def test_grid_cell_owned_pass(gpu, ndim, N, nh):
     plan.close()
 
 
+@pytest.mark.parametrize('ndim,N,nh,npart,mass', [(3, 64, 600, 1_200_000, False), (3, 61, 400, 1_100_000, True), (2, 250, 40, 1_050_000, False),
+                                                    (3, 64, 600, 5000, False)])
+def test_fused_deposit_baryonify_equals_the_two_calls(gpu, ndim, N, nh, npart, mass):
+    """bfgx_grid_deposit_baryonify_device (make_map + BaryonifyGrid: the deposit's last kernel also stores the start value of map_out and
+    the map's sum) == bfgx_deposit_particles_device followed by bfgx_grid_baryonify_device: map_in bit for bit, map_out to the order of
+    the fp64 sums; the tile-owned deposit (>= 2^20 particles) and the atomic one (small inputs: the copy pass runs as before)"""
+    import torch
+    from baryonification_amd import _lib, engine
+    c = _big_case(ndim, N, nh, 23)
+    cat = c['cat']
+    cos = dict(c['cosmo'], w0=-1.0)
+    m, keep = engine.model_from_tables([np.log(1 + c['z']), np.log(c['Mt']), np.log(c['r'])], c['d'], cos, 6.0, 8.0)
+    dev = torch.device('cuda:0')
+    t = {k: torch.tensor(cat[k], dtype=torch.float64, device=dev) for k in ('M', 'x', 'y', 'z')}
+    lnM = torch.tensor(np.log(cat['M'].astype(np.float32)).astype(np.float64), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = engine.GridPlan(m, keep, c['bins'], ndim, c['redshift'], nh, 0, stream)
+    dcat = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr() if ndim == 3 else 0,
+                                      lnM.data_ptr())
+    bins = np.asarray(c['bins'], dtype=np.float64)
+    res = bins[1] - bins[0]
+    edges = np.concatenate([bins - res / 2, [bins[-1] + res / 2]])
+    rng = np.random.default_rng(4)
+    pos = rng.uniform(edges[0] - 0.01 * res, edges[-1] + 0.01 * res, (3, npart))          # a few particles outside the box: dropped
+    pos[:, :100] = edges[3]                                                                  # some exactly on a bin edge
+    part = torch.tensor(pos, device=dev)
+    pm = torch.tensor(rng.uniform(0.5, 2.0, npart), device=dev) if mass else None
+    d_edges = torch.tensor(edges, device=dev)
+    a_in, a_out, b_in, b_out = (torch.full((N ** ndim,), float('nan'), dtype=torch.float64, device=dev) for _ in range(4))
+    s_a, s_b = (torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(2))
+    engine.deposit_particles_device(part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr() if ndim == 3 else 0, pm.data_ptr() if mass else 0,
+                                    npart, N, d_edges.data_ptr(), a_in.data_ptr(), ndim, 0, stream)
+    n_a = plan.baryonify(dcat, a_in.data_ptr(), a_out.data_ptr(), s_a.data_ptr())
+    n_b = plan.deposit_baryonify(dcat, npart, part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr() if ndim == 3 else 0,
+                                 pm.data_ptr() if mass else 0, d_edges.data_ptr(), b_in.data_ptr(), b_out.data_ptr(), s_b.data_ptr())
+    torch.cuda.synchronize()
+    ai, ao, bi, bo = (v.cpu().numpy() for v in (a_in, a_out, b_in, b_out))
+    assert n_a == n_b > 0 and np.isfinite(bo).all()
+    # unit masses: every cell is an integer count, identical bit for bit; with masses the LDS adds of a tile arrive in any order
+    assert (np.abs(ai - bi).max() <= 1e-13 * ai.max() and ai.sum() > 0.5 * npart) if mass else (np.array_equal(ai, bi) and 0.9 * npart < ai.sum() < npart)
+    assert np.abs(ao - bo).max() <= 1e-12 * np.abs(ao).max() and not np.array_equal(bo, bi)
+    sa, sb = s_a.cpu().numpy(), s_b.cpu().numpy()
+    assert np.allclose(sa, sb, rtol=1e-12, atol=0) and np.isclose(sb[0], bi.sum(), rtol=1e-12) and np.isclose(sb[1], sb[0], rtol=1e-10)
+    plan.close()
+
+
 def test_grid_cell_owned_pass_refuses_what_it_cannot_do(gpu):
     """a plan that owns a slab, a plan holding a profile (log) table and a catalog larger than the plan fail loudly"""
     import torch
