@@ -154,7 +154,7 @@ class BaryonifyGrid(DefaultRunnerGrid):
         cat, cols = self._catalog(p_keys, rmat)
         grid, gkeep = self._grid()
         orig_map = _lib.f8(self.GriddedMap.map)
-        new_map = np.empty(orig_map.shape, dtype=np.float64)
+        new_map = _lib.pinned_empty(orig_map.size).reshape(orig_map.shape)     # page-locked and pooled: the copy back runs at the PCIe rate
         opts = _lib.bfgx_opts(int(self.device), 1, 1, 1, 1, 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_baryonify_grid(C.byref(cat), C.byref(model), C.byref(grid), orig_map.ctypes.data,
@@ -181,7 +181,7 @@ class PaintProfilesGrid(DefaultRunnerGrid):
         model, p_keys, keep = build_model(self, 'projected' if self.GriddedMap.is2D else 'real', self._runner_cosmo())
         cat, cols = self._catalog(p_keys, rmat)
         grid, gkeep = self._grid()
-        new_map = np.empty(self.GriddedMap.map.shape, dtype=np.float64)
+        new_map = _lib.pinned_empty(int(np.prod(self.GriddedMap.map.shape))).reshape(self.GriddedMap.map.shape)
         opts = _lib.bfgx_opts(int(self.device), 1, 1, 0, 1, 0)
         stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_paint_grid(C.byref(cat), C.byref(model), C.byref(grid), new_map.ctypes.data, C.byref(opts),

@@ -284,11 +284,12 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
 
 // nz[0 .. *nnz) = the blocks whose halo list is not empty (any order): one atomic per workgroup on the counter
 __global__ void __launch_bounds__(256)
-grid_nonempty_blocks_kernel(int64_t nblk, const int32_t *__restrict__ start, int32_t *__restrict__ nz, int32_t *__restrict__ nnz)
+grid_nonempty_blocks_kernel(int64_t blk_lo, int64_t nblk, const int32_t *__restrict__ start, int32_t *__restrict__ nz, int32_t *__restrict__ nnz)
 {
+    // (the blocks [blk_lo, nblk) that list a halo -> nz[0 ..), their number -> *nnz)
     __shared__ int s_n, s_base;
     __shared__ int32_t s_list[256];
-    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < nblk; b0 += (int64_t)gridDim.x * 256) {
+    for (int64_t b0 = blk_lo + (int64_t)blockIdx.x * 256; b0 < nblk; b0 += (int64_t)gridDim.x * 256) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         const int64_t b = b0 + threadIdx.x;

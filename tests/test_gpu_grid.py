@@ -742,3 +742,37 @@ def test_callable_models_on_the_grid_and_snapshot_runners(gpu):
     assert scale > 1e-3 and np.abs(got - oras).max() <= max(1e-10 * scale, 1e-13 * L)
     with pytest.raises(TypeError):
         bfg.Runners.BaryonifyGrid(HCat2, GMap2, 5.0, object(), verbose=False).process()
+
+
+@pytest.mark.parametrize('ndim,N,nh,chunks', [(3, 64, 700, 4), (3, 61, 500, 3), (3, 96, 900, 6), (2, 250, 60, 5), (2, 512, 300, 8)])
+def test_grid_host_entry_in_plane_ranges_equals_one_pass(gpu, monkeypatch, ndim, N, nh, chunks):
+    """BaryonifyGrid.process() streams the map in ranges of whole block rows (upload, copy + gather, download overlapped; the first block
+    row gathered last because the grid is periodic) == the one-pass route == the oracle; plans and device maps are cached between calls"""
+    import baryonification_amd as bfg
+    c = _big_case(ndim, N, nh, 31)
+    cat = c['cat']
+    # halos on the first / last planes so that deposits cross the periodic face and the range boundaries
+    cat['x'][:20] = np.float32(0.01 * c['L'] / N); cat['y'][20:40] = np.float32(c['L'] * (1 - 0.01 / N))
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(c['cosmo']), epsilon_max=8.0)
+    model.set_table(c['z'], c['Mt'], c['r'], c['d'])
+    kw = dict(x=cat['x'], y=cat['y'], M=cat['M'], redshift=c['redshift'], cosmo=c['cosmo'])
+    if ndim == 3:
+        kw['z'] = cat['z']
+    HCat = bfg.utils.HaloNDCatalog(**kw)
+    GMap = bfg.utils.GriddedMap(map=c['map'], redshift=c['redshift'], bins=c['bins'], cosmo=c['cosmo'])
+    runner = bfg.Runners.BaryonifyGrid(HCat, GMap, 6.0, model, verbose=False)
+    monkeypatch.setenv('BFGX_NO_PIPELINE', '1')
+    one = runner.process().copy()
+    monkeypatch.delenv('BFGX_NO_PIPELINE')
+    monkeypatch.setenv('BFGX_PIPE_CHUNKS', str(chunks))
+    piped = runner.process().copy()
+    again = runner.process().copy()                                     # warm: cached plan, pooled pinned result
+    assert np.abs(piped - one).max() <= 1e-12 * np.abs(one).max() and np.abs(again - one).max() <= 1e-12 * np.abs(one).max()
+    assert not np.array_equal(one, c['map']) and np.isclose(piped.sum(), c['map'].sum())
+    cos = dict(c['cosmo'], w0=-1.0)                                     # the grid runners drop w0 (Map2DRunner.py:456-459)
+    ocat = {k: np.asarray(HCat.cat[k], dtype=np.float64) for k in (('M', 'x', 'y', 'z') if ndim == 3 else ('M', 'x', 'y'))}
+    ocat.setdefault('z', np.zeros(nh))
+    ora = H.grid_oracle_run(dict(kind='baryonify', tab_z=c['z'], tab_M=c['Mt'], tab_r=c['r'], tab_values=c['d'], rdelta=False, eps_model=8.0,
+                                 map_in=c['map'], bins=c['bins'], cat=ocat, redshift=c['redshift'], eps_runner=6.0, cosmo_runner=cos,
+                                 cosmo_model=c['cosmo'], rmat=None))
+    assert np.abs(piped - ora).max() <= 1e-10 * np.abs(ora).max()
