@@ -29,6 +29,7 @@ class DefaultRunnerSnapshot(object):
         self.verbose = verbose
         self.tree = None               # the reference keeps a scipy KDTree here; the GPU path needs none
         self.device = 0
+        self.use_records = True        # engine knob: hand the structured array to the library as it is (False: gather the columns on the host)
         self.last_stats = None
 
     def enforce_periodicity(self, dx):
@@ -59,14 +60,30 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
         with np.errstate(invalid='ignore', divide='ignore'):
             lnM = np.log(np.asarray(hcat['M'], dtype=np.float32)).astype(np.float64)     # float32 log, as BaryonifyGrid
         cat, cols = _lib.make_grid_catalog_host(hcat['M'], hcat['x'], hcat['y'], None if is2D else hcat['z'], lnM)
+        opts = _lib.bfgx_opts(int(self.device), 1, 1, 0, 1, 0)
+        stats = _lib.bfgx_stats()
+        rec = snap.cat
+        fields = rec.dtype.fields or {}
+        ok = (getattr(self, 'use_records', True) and isinstance(rec, np.ndarray) and rec.ndim == 1 and rec.flags.c_contiguous and rec.dtype.itemsize % 8 == 0 and rec.dtype.itemsize >= 16 and
+              all(k in fields and fields[k][0] == np.float64 and fields[k][1] % 8 == 0 for k in (('x', 'y') if is2D else ('x', 'y', 'z'))))
+        if ok:
+            # the records as they are: uploaded in chunks, displaced in place on the device, downloaded into the new catalog -- the host
+            # neither gathers the strided columns nor scatters them back (`new_cat = cat.copy(); new_cat['x'] = ...`, SnapshotRunner.py:254-262)
+            new_cat = _lib.pinned_empty(rec.size * rec.dtype.itemsize, np.uint8).view(rec.dtype) if rec.size else rec.copy()
+            rc = _lib.load().bfgx_baryonify_snapshot_records(
+                C.byref(cat), C.byref(model), 2 if is2D else 3, float(snap.L), float(self.HaloNDCatalog.redshift), rec.size,
+                rec.ctypes.data if rec.size else None, new_cat.ctypes.data if rec.size else None, rec.dtype.itemsize, fields['x'][1], fields['y'][1],
+                0 if is2D else fields['z'][1], C.byref(opts), C.byref(stats))
+            _lib.check(rc)
+            self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+            del keep, cols
+            return new_cat
         x, y = _lib.f8(snap.cat['x']), _lib.f8(snap.cat['y'])
         z = None if is2D else _lib.f8(snap.cat['z'])
         s = _lib.bfgx_snapshot(2 if is2D else 3, 0, x.size, x.ctypes.data, y.ctypes.data, None if is2D else z.ctypes.data,
                                float(snap.L), float(self.HaloNDCatalog.redshift))
         ox, oy = np.empty_like(x), np.empty_like(y)
         oz = None if is2D else np.empty_like(z)
-        opts = _lib.bfgx_opts(int(self.device), 1, 1, 0, 1, 0)
-        stats = _lib.bfgx_stats()
         rc = _lib.load().bfgx_baryonify_snapshot(C.byref(cat), C.byref(model), C.byref(s), ox.ctypes.data, oy.ctypes.data,
                                                  None if is2D else oz.ctypes.data, C.byref(opts), C.byref(stats))
         _lib.check(rc)

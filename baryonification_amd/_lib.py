@@ -150,6 +150,8 @@ SYMBOLS = {
     'bfgx_power_spectrum': (C.c_int, [C.c_int, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_baryonify_snapshot': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_snapshot), C.c_void_p, C.c_void_p, C.c_void_p,
                                           _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_baryonify_snapshot_records': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_void_p,
+                                                  C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(bfgx_opts), _P(bfgx_stats)]),
     'bfgx_baryonify_snapshot_device': (C.c_int, [C.c_int, C.c_void_p, _P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_snapshot), C.c_void_p,
                                                  C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     'bfgx_snapshot_plan_create': (C.c_int, [C.c_int, C.c_void_p, _P(bfgx_model), C.c_int32, C.c_double, C.c_double, C.c_int64, _P(C.c_void_p)]),

@@ -280,11 +280,14 @@ constexpr int kSnapQueue = 768;                      // queued hits per 256 part
 
 template <int DIM>
 __global__ void __launch_bounds__(256)
-snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restrict__ px, const double *__restrict__ py,
-                     const double *__restrict__ pz, const SnapHaloRec *__restrict__ recs, const uint32_t *__restrict__ bitmap,
-                     const int32_t *__restrict__ cell_start, const SnapEntry *__restrict__ entries, double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ oz,
-                     int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total)
+snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, const double *py,
+                     const double *pz, const SnapHaloRec *__restrict__ recs, const uint32_t *__restrict__ bitmap,
+                     const int32_t *__restrict__ cell_start, const SnapEntry *__restrict__ entries, double *ox, double *oy, double *oz,
+                     int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total, int64_t sin, int64_t sout)
 {
+    // sin / sout: distance in doubles between consecutive particles of the input / output columns (1: plain columns; the records entry
+    // passes the record size / 8 and column pointers into the record buffer -- possibly the SAME buffer: a particle's own coordinates are
+    // read before they are written, and no other thread reads them)
     __shared__ double spos[3][256], sacc[3][256];
     __shared__ int qslot[kSnapQueue], qent[kSnapQueue];
     __shared__ int qn;
@@ -344,7 +347,7 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
     for (int64_t base = (int64_t)blockIdx.x * 256; base < np; base += (int64_t)gridDim.x * 256) {
         const int64_t p = base + tid;
         const bool on = p < np;
-        const double x = on ? px[p] : 0.0, y = on ? py[p] : 0.0, z = (DIM == 3 && on) ? pz[p] : 0.0;
+        const double x = on ? px[p * sin] : 0.0, y = on ? py[p * sin] : 0.0, z = (DIM == 3 && on) ? pz[p * sin] : 0.0;
         spos[0][tid] = x; spos[1][tid] = y; spos[2][tid] = z;
         sacc[0][tid] = 0.0; sacc[1][tid] = 0.0; sacc[2][tid] = 0.0;
         if (tid == 0) qn = 0;
@@ -381,11 +384,11 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *__restr
             if (nx < 0.0) nx += g.L;
             if (ny > g.L) ny -= g.L;
             if (ny < 0.0) ny += g.L;
-            ox[p] = nx; oy[p] = ny;
+            ox[p * sout] = nx; oy[p * sout] = ny;
             if (DIM == 3) {
                 if (nz > g.L) nz -= g.L;
                 if (nz < 0.0) nz += g.L;
-                oz[p] = nz;
+                oz[p * sout] = nz;
             }
         }
         __syncthreads();                                   // the LDS buffers are reused by the next block of particles

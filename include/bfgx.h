@@ -453,6 +453,15 @@ typedef struct bfgx_snapshot {
 
 int bfgx_baryonify_snapshot(const bfgx_grid_catalog *halos_host, const bfgx_model *model, const bfgx_snapshot *snap_host,
                             double *x_out_host, double *y_out_host, double *z_out_host, const bfgx_opts *opts, bfgx_stats *stats);
+/* The same on the snapshot's RECORDS as ParticleSnapshot keeps them (io.py:378-470: one structured array `cat` with float64 fields M, x, y,
+ * z): records_in [n][itemsize bytes] is copied to the device in chunks, the coordinate fields at byte offsets off_x / off_y / off_z (off_z
+ * ignored in 2-D) are displaced in place, and the records -- every other field untouched -- arrive in records_out (may not alias
+ * records_in): what `new_cat = cat.copy(); new_cat['x'] = ...` (SnapshotRunner.py:254-262) leaves, without a strided gather or scatter
+ * of the columns on the host.  Upload, displacement and download of successive chunks overlap; plan and device buffer are cached
+ * (bfgx_cache_clear).  itemsize and the offsets must be multiples of 8. */
+int bfgx_baryonify_snapshot_records(const bfgx_grid_catalog *halos_host, const bfgx_model *model, int32_t ndim, double L, double redshift,
+                                    int64_t n, const void *records_in, void *records_out, int32_t itemsize, int32_t off_x, int32_t off_y,
+                                    int32_t off_z, const bfgx_opts *opts, bfgx_stats *stats);
 /* resident form: the model and the halo-cell workspace live in a plan (one per box / redshift / model); all columns and
  * outputs are device pointers (out may not alias in); blocking (two small read-backs) */
 typedef struct bfgx_snapshot_plan bfgx_snapshot_plan;

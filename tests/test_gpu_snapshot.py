@@ -128,3 +128,50 @@ def test_snapshot_edge_cases(gpu):
     runner2 = H.snapshot_product_runner(g)
     runner2.ParticleSnapshot = bfg.utils.ParticleSnapshot(x=np.zeros(0), y=np.zeros(0), z=None, M=np.zeros(0), L=g['L'], redshift=g['redshift'], cosmo=cos)
     assert runner2.process().size == 0
+
+
+@pytest.mark.parametrize('ndim,chunks', [(3, 1), (3, 5), (2, 3), (3, 64)])
+def test_snapshot_records_entry_streamed_equals_columns(gpu, monkeypatch, ndim, chunks):
+    """bfgx_baryonify_snapshot_records (the structured array uploaded in chunks, displaced in place, downloaded into the new catalog)
+    == the column entry (host gathers x, y, z, library displaces, host scatters them into a copy): same positions bit for bit, every other
+    field untouched, the input catalog unchanged"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    rng = np.random.default_rng(70 + ndim)
+    L, nh, npart, zr = 250.0, 1200, 200_003, 0.1
+    M = (10 ** rng.uniform(12.8, 15.0, nh)).astype(np.float32).astype(np.float64)
+    hpos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    part = rng.uniform(0, L, (npart, 3))
+    part[:40_000] = (hpos[rng.integers(0, nh, 40_000)] + rng.normal(scale=1.0, size=(40_000, 3))) % L
+    z, Mt, r = np.linspace(0.05, 0.15, 3), np.geomspace(10 ** 12.7, 10 ** 15.1, 8), np.geomspace(1e-3, 2e2, 200)
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO), epsilon_max=6.0)
+    model.set_table(z, Mt, r, syn.displacement_table(z, Mt, r) * 20)
+    kw = dict(x=hpos[:, 0], y=hpos[:, 1], M=M, redshift=zr, cosmo=syn.COSMO)
+    pk = dict(x=part[:, 0], y=part[:, 1], M=rng.uniform(1, 2, npart), L=L, redshift=zr, cosmo=syn.COSMO)
+    if ndim == 3:
+        kw['z'] = hpos[:, 2]; pk['z'] = part[:, 2]
+    HCat, Snap = bfg.utils.HaloNDCatalog(**kw), bfg.utils.ParticleSnapshot(**pk)
+    before = Snap.cat.copy()
+    runner = bfg.Runners.BaryonifySnapshot(HCat, Snap, 5.0, model, verbose=False)
+    runner.use_records = False
+    cols = runner.process()
+    n_cols = runner.last_stats['n_pairs']
+    runner.use_records = True
+    monkeypatch.setenv('BFGX_PIPE_CHUNKS', str(chunks))
+    recs = runner.process()
+    assert recs.dtype == Snap.cat.dtype and recs is not Snap.cat and runner.last_stats['n_pairs'] == n_cols > 1000
+    def same(a, b):          # (a particle inside several balls sums their offsets in the order the LDS adds arrive: last bits differ run to run)
+        return np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b), initial=0.0) <= 1e-13 * L
+    for k in ('x', 'y', 'z', 'M'):
+        assert same(recs[k], cols[k]), k
+    assert np.array_equal(Snap.cat, before) and np.array_equal(recs['M'], before['M'])
+    assert 0.01 < np.mean(recs['x'] != before['x']) < 0.99             # (2-D: projected balls cover most of the box)
+    again = runner.process()                                           # warm call: cached plan and device buffer, pooled result
+    assert same(again['x'], cols['x'])
+    # a catalog whose records the library cannot take as they are (a float32 field in front: 4-byte offsets) falls back to the columns
+    odd = np.zeros(npart, dtype=[('tag', np.float32), ('M', np.float64), ('x', np.float64), ('y', np.float64), ('z', np.float64)])
+    for k in ('M', 'x', 'y', 'z'):
+        odd[k] = before[k]
+    Snap.cat = odd
+    out = runner.process()
+    assert out.dtype == odd.dtype and same(out['x'], cols['x']) and np.array_equal(out['tag'], odd['tag'])
