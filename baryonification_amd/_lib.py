@@ -147,6 +147,8 @@ SYMBOLS = {
     'bfgx_regrid_pixels': (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_deposit_particles': (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p]),
+    'bfgx_deposit_particles_records': (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_void_p, C.c_void_p]),
     'bfgx_power_spectrum': (C.c_int, [C.c_int, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_baryonify_snapshot': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), _P(bfgx_snapshot), C.c_void_p, C.c_void_p, C.c_void_p,
                                           _P(bfgx_opts), _P(bfgx_stats)]),

@@ -1194,7 +1194,7 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
     }
 }
 
-namespace { void dep_release_all(); void fft_release_all(); void gcache_release_all(); void scache_release_all(); }
+namespace { void dep_release_all(); void fft_release_all(); void gcache_release_all(); void scache_release_all(); void deprec_release_all(); }
 
 extern "C" {
 
@@ -1536,6 +1536,7 @@ void bfgx_cache_clear(void)
     fft_release_all();           // twiddle / wavenumber tables of the power spectrum
     gcache_release_all();        // plans + device maps of the one-shot grid entries
     scache_release_all();        // plan + device record buffer of the snapshot records entry
+    deprec_release_all();        // device buffers of the deposit's records entry
 }
 
 long long bfgx_debug_alloc_count(void) { return (long long)g_bfgx_allocs.load(); }

@@ -69,8 +69,9 @@ constexpr uint32_t kDepNoKey = 0xffffffffu;        // particle outside the edges
 template <int DIM>
 __global__ void __launch_bounds__(256)
 deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                    const double *__restrict__ edges, uint32_t *__restrict__ keys, int32_t *__restrict__ wg_hist)
+                    const double *__restrict__ edges, uint32_t *__restrict__ keys, int32_t *__restrict__ wg_hist, int64_t stride)
 {
+    // stride: doubles between consecutive particles of a column (1: plain columns; > 1: fields of a record buffer)
     __shared__ int hist[1024];
     __shared__ double sedge[kDepEdgesLds];
     const int tid = threadIdx.x;
@@ -91,7 +92,7 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
             for (int q = 0; q < kBatch; ++q) {
                 const int64_t p = base + (q0 + q) * 256 + tid;
                 const bool on = p < n;
-                vx[q] = on ? x[p] : 0.0; vy[q] = on ? y[p] : 0.0; vz[q] = (DIM == 3 && on) ? z[p] : 0.0;
+                vx[q] = on ? x[p * stride] : 0.0; vy[q] = on ? y[p * stride] : 0.0; vz[q] = (DIM == 3 && on) ? z[p * stride] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) {
@@ -159,8 +160,9 @@ template <int LEVEL, bool MASS>
 __global__ void __launch_bounds__(256)
 deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_dev, const uint32_t *__restrict__ keys_in,
                      const double *__restrict__ mass_in, const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
-                     uint32_t *__restrict__ keys_out, double *__restrict__ mass_out)
+                     uint32_t *__restrict__ keys_out, double *__restrict__ mass_out, int64_t mstride)
 {
+    // mstride: doubles between consecutive masses of mass_in (1 unless level 1 reads a field of a record buffer)
     __shared__ int hist[kDepHist];                  // per bucket: count -> local prefix -> (global base - local prefix)
     __shared__ uint32_t skey[kDepChunk];
     __shared__ double smass[MASS ? kDepChunk : 1];
@@ -210,7 +212,7 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
         if (rank[q] >= 0) {
             const int slot = hist[dep_bucket<LEVEL>(g, key[q]) - bmin] + rank[q];
             skey[slot] = key[q];
-            if (MASS) smass[slot] = mass_in[base + q * 256 + tid];
+            if (MASS) smass[slot] = mass_in[(base + q * 256 + tid) * mstride];
         } else if (rank[q] == -2) {                 // bucket beyond the local table (almost empty buckets only)
             const int b = dep_bucket<LEVEL>(g, key[q]);
             const int64_t dst = (int64_t)start[b] + atomicAdd(cursor + b, 1);

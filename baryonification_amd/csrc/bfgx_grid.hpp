@@ -444,19 +444,28 @@ template <int DIM>
 __global__ void __launch_bounds__(256)
 particle_deposit_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                         const double *__restrict__ mass, int nb, const double *__restrict__ edges, double *__restrict__ out,
-                        int plane_lo, int plane_n)
+                        int plane_lo, int plane_n, int64_t stride)
 {
     // out holds the planes [plane_lo, plane_lo + plane_n) of the first axis (the whole grid: 0, nb)
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const double scale = (double)nb / (edges[nb] - edges[0]);
-    int bx = histogram_bin(edges, nb, x[p], scale);
-    const int by = histogram_bin(edges, nb, y[p], scale);
-    const int bz = (DIM == 3) ? histogram_bin(edges, nb, z[p], scale) : 0;
+    int bx = histogram_bin(edges, nb, x[p * stride], scale);
+    const int by = histogram_bin(edges, nb, y[p * stride], scale);
+    const int bz = (DIM == 3) ? histogram_bin(edges, nb, z[p * stride], scale) : 0;
     bx = (bx >= plane_lo && bx < plane_lo + plane_n) ? bx - plane_lo : -1;
     if (bx < 0 || by < 0 || bz < 0) return;
     const int64_t flat = (DIM == 3) ? ((int64_t)bx * nb + by) * nb + bz : (int64_t)bx * nb + by;
-    atomicAdd(out + flat, mass ? mass[p] : 1.0);
+    atomicAdd(out + flat, mass ? mass[p * stride] : 1.0);
+}
+
+// *flag |= 1 when any of n doubles at ptr[i * stride] is NaN (ParticleSnapshot.make_map's assert on the masses, io.py:636)
+__global__ void __launch_bounds__(256)
+nan_scan_strided_kernel(int64_t n, const double *__restrict__ ptr, int64_t stride, int32_t *__restrict__ flag)
+{
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) any |= (ptr[i * stride] != ptr[i * stride]);
+    if (__any(any) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(flag, 1);
 }
 
 }  // namespace bfgx

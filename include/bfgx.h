@@ -359,6 +359,12 @@ int bfgx_regrid_pixels(int device, int32_t ndim, int32_t npix, int64_t n, const 
  * given by the caller), weights = mass (NULL -> 1).  x, y, z host arrays; z NULL for 2D. */
 int bfgx_deposit_particles(int device, int32_t ndim, int64_t n, const double *x, const double *y, const double *z,
                            const double *mass, int32_t n_grid, const double *edges, double *map_out_host);
+/* The same on the snapshot's RECORDS (io.py:378-470: one structured array with float64 fields M, x, y, z): records [n][itemsize bytes] go
+ * to the device as they are and the kernels read the fields at byte offsets off_x / off_y / off_z (ignored in 2-D) / off_mass (< 0: unit
+ * masses) -- the four strided column gathers of make_map's host side (io.py:640-650) do not happen.  itemsize and the offsets must be
+ * multiples of 8.  Device buffers are kept between calls (bfgx_cache_clear). */
+int bfgx_deposit_particles_records(int device, int32_t ndim, int64_t n, const void *records, int32_t itemsize, int32_t off_x, int32_t off_y,
+                                   int32_t off_z, int32_t off_mass, int32_t n_grid, const double *edges, double *map_out);
 /* |FFT(map)|^2 averaged in nk linear k-bins between 2 pi / L and the Nyquist frequency (3D, n_grid a power of two):
  * pk[nk], kcen[nk] (mean |k| per bin), counts[nk] (modes per bin).  Empty bins give NaN as in the notebook. */
 int bfgx_power_spectrum(int device, int32_t n_grid, const double *map_host, double L, int32_t nk,

@@ -776,3 +776,35 @@ def test_grid_host_entry_in_plane_ranges_equals_one_pass(gpu, monkeypatch, ndim,
                                  map_in=c['map'], bins=c['bins'], cat=ocat, redshift=c['redshift'], eps_runner=6.0, cosmo_runner=cos,
                                  cosmo_model=c['cosmo'], rmat=None))
     assert np.abs(piped - ora).max() <= 1e-10 * np.abs(ora).max()
+
+
+def test_make_map_records_entry_equals_columns(gpu):
+    """ParticleSnapshot.make_map hands the structured array to the library as it is (bfgx_deposit_particles_records: fields read at their
+    stride on the device) == the column entry a catalog with an unaligned layout falls back to"""
+    import baryonification_amd as bfg
+    rng = np.random.default_rng(9)
+    L, N, npart = 100.0, 96, 1_200_000
+    xyz = rng.uniform(-0.01 * L, 1.01 * L, (npart, 3))
+    mass = rng.uniform(0.5, 2.0, npart)
+    Snap = bfg.utils.ParticleSnapshot(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2], M=mass, L=L, redshift=0.0, cosmo=H.load_grid_golden('grid2d_paint')['cosmo_runner'])
+    a = Snap.make_map(N).copy()
+    odd = np.zeros(npart, dtype=[('tag', np.float32), ('M', np.float64), ('x', np.float64), ('y', np.float64), ('z', np.float64)])
+    for k in ('M', 'x', 'y', 'z'):
+        odd[k] = Snap.cat[k]
+    Snap.cat = odd
+    b = Snap.make_map(N)
+    assert np.array_equal(a != 0, b != 0) and np.abs(a - b).max() <= 1e-12 * a.max() and np.isclose(a.sum(), mass[(xyz >= 0).all(1) & (xyz <= L).all(1)].sum())
+
+
+def test_make_map_refuses_nan_masses_as_the_reference(gpu):
+    """io.py:636: `assert np.isnan(self.cat['M']).sum() == 0` -- on the records path the library makes the check on the device"""
+    import baryonification_amd as bfg
+    rng = np.random.default_rng(2)
+    xyz = rng.uniform(0, 50.0, (5000, 3))
+    m = np.ones(5000)
+    m[4321] = np.nan
+    Snap = bfg.utils.ParticleSnapshot(x=xyz[:, 0], y=xyz[:, 1], z=xyz[:, 2], M=m, L=50.0, redshift=0.0, cosmo=H.load_grid_golden('grid2d_paint')['cosmo_runner'])
+    with pytest.raises(AssertionError, match="provide a value for the particle mass"):
+        Snap.make_map(16)
+    Snap.cat['M'][4321] = 1.0
+    assert Snap.make_map(16).sum() == 5000
