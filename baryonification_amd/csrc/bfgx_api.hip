@@ -109,6 +109,10 @@ struct bfgx_plan {
     Tiling tiling;
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
             *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
+    // narrow halos over <= 4 tiles are placed by K0 itself into fixed-capacity lists [ntiles][entries_a_cap]; the others are listed per K0
+    // workgroup for the placement pass; tile_zeros: ntiles zeros (the shared entry list holds only the regions [B | wide] of a tile)
+    int32_t *entries_a = nullptr, *slow_list = nullptr, *slow_cnt = nullptr, *tile_zeros = nullptr;
+    int32_t entries_a_cap = 0;
     TileRef *tref = nullptr;
     FarList far;                     // deposits of the gathering regrid that need the generic route (bfgx_regrid2.hpp)
     int32_t *far_overflow_full = nullptr;   // full-map regrid: overflow of the list is repaired in-stream (pass 1), not an error
@@ -283,7 +287,10 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
     o.fast = (bin && use_fast(p)) ? 1 : 0;
     o.rec_all = (rec_all || !o.fast) ? 1 : 0;
     o.rowrec = p->rowrec; o.pairrec = p->pairrec; o.fbrec = p->fbrec;
-    if (bin) { o.tref = p->tref; o.cnt_a = p->tile_count; o.cnt_b = p->tile_count_b; o.cnt_w = p->tile_count_w; }
+    if (bin) {
+        o.tref = p->tref; o.cnt_a = p->tile_count; o.cnt_b = p->tile_count_b; o.cnt_w = p->tile_count_w;
+        o.entries_a = o.fast ? p->entries_a : nullptr; o.cap_a = p->entries_a_cap; o.slow_list = p->slow_list; o.slow_cnt = p->slow_cnt;
+    }
     o.ncell_m = p->model.tab.n[1] - 1; o.nrm1 = p->model.tab.n[2] - 1;
 #define BFGX_PREP(NCV, REAL)                                                                                        \
     hipLaunchKernelGGL((halo_prep_kernel<NCV, REAL>), dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
@@ -300,8 +307,9 @@ static int launch_place(bfgx_plan *p, const bfgx_catalog *c)
 {
     const unsigned grid = (unsigned)((c->n + 255) / 256);
     hipLaunchKernelGGL(tile_place_kernel, dim3(grid), dim3(256), 0, p->stream, p->hpx, p->tiling, c->n,
-                       (const TileRef *)p->tref, (const int32_t *)p->tile_start, (const int32_t *)p->tile_count,
-                       (const int32_t *)p->tile_count_b, p->tile_cursor, p->tile_cursor_w, p->entries, p->capacity, p->overflow);
+                       (const TileRef *)p->tref, (const int32_t *)p->tile_start, (const int32_t *)p->tile_zeros,
+                       (const int32_t *)p->tile_count_b, p->tile_cursor, p->tile_cursor_w, p->entries, p->capacity, p->overflow,
+                       (const int32_t *)p->slow_list, (const int32_t *)p->slow_cnt);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -315,14 +323,14 @@ static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback
     KernelTimer kt(p, BFGX_K_BIN);
     const int nt_i = p->tiling.ntiles, nsb = (nt_i + kScanTilesPerWg - 1) / kScanTilesPerWg;
     if (nsb <= 1 || nsb > 1024) {
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_count,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_zeros,
                            (const int32_t *)p->tile_count_b, (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles);
     } else {        // NSIDE >= 2048: the scan spread over the tiles' blocks (three short launches instead of up to 48 serial rounds)
         int32_t *tot = p->wide_tiles + nt_i + 1, *off = tot + 2048;
-        hipLaunchKernelGGL(tile_scan_part_kernel<0>, dim3(nsb), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
+        hipLaunchKernelGGL(tile_scan_part_kernel<0>, dim3(nsb), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_zeros, (const int32_t *)p->tile_count_b,
                            (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles, tot, (const int32_t *)off);
         hipLaunchKernelGGL(tile_scan_blocks_kernel, dim3(1), dim3(1024), 0, p->stream, nsb, nt_i, (const int32_t *)tot, off, p->tile_start, p->wide_tiles);
-        hipLaunchKernelGGL(tile_scan_part_kernel<1>, dim3(nsb), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
+        hipLaunchKernelGGL(tile_scan_part_kernel<1>, dim3(nsb), dim3(1024), 0, p->stream, nt_i, (const int32_t *)p->tile_zeros, (const int32_t *)p->tile_count_b,
                            (const int32_t *)p->tile_count_w, p->tile_start, p->wide_tiles, tot, (const int32_t *)off);
     }
     HIP_TRY(hipGetLastError());
@@ -355,7 +363,7 @@ static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out, bool wide_only)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kWavesPerBlock), lds, p->stream,
                        make_pair_table(p->model.tab), p->hpx, p->tiling, (const HaloRec *)p->recs, (const RowSetX *)p->rowsx,
                        (const int32_t *)p->tile_start, (const int32_t *)p->entries, p->capacity, out, p->pair_total,
-                       wide_only ? (const int32_t *)p->tile_count : (const int32_t *)nullptr,
+                       wide_only ? (const int32_t *)p->tile_zeros : (const int32_t *)nullptr,
                        wide_only ? (const int32_t *)p->tile_count_b : (const int32_t *)nullptr, wide_only ? 1 : 0,
                        wide_only ? (const int32_t *)p->wide_tiles : (const int32_t *)nullptr,
                        (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
@@ -384,7 +392,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
-                       (const int32_t *)p->entries, p->capacity, out, p->pair_total, tile_counter,
+                       (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, out, p->pair_total, tile_counter,
                        (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
                        p->k1_tile_lo, p->k1_tile_n);
     HIP_TRY(hipGetLastError());
@@ -650,6 +658,21 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         p->tile_cursor = p->tile_count + 3 * (T.ntiles + 1); p->tile_cursor_w = p->tile_count + 4 * (T.ntiles + 1);
         p->tile_start = (int32_t *)d1; p->tref = (TileRef *)d6;
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
+        {
+            // capacity of a tile's fixed list: 16 x the mean entries per tile (a rank of an N-GPU run bins its share of the halos into 1 / N
+            // of the tiles; a sky patch does the same), a power of two in [64, 2048], the whole array at most 1 GB
+            const double mean = 1.3 * (double)std::max<int64_t>(max_halos, 1) / (double)T.ntiles;
+            int cap_a = 64;
+            while (cap_a < 2048 && (double)cap_a < 16.0 * mean + 64.0) cap_a <<= 1;
+            while (cap_a > 64 && (size_t)T.ntiles * cap_a * sizeof(int32_t) > ((size_t)1 << 30)) cap_a >>= 1;
+            if (const char *e = std::getenv("BFGX_TILE_LIST_CAP")) cap_a = std::max(1, std::atoi(e));        // tests: force the overflow into region B
+            void *da = nullptr, *ds = nullptr, *dc = nullptr;
+            const size_t nblk = ((size_t)std::max<int64_t>(max_halos, 1) + 255) / 256;
+            if (dalloc(sizeof(int32_t) * (size_t)T.ntiles * cap_a, &da) || dalloc(sizeof(int32_t) * nblk * 256, &ds) || dalloc(sizeof(int32_t) * nblk, &dc))
+                return bail(fail(BFGX_ERR_HIP, "hipMalloc(tile lists) failed"));
+            p->entries_a = (int32_t *)da; p->slow_list = (int32_t *)ds; p->slow_cnt = (int32_t *)dc; p->entries_a_cap = cap_a;
+            p->tile_zeros = p->tile_count + 5 * ((size_t)T.ntiles + 1) + 1;      // the words behind K1's tile counter: zeroed with the counters, never written
+        }
         {
             void *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *f3 = nullptr;
             p->far.cap = std::max<int64_t>((int64_t)1 << 20, p->hpx.npix / 16);

@@ -537,6 +537,12 @@ struct PrepOut {
     FbRec *fbrec;
     TileRef *tref;                // tile binning (nullptr: no binning)
     int32_t *cnt_a, *cnt_b, *cnt_w;
+    // direct placement of the narrow halos that touch <= kRefMax tiles (almost all of them): their slot in a tile's FIXED-CAPACITY list
+    // entries_a[tile][cap_a] is the value the counting atomic returns, so K0 stores the halo index there itself -- no TileRef, no placement
+    // pass.  Only the others (wide discs, discs over more than kRefMax tiles, slots beyond cap_a) are listed per K0 workgroup
+    // (slow_list[block][256], slow_cnt[block]) for tile_place_kernel, which draws their slots from cursors after the scan.
+    int32_t *entries_a, *slow_list, *slow_cnt;
+    int32_t cap_a;
     int32_t fast;                 // 1: narrow halos are class kClsNarrow (fast kernel), 0: every halo is kClsWide (generic kernel)
     int32_t rec_all;              // 1: HaloRec for every halo (halo-centric algo 0)
     int32_t ncell_m, nrm1;        // (nm - 1), (nr - 1) of the interleaved table
@@ -546,6 +552,14 @@ struct PrepOut {
 // record.  `real` = precision of the fast kernel's pair records.  lnz1 / lnM (optional): ln(1 + z), ln M computed by the
 // caller (numpy on the host), so that halos on a table edge are classified exactly as the reference does (README.md:78-80).
 template <int NC, typename real>
+__device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, const double *gz, const double *gm,
+                                              const double *__restrict__ M, const double *__restrict__ z,
+                                              const double *__restrict__ ra, const double *__restrict__ dec,
+                                              const double *__restrict__ ex0, const double *__restrict__ ex1,
+                                              const double *__restrict__ lnz1, const double *__restrict__ lnM,
+                                              int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow);
+
+template <int NC, typename real>
 __global__ void __launch_bounds__(256)
 halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ M, const double *__restrict__ z,
@@ -554,6 +568,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ lnz1, const double *__restrict__ lnM,
                  int fallback4, Tiling T, PrepOut o)
 {
+    __shared__ int s_nslow;                               // halos of this workgroup left to the placement pass
+    if (threadIdx.x == 0) s_nslow = 0;
     // the (z, M) axes of the table go to LDS when they are short (the usual 10 - 30 nodes)
     constexpr int kAxisLds = 128;
     __shared__ double ax_lds[2 * kAxisLds];
@@ -574,8 +590,23 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         __syncthreads();
         T.band_tile0 = band_lds; T.band_nphi = band_lds + kBandLds + 1; T.band_nrmin = band_lds + 2 * kBandLds + 1;
     }
+    __syncthreads();                                       // (s_nslow)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nhalo) return;
+    if (j < nhalo) halo_prep_one<NC, real>(m, h, j, gz, gm, M, z, ra, dec, ex0, ex1, lnz1, lnM, fallback4, T, o, &s_nslow);
+    if (o.slow_cnt) {
+        __syncthreads();
+        if (threadIdx.x == 0) o.slow_cnt[blockIdx.x] = s_nslow;
+    }
+}
+
+template <int NC, typename real>
+__device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, const double *gz, const double *gm,
+                                              const double *__restrict__ M, const double *__restrict__ z,
+                                              const double *__restrict__ ra, const double *__restrict__ dec,
+                                              const double *__restrict__ ex0, const double *__restrict__ ex1,
+                                              const double *__restrict__ lnz1, const double *__restrict__ lnM,
+                                              int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow)
+{
     HaloRec r;
     const double M_j = M[j], z_j = z[j];
     const double a = 1.0 / (1.0 + z_j);                                   // HealpixRunner.py:295
@@ -689,7 +720,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         if (cls != kClsNone) for_each_tile(h, T, ds, [&](int t) { if (nt < kRefMax) tl[nt] = t; ++nt; });
         ref.n = nt; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
         if (nt <= kRefMax) {
-            // narrow halos take their slot now (returning atomic); wide ones are placed by cursor after the scan
+            // narrow halos take their slot now (returning atomic; the halo index is stored into the slot at the end of this function, when
+            // the atomic has long returned); wide ones are placed by cursor after the scan
             for (int i = 0; i < kRefMax; ++i) {
                 ref.few.tile[i] = (i < nt) ? tl[i] : 0;
                 ref.few.slot[i] = 0;
@@ -760,7 +792,19 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
         }
     }
     if (BFGX_ABL0 & 1) { if (r.cosr == 1.2345 && wv[0] == 0.5) o.rowrec[j].z0 = r.lnoff + r.rcut; }      // keep the values alive
-    if (o.tref && !(BFGX_ABL0 & 2)) o.tref[j] = ref;          // (the slots were reserved above, see there)
+    if (o.tref && !(BFGX_ABL0 & 2)) {                          // (the slots were reserved above, see there)
+        bool slow = (ref.cls != kClsNone) && (ref.n > kRefMax || ref.cls != kClsNarrow);
+        if (ref.cls == kClsNarrow && ref.n <= kRefMax) {
+            for (int i = 0; i < kRefMax; ++i) if (i < ref.n) {
+                const int sl = ref.few.slot[i];
+                if (o.entries_a && sl < o.cap_a) o.entries_a[(int64_t)ref.few.tile[i] * o.cap_a + sl] = (int32_t)j;
+                else if (o.entries_a) { ref.few.slot[i] = -1; atomicAdd(o.cnt_b + ref.few.tile[i], 1); slow = true; }      // the tile's fixed list is full: region B
+                else slow = true;                                                                                         // (no direct placement: every halo is listed)
+            }
+        }
+        if (slow || !o.slow_list) o.tref[j] = ref;
+        if (slow && o.slow_list) o.slow_list[(int64_t)blockIdx.x * 256 + atomicAdd(s_nslow, 1)] = (int32_t)j;
+    }
 }
 
 // Ring range [first, last] (1-based, inclusive; first > last: nothing) that a halo's disc -- or its 4 fallback pixels -- can touch,
@@ -999,9 +1043,16 @@ __global__ void __launch_bounds__(256)
 tile_place_kernel(Hpx h, Tiling T, int64_t nhalo, const TileRef *__restrict__ tref,
                   const int32_t *__restrict__ start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                   int32_t *__restrict__ cur_b, int32_t *__restrict__ cur_w,
-                  int32_t *__restrict__ entries, int64_t capacity, int32_t *__restrict__ overflow)
+                  int32_t *__restrict__ entries, int64_t capacity, int32_t *__restrict__ overflow,
+                  const int32_t *__restrict__ slow_list, const int32_t *__restrict__ slow_cnt)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // workgroup b = the halos K0's workgroup b left to this pass (slow_list[b][256], slow_cnt[b]); cnt_a is an array of zeros when region
+    // A lives in the fixed-capacity lists K0 fills itself (the shared list then holds [B | wide] per tile)
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slow_list) {
+        if ((int)threadIdx.x >= slow_cnt[blockIdx.x]) return;
+        j = slow_list[j];
+    }
     if (j >= nhalo) return;
     const TileRef ref = tref[j];
     if (ref.cls == kClsNone) return;
@@ -1009,7 +1060,10 @@ tile_place_kernel(Hpx h, Tiling T, int64_t nhalo, const TileRef *__restrict__ tr
     if (ref.n <= kRefMax) {
         for (int i = 0; i < kRefMax; ++i) if (i < ref.n) {
             const int t = ref.few.tile[i];
-            if (ref.cls == kClsNarrow) put((int64_t)start[t] + ref.few.slot[i]);
+            if (ref.cls == kClsNarrow) {
+                if (!slow_list) put((int64_t)start[t] + ref.few.slot[i]);
+                else if (ref.few.slot[i] < 0) put((int64_t)start[t] + cnt_a[t] + atomicAdd(cur_b + t, 1));      // its tile's fixed list was full
+            }
             else put((int64_t)start[t] + cnt_a[t] + cnt_b[t] + atomicAdd(cur_w + t, 1));
         }
     } else {

@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(kWave * kW2, (sizeof(real) == 4 ? 4 : 2))
 tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
-                     const int32_t *__restrict__ entries, int64_t capacity,
+                     const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a,
                      ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
                      unsigned int *__restrict__ omax2, int tile_lo, int tile_n)
 {
@@ -325,10 +325,17 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     }
     __syncthreads();
 
+    // the narrow halos of the tile: region A = the tile's fixed-capacity list K0 filled directly (entries_a[tile][cap_a]; without it: the
+    // head of the shared list), region B = discs over more than kRefMax tiles and what did not fit A, at tile_start in the shared list
     const int64_t e0 = tile_start[tile];
-    int64_t ne64 = (int64_t)cnt_a[tile] + cnt_b[tile];            // the narrow-halo region of the tile's entry list
-    if (e0 + ne64 > capacity) ne64 = capacity > e0 ? capacity - e0 : 0;
-    const int ne = (int)ne64;
+    const int na = entries_a ? min(cnt_a[tile], cap_a) : cnt_a[tile];
+    const int32_t *ea = entries_a ? entries_a + (int64_t)tile * cap_a : entries + e0;
+    const int64_t eb0 = e0 + (entries_a ? 0 : na);
+    int64_t nb64 = cnt_b[tile];
+    if (eb0 + nb64 > capacity) nb64 = capacity > eb0 ? capacity - eb0 : 0;
+    if (!entries_a && e0 + na > capacity) nb64 = 0;
+    const int32_t *eb = entries + eb0;
+    const int ne = (!entries_a && e0 + na > capacity) ? (int)(capacity > e0 ? capacity - e0 : 0) : na + (int)nb64;
     // entries per chunk: at most kChunk2, fewer when the tile's list is short, so that every wave of the workgroup gets a chunk (a
     // large-NSIDE tile lists ~20 halos with hundreds of pixels each: in chunks of 16 entries two of the eight waves did all the
     // work).  One chunk per wave measured best (NSIDE 2048: K1 1.91 -> 1.56 ms, 8192: 56.8 -> 24.0 ms; 16 or 32 chunks per tile pack worse)
@@ -350,7 +357,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         EntC2 en;
         en.hidx = 0; en.prefix = 0; en.ring_lo = 0; en.fb = 0;
         if (lane < csz && c * csz + lane < ne) {
-            en.hidx = entries[e0 + c * csz + lane];
+            const int ei = c * csz + lane;
+            en.hidx = ei < na ? ea[ei] : eb[ei - na];
             const RowRec &rr = rowrecs[en.hidx];
             en.fb = rr.fb;
             if (en.fb) nrows = 4;
