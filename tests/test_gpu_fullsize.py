@@ -726,3 +726,41 @@ def test_config4_full_size_eight_rank_decomposition_on_one_gpu(gpu):
     diff = (new - full_out).abs()
     assert diff.max().item() <= 1e-6 * hmap.mean() and (diff > 1e-12 * map_scale).float().mean().item() < 0.05 and n_far < npix // 100
     plan.close()
+
+
+@pytest.mark.parametrize('cap', ['3', '40'])
+def test_tile_lists_overflow_into_the_shared_list(gpu, monkeypatch, cap):
+    """K0 places a narrow halo directly into its tiles' fixed-capacity lists; what does not fit (here: lists of 3 / 40 entries for ~160
+    halos per tile) goes through the per-workgroup slow lists, the scan and the placement pass into region B of the shared list: same
+    pix_offsets, same pair census, same map"""
+    N, nside = 150_000, 256
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    npix = 12 * nside * nside
+    cd, keep1 = _cat_dev(torch, _lib, dev, cat)
+
+    def run(pl):
+        off = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+        pl.set_algo(1)
+        pl.offsets(cd, off.data_ptr(), True)
+        torch.cuda.synchronize()
+        pl.status()
+        return off, pl.count_pairs(cd, True)
+
+    ref, n_ref = run(plan)
+    monkeypatch.setenv('BFGX_TILE_LIST_CAP', cap)
+    from baryonification_amd import engine
+    model, keep = engine.model_from_tables(axes, table, syn.COSMO, 10.0, 10.0)
+    small = engine.ShellPlan(model, keep, nside, N, 0, torch.cuda.current_stream().cuda_stream)
+    got, n_got = run(small)
+    assert n_got == n_ref > 5e5 and (got - ref).abs().max().item() <= 2e-14
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+    out = torch.zeros(npix, dtype=torch.float64, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    f_off = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    small.baryonify(cd, d_map.data_ptr(), f_off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    torch.cuda.synchronize()
+    small.status()
+    s = sums.cpu().numpy()
+    assert np.isclose(s[1], s[0]) and np.isclose(out.sum().item(), hmap.sum())
+    small.close(); plan.close()
