@@ -675,7 +675,10 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         }
         {
             void *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *f3 = nullptr;
-            p->far.cap = std::max<int64_t>((int64_t)1 << 20, p->hpx.npix / 16);
+            // deposits listed for the generic route: four per pixel that moves beyond the gathering reach (15 rings = 9.9 / NSIDE rad).  At NSIDE
+            // 1024 on the S19 table that is 0.2 % of the pixels; at NSIDE 2048 the same field in radians sends 8 % there (16 M entries), and a
+            // list that overflows costs a second pass with the generic evaluation under divergence (25 ms): room for half the pixels, 1 GB at most
+            p->far.cap = std::min<int64_t>(std::max<int64_t>((int64_t)1 << 20, p->hpx.npix / 2), (int64_t)1 << 26);
             // control words in one allocation: [0..7] entries listed, [8..11] overflow (full-map regrid), [12..15] tiles left to
             // the walking kernel (followed by their numbers), ... ; the banded regrid's overflow flag lives after the tile list
             void *f4 = nullptr;

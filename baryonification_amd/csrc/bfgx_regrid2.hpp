@@ -195,9 +195,9 @@ struct ReachArgs {
 };
 
 // the walking kernel (PASS 2) compacts its source pixels: per wave a queue of kWalkQ survivors {position, offset, value}, per
-// workgroup a list of kWalkFar own pixels that take the generic route, per ring of the window two thresholds of the scan
+// wave a second queue for its own pixels that take the generic route, per ring of the window two thresholds of the scan
 constexpr int kWalkQ = 128;         // entries per wave: a wave pushes at most 64 onto fewer than 64
-constexpr int kWalkFar = 256;       // far pixels listed per tile before the rest is evaluated in place
+constexpr int kWalkFar = (256 / kWave) * kWalkQ;      // per wave a second queue of kWalkQ positions: its own pixels that take the generic route
 __host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size, bool walk = false)
 {
     const size_t base = (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + 8 * real_size) + 16;
@@ -429,6 +429,33 @@ __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<r
     return true;
 }
 
+// one source pixel by the generic route, its four deposits appended to the far list (the walking kernel's rare path: kept out of line so
+// that it does not cost the scan loop registers); returns the sum of the deposits
+__device__ __noinline__ double regrid_far_pixel(const Hpx &h, const RegRow *rows, int LR, int rth0, int ti, int x, double o0, double o1, double o2,
+                                                double val, FarList far)
+{
+    int tr[4], tk[4];
+    double w[4], tot = 0.0;
+    regrid_targets_generic(h, rows, LR, rth0, ti, x, o0, o1, o2, tr, tk, w);
+    // ONE returning atomic per wave reserves the four entries of every active lane (one per deposit would be tens of millions of atomics on
+    // a single address where the field moves far: they serialise at ~5 ns each)
+    const unsigned long long act = __ballot(1);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+    const int leader = __ffsll((long long)act) - 1;
+    unsigned long long base = 0;
+    if (rank == 0) base = atomicAdd(far.count, 4ull * (unsigned long long)__popcll(act));
+    base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader, kWave) << 32) | (unsigned)__shfl((int)base, leader, kWave);
+    for (int q4 = 0; q4 < 4; ++q4) {
+        int64_t st_t, nr64; bool sh_t;
+        ring_info_small(h, tr[q4], st_t, nr64, sh_t);
+        const double v = w[q4] * val;
+        const unsigned long long i = base + 4ull * (unsigned long long)rank + (unsigned long long)q4;
+        if ((int64_t)i < far.cap) { far.pix[i] = st_t + tk[q4]; far.val[i] = v; } else atomicOr(far.overflow, 1);
+        tot += v;
+    }
+    return tot;
+}
+
 // PASS 0: the gathering regrid of the tiles whose reach is ONE ring (no deposit travels further than the next ring: the
 // lean code, 4 waves / SIMD); tiles with a longer reach are appended to `todo` and left to PASS 2, the same kernel with the
 // ring walk compiled in, which a small persistent grid runs over that list (or over all tiles: banded regrid with a fixed
@@ -655,16 +682,18 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 }
             }
         };
-        auto far_eval = [&](int ti, int x, double f0, double f1, double f2, double val) {      // the owner of the source pixel lists its deposits
-            int tr[4], tk[4];
-            double w[4];
-            regrid_targets_generic(h, rows, NT - 2, rth0, ti, x, f0, f1, f2, tr, tk, w);
-            for (int q4 = 0; q4 < 4; ++q4) {
-                int64_t st_t, nr64; bool sh_t;
-                ring_info_small(h, tr[q4], st_t, nr64, sh_t);
-                far_add(st_t + tk[q4], w[q4] * val);
-            }
+        // a listed position (ring of the tables << 16 | column + kap) of one of the tile's own pixels -> its deposits on the far list
+        auto far_from = [&](int pk) {
+            const int ti = pk >> 16, x = (pk & 0xffff) - kap;
+            const RegRow &rw = rows[ti];
+            int k = rw.ks + x;
+            if (k < 0) k += rw.nr;
+            if (k >= rw.nr) k -= rw.nr;
+            const int64_t p = rw.start + k;
+            sum_out += regrid_far_pixel(h, rows, NT - 2, rth0, ti, x, (double)offsets[3 * p + 0], (double)offsets[3 * p + 1], (double)offsets[3 * p + 2], map_in[p], far);
         };
+        int32_t *fq = farq + wid * kWalkQ;
+        int fn = 0;                                                            // entries in this wave's queue of generic-route pixels
         int qn = 0;                                                            // entries in this wave's queue (wave-uniform)
         constexpr int U = BFGX_K2U;                                                   // window pixels per lane and trip: 2 U loads in flight
         const int64_t pdummy = rows[R + 1].start + rows[R + 1].ks;             // (a pixel this tile may read, for the lanes without one)
@@ -690,7 +719,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 ca0[u] = offsets[3 * p + 0]; ca1[u] = offsets[3 * p + 1]; ca2[u] = offsets[3 * p + 2];
                 cval[u] = map_in[p];
             }
-            bool cpush[U];
+            bool cpush[U], cfar[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {                                      // the two thresholds
                 const int x = cx[u];
@@ -703,10 +732,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 const float g = (float)dc - colslack, of = (float)osq;
                 const bool reaches = cown[u] || (of >= cneed2[u] && (g <= 0.0f || of * ccf2[u] >= g * g));
                 cpush[u] = live && gathered && reaches;
-                if (live && !gathered && cown[u]) {                            // rare: the generic route, listed per tile
-                    const int slot = atomicAdd(nfar, 1);
-                    if (slot < kWalkFar) farq[slot] = cpos[u];
-                }
+                cfar[u] = live && !gathered && cown[u];                        // the generic route (|o| beyond the cap, next to a pole)
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {                                      // survivors onto the queue; a full wave of them evaluated
@@ -725,39 +751,25 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                     __builtin_amdgcn_wave_barrier();
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                      // the same for the pixels of the generic route (usually none)
+                const unsigned long long m = __ballot(cfar[u]);
+                if (m == 0ull) continue;
+                if (cfar[u]) fq[fn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = cpos[u];
+                fn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (fn >= kWave) {
+                    fn -= kWave;
+                    far_from(fq[fn + lane]);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
         if (lane < qn) {
             const int pk = qpos[lane];
             deposit(pk >> 16, (pk & 0xffff) - kap, qo[lane], qo[kWalkQ + lane], qo[2 * kWalkQ + lane], qval[lane]);
         }
-        __syncthreads();
-        // the far pixels of the tile: from the list, or -- more of them than it holds -- by a sweep over the tile's own pixels
-        const int nf = *nfar;
-        const bool sweep = nf > kWalkFar;
-        const int ncand = sweep ? nown * maxspan : nf;
-        for (int e = tid; e < ncand; e += 256) {
-            int ti, x;
-            if (sweep) {
-                const int rr = e / maxspan;
-                ti = R + 1 + rr; x = e - rr * maxspan;
-                if (x >= rows[ti].ke - rows[ti].ks) continue;
-            } else {
-                const int pk = farq[e];
-                ti = pk >> 16; x = (pk & 0xffff) - kap;
-            }
-            const RegRow &rw = rows[ti];
-            int k = rw.ks + x;
-            if (k < 0) k += rw.nr;
-            if (k >= rw.nr) k -= rw.nr;
-            const int64_t p = rw.start + k;
-            const double val = map_in[p];
-            const ACC a0 = offsets[3 * p + 0], a1 = offsets[3 * p + 1], a2 = offsets[3 * p + 2];
-            if (sweep) {
-                const real o0 = (real)a0, o1 = (real)a1, o2 = (real)a2;
-                if (!(val > 0.0) || (double)fma_(o0, o0, fma_(o1, o1, o2 * o2)) < rw.lim2) continue;
-            }
-            far_eval(ti, x, (double)a0, (double)a1, (double)a2, val);
-        }
+        if (lane < fn) far_from(fq[lane]);
     } else
     for (int idx = tid; idx < NR * LWs; idx += 256) {
         const Src cur = fetch(idx);
