@@ -1328,6 +1328,20 @@ struct DevBuf {
     int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : 1; }
 };
 
+// Every one-shot host entry leaves NOTHING in flight when it returns -- on success and on every error path: asynchronous copies read the
+// caller's arrays (page-locked for the call, or pinned on the fly by the runtime) and write into the caller's result; a copy that is
+// still running when the caller frees or reuses those arrays is a GPU memory fault at a host address.  Declared first in an entry, it
+// is destroyed last (after the Pin objects have unregistered): its streams are drained at scope exit whatever the return path.
+struct DrainOnExit {
+    hipStream_t *s[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool null_stream = false;
+    ~DrainOnExit()
+    {
+        for (hipStream_t *q : s) if (q && *q) (void)hipStreamSynchronize(*q);
+        if (null_stream) (void)hipStreamSynchronize(nullptr);
+    }
+};
+
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
     Timer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
@@ -1595,6 +1609,8 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     bfgx_plan *p = e->plan;
     p->algo = o.algo;
     HIP_TRY(hipSetDevice(p->device));
+    DrainOnExit drain;
+    drain.s[0] = &p->stream; drain.s[1] = &e->copy_stream; drain.s[2] = &e->out_stream; drain.null_stream = (p->stream == nullptr);
 
     const size_t npix = (size_t)p->hpx.npix;
     const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
@@ -1796,6 +1812,8 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     bfgx_plan *p = e->plan;
     p->algo = o.algo;
     HIP_TRY(hipSetDevice(p->device));
+    DrainOnExit drain;
+    drain.s[0] = &p->stream; drain.s[1] = &e->copy_stream; drain.s[2] = &e->out_stream; drain.null_stream = (p->stream == nullptr);
 
     const size_t npix = (size_t)p->hpx.npix;
     std::vector<double> hostlog;

@@ -151,6 +151,9 @@ template <> struct RMath<double> {
 #ifndef BFGX_K2U
 #define BFGX_K2U 2
 #endif
+#ifndef BFGX_K2LEAN_U
+#define BFGX_K2LEAN_U 2          // window pixels per lane and trip of the lean / repair kernels
+#endif
 constexpr int kReachMax = 16;       // most rings a gathered deposit travels; the ring tables hold BR + 2 kReachMax + 2 rings
 constexpr int kReachColsMax = 256;  // most apron columns per side
 
@@ -429,9 +432,17 @@ __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<r
     return true;
 }
 
-// one source pixel by the generic route, its four deposits appended to the far list (the walking kernel's rare path: kept out of line so
-// that it does not cost the scan loop registers); returns the sum of the deposits
-__device__ __noinline__ double regrid_far_pixel(const Hpx &h, const RegRow *rows, int LR, int rth0, int ti, int x, double o0, double o1, double o2,
+// one source pixel by the generic route, its four deposits appended to the far list; returns the sum of the deposits.  (Out of line it costs
+// the walking kernel 23 spilled registers around the call and 3 % of its time, the lean kernel 20 %: inlined by default.)
+#ifndef BFGX_FAR_INLINE
+#define BFGX_FAR_INLINE 1
+#endif
+#if BFGX_FAR_INLINE
+__device__ inline double regrid_far_pixel(
+#else
+__device__ __noinline__ double regrid_far_pixel(
+#endif
+    const Hpx &h, const RegRow *rows, int LR, int rth0, int ti, int x, double o0, double o1, double o2,
                                                 double val, FarList far)
 {
     int tr[4], tk[4];
@@ -770,20 +781,19 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             deposit(pk >> 16, (pk & 0xffff) - kap, qo[lane], qo[kWalkQ + lane], qo[2 * kWalkQ + lane], qval[lane]);
         }
         if (lane < fn) far_from(fq[lane]);
-    } else
-    for (int idx = tid; idx < NR * LWs; idx += 256) {
-        const Src cur = fetch(idx);
+    } else {
+    auto handle = [&](const Src &cur) {
         if (cur.ok && cur.own) sum_in += cur.val;
-        if (!cur.ok || !(cur.val > 0.0)) continue;                           // HealpixRunner.py:335
+        if (!cur.ok || !(cur.val > 0.0)) return;                             // HealpixRunner.py:335
         const double val = cur.val;
         const real o0 = (real)cur.o0, o1 = (real)cur.o1, o2 = (real)cur.o2;
         const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
         const bool gathered = (double)osq < rows[cur.ti].lim2;
         if (gathered) {
-            if (PASS == 1) continue;
+            if (PASS == 1) return;
             int tt[4], tk[4];
             real w[4];
-            if (!regrid_gather_targets<real, false>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) continue;
+            if (!regrid_gather_targets<real, false>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) return;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
                 const int rr = tt[q4] - (R + 1);
@@ -805,6 +815,16 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 far_add(st_t + tk[q4], w[q4] * val);
             }
         }
+    };
+    if (BFGX_K2LEAN_U == 2) {
+        // two window pixels per lane and trip: the four loads are in flight before either pixel is evaluated
+        for (int idx = tid; idx < NR * LWs; idx += 512) {
+            const Src a = fetch(idx), b = fetch(idx + 256);
+            handle(a);
+            handle(b);
+        }
+    } else
+        for (int idx = tid; idx < NR * LWs; idx += 256) handle(fetch(idx));
     }
     if (PASS == 1) continue;
     __syncthreads();
