@@ -1342,6 +1342,49 @@ struct DrainOnExit {
     }
 };
 
+// A caller's host array as the source / destination of the ASYNCHRONOUS copies of a one-shot entry:
+//  * already page-locked by the caller (bfgx_host_alloc): used as it is;
+//  * >= 32 MiB -- beyond glibc's largest mmap threshold, i.e. a mapping of its own that shares no page with another object: page-locked in
+//    place for the call (hipHostRegister);
+//  * smaller: NEVER page-locked in place.  A small numpy array lives in the process heap next to other live objects; page-locking and
+//    unlocking those pages call after call left a later, ordinary pageable copy from the same heap region reading through a mapping that
+//    was gone (seen twice in round 4 as "Memory access fault by GPU ... on address <heap address>").  Small arrays take the entry's
+//    synchronous route; `stage` (tests force the streamed route on small maps: BFGX_PIPE_CHUNKS) goes through a page-locked buffer of ours.
+constexpr size_t kPinInPlaceMin = (size_t)32 << 20;
+struct HostSpan {
+    void *user = nullptr, *use = nullptr;
+    size_t bytes = 0;
+    bool registered = false, staged = false, is_out = false;
+    hipStream_t *streams[3] = {nullptr, nullptr, nullptr};       // copies of the span may be in flight on these when an error returns early
+    bool open(const void *q, size_t nb, bool out, bool stage)
+    {
+        user = (void *)q; bytes = nb; is_out = out;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) == hipSuccess && at.type == hipMemoryTypeHost) { use = user; return true; }
+        (void)hipGetLastError();
+        if (nb >= kPinInPlaceMin) {
+            if (hipHostRegister(user, nb, hipHostRegisterDefault) == hipSuccess) { registered = true; use = user; return true; }
+            (void)hipGetLastError();
+            return false;
+        }
+        if (!stage) return false;
+        if (hipHostMalloc(&use, nb ? nb : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); use = nullptr; return false; }
+        staged = true;
+        if (!out) std::memcpy(use, q, nb);
+        return true;
+    }
+    void drain() const { for (hipStream_t *s : streams) if (s && *s) (void)hipStreamSynchronize(*s); }
+    // success path, after the entry has drained its streams: a staged result reaches the caller's array
+    void commit() { if (staged && is_out && use) { drain(); std::memcpy(user, use, bytes); } }
+    ~HostSpan()
+    {
+        if (!registered && !staged) return;
+        drain();                                             // never unlock / free a buffer a copy still uses
+        if (registered) (void)hipHostUnregister(user);
+        if (staged && use) (void)hipHostFree(use);
+    }
+};
+
 struct Timer {
     hipEvent_t a = nullptr, b = nullptr;
     Timer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
@@ -1648,30 +1691,14 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     if (const char *ce = std::getenv("BFGX_PIPE_CHUNKS")) kChunks = std::max(2, std::min(kChunksMax, std::atoi(ce)));       // (tests: small maps)
     bool piped = o.algo == 1 && kChunks >= 2 && p->tiling.nbands >= 2 * kChunks && !std::getenv("BFGX_NO_PIPELINE");
     bool whole_map_sent = false;
-    struct Pin {
-        void *p = nullptr;
-        hipStream_t *streams[3] = {nullptr, nullptr, nullptr};     // copies of the pinned buffer may be in flight on these when an error returns early
-        ~Pin()
-        {
-            if (!p) return;
-            // never hand a buffer back to the caller (or unregister it) while an asynchronous copy still reads or writes it
-            for (hipStream_t *s : streams) if (s && *s) (void)hipStreamSynchronize(*s);
-            (void)hipHostUnregister(p);
-        }
-        // true if [q, q + bytes) is page-locked afterwards (registered here, or already by the caller: bfgx_host_alloc)
-        bool lock(const void *q, size_t bytes)
-        {
-            if (hipHostRegister((void *)q, bytes, hipHostRegisterDefault) == hipSuccess) { p = (void *)q; return true; }
-            (void)hipGetLastError();
-            hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, q) == hipSuccess && at.type == hipMemoryTypeHost) return true;
-            (void)hipGetLastError();
-            return false;
-        }
-    } pin_in, pin_out;
-    pin_in.streams[0] = pin_out.streams[0] = &e->copy_stream; pin_in.streams[1] = pin_out.streams[1] = &p->stream;
-    pin_in.streams[2] = pin_out.streams[2] = &e->out_stream;
-    if (piped) piped = pin_in.lock(map_in, npix * sizeof(double)) && pin_out.lock(map_out, npix * sizeof(double));
+    HostSpan hin, hout;
+    hin.streams[0] = hout.streams[0] = &e->copy_stream; hin.streams[1] = hout.streams[1] = &p->stream; hin.streams[2] = hout.streams[2] = &e->out_stream;
+    const bool stage_small = std::getenv("BFGX_PIPE_CHUNKS") != nullptr;
+    if (piped) piped = hin.open(map_in, npix * sizeof(double), false, stage_small) && hout.open(map_out, npix * sizeof(double), true, stage_small);
+    const double *const user_map_in = map_in;
+    double *const user_map_out = map_out;
+    (void)user_map_in; (void)user_map_out;
+    if (piped) { map_in = (const double *)hin.use; map_out = (double *)hout.use; }       // (from here on: the page-locked views)
     if (piped) {
         int nb = 0;
         std::vector<int64_t> bfp((size_t)p->tiling.nbands + 1);
@@ -1781,6 +1808,7 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     (void)hipEventElapsedTime(&f_d2h, e->ev[2], e->ev[3]);
     const double ms_h2d = f_h2d, ms_k = f_k, ms_d2h = f_d2h;
     if (int rc = bfgx_plan_status(p)) return rc;             // far-deposit list / entry list
+    hout.commit();                                           // (a staged result reaches the caller's array)
 
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -1830,25 +1858,10 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     int kChunks = (int)std::min<size_t>(kChunksMax, npix * sizeof(double) / ((size_t)16 << 20));
     if (const char *ce = std::getenv("BFGX_PIPE_CHUNKS")) kChunks = std::max(2, std::min(kChunksMax, std::atoi(ce)));       // (tests: small maps)
     bool piped = o.algo == 1 && o.acc_paint_f64 != 0 && kChunks >= 2 && p->tiling.nbands >= 2 * kChunks && !std::getenv("BFGX_NO_PIPELINE");
-    struct Pin {
-        void *p = nullptr;
-        hipStream_t *streams[2] = {nullptr, nullptr};
-        ~Pin()
-        {
-            if (!p) return;
-            for (hipStream_t *s : streams) if (s && *s) (void)hipStreamSynchronize(*s);      // (an early error return: copies into map_out may be in flight)
-            (void)hipHostUnregister(p);
-        }
-    } pin_out;
-    pin_out.streams[0] = &p->stream; pin_out.streams[1] = &e->out_stream;
-    if (piped) {
-        if (hipHostRegister((void *)map_out, npix * sizeof(double), hipHostRegisterDefault) == hipSuccess) pin_out.p = (void *)map_out;
-        else {
-            (void)hipGetLastError();
-            hipPointerAttribute_t at;
-            if (!(hipPointerGetAttributes(&at, map_out) == hipSuccess && at.type == hipMemoryTypeHost)) { (void)hipGetLastError(); piped = false; }
-        }
-    }
+    HostSpan hout;
+    hout.streams[0] = &p->stream; hout.streams[1] = &e->out_stream;
+    if (piped) piped = hout.open(map_out, npix * sizeof(double), true, std::getenv("BFGX_PIPE_CHUNKS") != nullptr);
+    if (piped) map_out = (double *)hout.use;                 // (from here on: the page-locked view)
     double ms_k = 0.0;
     if (piped) {
         if (int rc = check_catalog(p, &dcat)) return rc;
@@ -1902,6 +1915,7 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
     }
     const double ms_d2h = t.stop(p->stream);
     if (int rc = bfgx_plan_status(p)) return rc;
+    hout.commit();
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->ms_h2d = ms_h2d; stats->ms_kernels = ms_k; stats->ms_d2h = ms_d2h;
