@@ -90,6 +90,10 @@ template <typename real>
 struct alignas(16) RingC2 { real sth, zf, dphi, _pad; };      // sin / cos of the colatitude, 2 pi / nr
 
 struct EntC2 { int32_t hidx, prefix, ring_lo, fb; };      // one non-empty entry of the chunk (compacted)
+struct RowGeo { double z0, s0, xa, cosr, phi0; };          // what the ring-row phase needs of a halo's RowRec, staged per entry (BFGX_K1_GEO)
+#ifndef BFGX_K1_GEO
+#define BFGX_K1_GEO 0
+#endif
 
 template <typename real>
 struct Wave2Lds {
@@ -98,6 +102,9 @@ struct Wave2Lds {
     unsigned long long mask[kWave + 4];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
     EntC2 ent[kChunk2];
     unsigned long long emask[kChunk2];       // bit R set <=> row R of the chunk is the first row of an entry (<= 16 x 64 rows)
+#if BFGX_K1_GEO
+    RowGeo geo[kChunk2];
+#endif
 };
 
 template <typename real>
@@ -356,10 +363,13 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         int nrows = 0;
         EntC2 en;
         en.hidx = 0; en.prefix = 0; en.ring_lo = 0; en.fb = 0;
+        RowGeo gg;
+        gg.z0 = gg.s0 = gg.xa = gg.cosr = gg.phi0 = 0.0;
         if (lane < csz && c * csz + lane < ne) {
             const int ei = c * csz + lane;
             en.hidx = ei < na ? ea[ei] : eb[ei - na];
             const RowRec &rr = rowrecs[en.hidx];
+            if (BFGX_K1_GEO) { gg.z0 = rr.z0; gg.s0 = rr.s0; gg.xa = rr.xa; gg.cosr = rr.cosr; gg.phi0 = rr.phi0; }
             en.fb = rr.fb;
             if (en.fb) nrows = 4;
             else {
@@ -378,6 +388,9 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
             if (nrows > 0) {
                 const int slot = __popcll(nzE & lt);
                 L.ent[slot] = en;
+#if BFGX_K1_GEO
+                L.geo[slot] = gg;
+#endif
                 if (MODE != MODE_COUNT) L.pair[slot] = pairrecs[en.hidx];
                 atomicOr(&L.emask[en.prefix >> 6], 1ull << (en.prefix & 63));
             }
@@ -403,7 +416,11 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
             double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0;
             if (rvalid) {
                 const int q = R - ep;
+#if BFGX_K1_GEO
+                const RowGeo rr = L.geo[es];                       // (staged by the entry phase: one global read per halo instead of one per ring row)
+#else
                 const RowRec &rr = rowrecs[eh];
+#endif
                 if (efb) {
                     const int ring = fbrecs[eh].ring[q], fk = fbrecs[eh].k[q];
                     if (ring >= i0 && ring < i1) {
