@@ -276,10 +276,21 @@ __device__ inline double min_image(double dx, double L)
 // LDS accumulator -- with one thread per particle doing this inline a wave ran the read-out whenever ANY of its 64 unrelated
 // particles had a hit (~15 % lane utilisation, 0.9 of the kernel's 2.9 ms).  Phase 3 (lane = particle): displaced, re-wrapped
 // position, written once.
-constexpr int kSnapQueue = 768;                      // queued hits per 256 particles (3 per particle; more are done inline)
+#ifndef BFGX_SNAP_PPT
+#define BFGX_SNAP_PPT 1             // particles per thread and round.  2 / 4 keep that many look-up chains (occupancy bit -> cell start -> list
+#endif                              // entries) of a thread in flight together; measured (round 4): 2.15 / 2.99 / 2.34 ms for 1 / 2 / 4 -- the entry
+                                    // records of the extra chains cost registers (126 -> 239 VGPRs at 4: two waves per SIMD), and waves hide this
+                                    // kernel's latency better than chains do.  Capping the registers instead (launch bounds for 6 / 8 waves per
+                                    // SIMD: 92 / 160 bytes of scratch per lane in the fp64 read-out) gave 3.1 / 3.7 ms.
+constexpr int kSnapPPT = BFGX_SNAP_PPT;
+constexpr int kSnapBlock = 256 * kSnapPPT;           // particles per workgroup and round
+constexpr int kSnapQueue = 768 * kSnapPPT;           // queued hits per round (3 per particle; more are done inline)
 
+#ifndef BFGX_SNAP_OCC
+#define BFGX_SNAP_OCC 4             // workgroups of 256 threads per SIMD group the kernel is compiled for (register budget 512 / (4 x this))
+#endif
 template <int DIM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BFGX_SNAP_OCC)
 snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, const double *py,
                      const double *pz, const SnapHaloRec *__restrict__ recs, const uint32_t *__restrict__ bitmap,
                      const int32_t *__restrict__ cell_start, const SnapEntry *__restrict__ entries, double *ox, double *oy, double *oz,
@@ -288,7 +299,7 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, con
     // sin / sout: distance in doubles between consecutive particles of the input / output columns (1: plain columns; the records entry
     // passes the record size / 8 and column pointers into the record buffer -- possibly the SAME buffer: a particle's own coordinates are
     // read before they are written, and no other thread reads them)
-    __shared__ double spos[3][256], sacc[3][256];
+    __shared__ double spos[3][kSnapBlock], sacc[3][kSnapBlock];
     __shared__ int qslot[kSnapQueue], qent[kSnapQueue];
     __shared__ int qn;
     const int tid = threadIdx.x;
@@ -344,33 +355,70 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, con
 
     // grid-stride over blocks of 256 particles: a bounded number of workgroups, so that the pair census ends in a few thousand
     // atomics on one address instead of one per wave (10^6 same-address atomics cost ~10 ms)
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < np; base += (int64_t)gridDim.x * 256) {
-        const int64_t p = base + tid;
-        const bool on = p < np;
-        const double x = on ? px[p * sin] : 0.0, y = on ? py[p * sin] : 0.0, z = (DIM == 3 && on) ? pz[p * sin] : 0.0;
-        spos[0][tid] = x; spos[1][tid] = y; spos[2][tid] = z;
-        sacc[0][tid] = 0.0; sacc[1][tid] = 0.0; sacc[2][tid] = 0.0;
+    for (int64_t base = (int64_t)blockIdx.x * kSnapBlock; base < np; base += (int64_t)gridDim.x * kSnapBlock) {
+        // particle k of this thread: slot = k * 256 + tid (consecutive lanes = consecutive particles: coalesced)
+        bool on[kSnapPPT];
+        double x[kSnapPPT], y[kSnapPPT], z[kSnapPPT];
+#pragma unroll
+        for (int k = 0; k < kSnapPPT; ++k) {
+            const int64_t p = base + k * 256 + tid;
+            on[k] = p < np;
+            x[k] = on[k] ? px[p * sin] : 0.0; y[k] = on[k] ? py[p * sin] : 0.0; z[k] = (DIM == 3 && on[k]) ? pz[p * sin] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kSnapPPT; ++k) {
+            const int sl = k * 256 + tid;
+            spos[0][sl] = x[k]; spos[1][sl] = y[k]; spos[2][sl] = z[k];
+            sacc[0][sl] = 0.0; sacc[1][sl] = 0.0; sacc[2][sl] = 0.0;
+        }
         if (tid == 0) qn = 0;
         __syncthreads();
-        // ---- phase 1
-        if (on) {
-            const bool inside = (x >= 0.0 && x <= g.L) && (y >= 0.0 && y <= g.L) && (DIM == 2 || (z >= 0.0 && z <= g.L));
-            if (!inside) atomicOr(flags, 2);
-            else {
-                const int64_t c = snap_cell_index(g, snap_cell(x, g), snap_cell(y, g), (DIM == 3) ? snap_cell(z, g) : 0);
-                int e0 = 0, e1 = 0;
-                if ((bitmap[c >> 5] >> (c & 31)) & 1u) { e0 = cell_start[c]; e1 = cell_start[c + 1]; }
-                const float pf[3] = {(float)x, (float)y, (float)z};
-                // four entries (one 64-byte line when aligned) are requested together: the loop waits for list entries, so its length
-                // in round trips is what counts
-                for (int e = e0; e < e1; e += 4) {
-                    SnapEntry en[4];
+        // ---- phase 1: the chains of the thread's particles advance together (all occupancy bits, then all cell starts, then a line of
+        // entries for every particle that still has some)
+        int e0[kSnapPPT], e1[kSnapPPT];
+        int64_t cell[kSnapPPT];
+        uint32_t bits[kSnapPPT];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) en[k] = entries[min(e + k, e1 - 1)];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (e + k < e1) test(tid, pf, en[k]);
+        for (int k = 0; k < kSnapPPT; ++k) {
+            e0[k] = 0; e1[k] = 0; cell[k] = 0; bits[k] = 0u;
+            if (on[k]) {
+                const bool inside = (x[k] >= 0.0 && x[k] <= g.L) && (y[k] >= 0.0 && y[k] <= g.L) && (DIM == 2 || (z[k] >= 0.0 && z[k] <= g.L));
+                if (!inside) { atomicOr(flags, 2); on[k] = false; }
+                else {
+                    cell[k] = snap_cell_index(g, snap_cell(x[k], g), snap_cell(y[k], g), (DIM == 3) ? snap_cell(z[k], g) : 0);
+                    bits[k] = bitmap[cell[k] >> 5];
                 }
             }
+        }
+        bool outside[kSnapPPT];
+#pragma unroll
+        for (int k = 0; k < kSnapPPT; ++k) {
+            outside[k] = !on[k] && (base + k * 256 + tid < np);
+            if (on[k] && ((bits[k] >> (cell[k] & 31)) & 1u)) { e0[k] = cell_start[cell[k]]; e1[k] = cell_start[cell[k] + 1]; }
+        }
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < kSnapPPT; ++k) more = more || (e0[k] < e1[k]);
+        while (more) {
+            // four entries (one 64-byte line when aligned) per particle and trip: the loop waits for list entries, so its length in round
+            // trips is what counts
+            SnapEntry en[kSnapPPT][4];
+#pragma unroll
+            for (int k = 0; k < kSnapPPT; ++k)
+                if (e0[k] < e1[k]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) en[k][q] = entries[min(e0[k] + q, e1[k] - 1)];
+                }
+            more = false;
+#pragma unroll
+            for (int k = 0; k < kSnapPPT; ++k)
+                if (e0[k] < e1[k]) {
+                    const float pf[3] = {(float)x[k], (float)y[k], (float)z[k]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (e0[k] + q < e1[k]) test(k * 256 + tid, pf, en[k][q]);
+                    e0[k] += 4;
+                    more = more || (e0[k] < e1[k]);
+                }
         }
         __syncthreads();
         // ---- phase 2: the queued hits, one per lane
@@ -378,17 +426,22 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, con
         for (int i = tid; i < nq; i += 256) hit(qslot[i], qent[i]);
         __syncthreads();
         // ---- phase 3
-        if (on) {
-            double nx = x + sacc[0][tid], ny = y + sacc[1][tid], nz = z + sacc[2][tid];  // :254-257
-            if (nx > g.L) nx -= g.L;                                                     // :259-262
-            if (nx < 0.0) nx += g.L;
-            if (ny > g.L) ny -= g.L;
-            if (ny < 0.0) ny += g.L;
-            ox[p * sout] = nx; oy[p * sout] = ny;
-            if (DIM == 3) {
-                if (nz > g.L) nz -= g.L;
-                if (nz < 0.0) nz += g.L;
-                oz[p * sout] = nz;
+#pragma unroll
+        for (int k = 0; k < kSnapPPT; ++k) {
+            const int64_t p = base + k * 256 + tid;
+            const int sl = k * 256 + tid;
+            if (on[k] || outside[k]) {
+                double nx = x[k] + sacc[0][sl], ny = y[k] + sacc[1][sl], nz = z[k] + sacc[2][sl];  // :254-257
+                if (nx > g.L) nx -= g.L;                                                     // :259-262
+                if (nx < 0.0) nx += g.L;
+                if (ny > g.L) ny -= g.L;
+                if (ny < 0.0) ny += g.L;
+                ox[p * sout] = nx; oy[p * sout] = ny;
+                if (DIM == 3) {
+                    if (nz > g.L) nz -= g.L;
+                    if (nz < 0.0) nz += g.L;
+                    oz[p * sout] = nz;
+                }
             }
         }
         __syncthreads();                                   // the LDS buffers are reused by the next block of particles
