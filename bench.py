@@ -340,10 +340,34 @@ def main_grid(args):
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+    ev_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in lst])) for k, lst in ev.items() if lst}      # (the timed region's events)
+    sorted_companion = None
+    if snapshot and not args.sorted_particles:
+        # the same flow on the same particles in the order snapshot files stored along a space-filling curve have (raster order of 64^3
+        # coarse cells): the displacement's look-ups then fall into lines the neighbouring lanes touch too.  BaryonifySnapshot returns the
+        # particles in the caller's order, so this costs the caller nothing but is not something the library may do to unsorted input.
+        key = ((part[0] * (64 / L)).long().clamp_(0, 63) * 64 + (part[1] * (64 / L)).long().clamp_(0, 63)) * 64 + (part[2] * (64 / L)).long().clamp_(0, 63)
+        part = part[:, torch.argsort(key)].contiguous()
+        del key
+        for k in ev:
+            ev[k].clear()
+        for _ in range(3):
+            step()
+        fence()
+        for k in ev:
+            ev[k].clear()
+        ns = max(5, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(ns):
+            step()
+        fence()
+        els = time.perf_counter() - t0
+        sorted_companion = {"value": npart / els * ns, "unit": "particles/s", "ms_per_step": els / ns * 1e3, "steps": ns,
+                            "particle_order": "coarse-cell raster (64^3)",
+                            "kernel_ms": {k: float(np.mean([a.elapsed_time(b) for a, b in lst])) for k, lst in ev.items() if lst}}
     if rank == 0:
         kernels = {k: ms / n for k, (ms, n) in kt.items() if n}
-        for k, lst in ev.items():
-            kernels[k] = float(np.mean([a.elapsed_time(b) for a, b in lst]))
+        kernels.update(ev_ms)
         if fused:        # the deposit's share of the fused call: what the plan's own kernel timers (prep, lists, gather, sums) do not cover
             kernels['deposit'] = kernels['deposit+baryonify'] - sum(kernels.get(k, 0.0) for k in ('prep', 'bin', 'offsets', 'sum', 'regrid'))
         sums = d_sums.cpu().numpy()
@@ -389,6 +413,8 @@ def main_grid(args):
                                        "pk": "fft_r2c_lines + fft_c2c_strided + fft_c2c_strided<bins>", "displace": "snap_displace_kernel<3>"}[dom],
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": g_traffic,
                             "traffic_source": g_src, "algorithmic_bytes_per_launch": alg[dom]}}
+        if sorted_companion is not None:
+            out["value_sorted_input"] = sorted_companion
         if world == 1 and not args.no_cpu_baseline and not snapshot:
             out["cpu_baseline"] = cpu_baseline_grid(args, cat, bins, zr, axes, table, eps)
         print(json.dumps(out), flush=True)
