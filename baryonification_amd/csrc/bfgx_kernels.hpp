@@ -508,7 +508,7 @@ struct FbRec { int32_t ring[4], k[4]; };   // the 4 get_interp_weights neighbour
 
 template <typename real>
 struct alignas(16) PairRecT {              // what the pair phase needs of a halo, in the precision of the pair math
-    real lnoffD;                           // ln(1/a) [- ln R_model] + ln D:  ln r axis coordinate = ln|u| + lnoffD,  u = diff / D
+    real scale2;                           // (D / a [/ R_model])^2: ln r axis coordinate = ln(|u| D / a) = ln(|u|^2 scale2) / 2,  u = diff / D
     real cut2;                             // 1 / (rcut a / D)^2, or 0 when the disc itself implies r < eps R
     real aD;                               // a / D: offset / D = d aD u / |u|
     real cph0, sph0;                       // rotation back by +phi0
@@ -772,7 +772,11 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
         PairRecT<real> pr;
         // a halo outside the (z, M) table reads NaN (RGI fill_value): its ln r offset is pushed beyond any table, so that the pair
         // phase's range test drops it without a flag of its own
-        pr.lnoffD = oob ? (real)1.0e30 : (real)(r.lnoff + fast_log(D));
+        // the scale goes INTO the logarithm's argument: ln|u| ~ -7 and ln(D / a) ~ +7 added afterwards cancel to an O(1) number that carries
+        // the absolute rounding of both (7e-7 in fp32); ln(|u|^2 scale2) / 2 carries half an ulp of the O(1) result
+        double scl = D * r.inv_a;
+        if (m.tab.rdelta) scl /= Rmod;
+        pr.scale2 = oob ? (real)1.0e30 : (real)(scl * scl);
         pr.cut2 = implied ? (real)0 : (real)(1.0 / rr.cut2);       // 1 / cut^2 (see pair_eval); 0: the disc itself implies r < eps R
         pr.aD = (real)(a / D);
         pr.cph0 = (real)r.cph0; pr.sph0 = (real)r.sph0;

@@ -208,11 +208,11 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     const real u2 = (MODE == MODE_PAINT) ? fma_((real)2 * rg.sth * (rg.sth - rc.ds), omc, fma_(rc.ds, rc.ds, rc.dz * rc.dz))
                                          : ux * ux + uy * uy + uz * uz;
     // r_sep = 0 (diff / r_sep is NaN -> 0, :322-323): |u|^2 is floored at 1e-37, whose ln lies below any table (and u = 0 adds nothing
-    // anyway); a halo outside the (z, M) table carries lnoffD = +1e30 (K0), which fails the range test: no flags of their own
+    // anyway); a halo outside the (z, M) table carries scale2 = +1e30 (K0), whose logarithm fails the range test: no flags of their own
     bool ok = act;
     const real u2s = (u2 > (real)1e-37) ? u2 : (real)1e-37;
     const real rinv = PM::rsq(u2s);                                // 1 / |u|
-    const real lx = PM::half_ln(u2s) + ph.lnoffD;                  // ln(r_sep / a) [- ln R when Rdelta]
+    const real lx = PM::half_ln(u2s * ph.scale2);                  // ln(r_sep / a) [- ln R when Rdelta]
     ok = ok && (lx >= tb.r0) && (lx <= tb.r1);                     // RGI fill_value = nan
     const real uu = (lx - tb.r0) * tb.inv_dr;
     const real uc = PM::med3(uu, (real)0, (real)(tb.nr - 2));      // (clamped BEFORE the conversion: uu may be +-huge)
