@@ -387,8 +387,28 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     // persistent grid: two 512-thread workgroups per CU (LDS and registers allow exactly that) draw tiles from a counter that the
     // binning step has reset (the sixth block of the counter array)
     unsigned int *tile_counter = (unsigned int *)(p->tile_count + 5 * ((size_t)p->tiling.ntiles + 1));
-    const int grid = std::min(p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1), 2 * p->num_cus);
+    const int ntodo = p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
+    if constexpr (sizeof(real) == 4 && MODE != MODE_COUNT) {
+        // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 keeps the other
+        static const int fluid = [] { const char *e = std::getenv("BFGX_K1_FLUID"); return e ? std::atoi(e) : 1; }();
+        const size_t ldsf = tile2f_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
+        // (shells of a few hundred tiles -- NSIDE <= 256 -- keep the other form: half as many workgroups cannot balance so few tiles)
+        if (fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && ntodo >= 4 * p->num_cus) {
+            auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
+            HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
+            const int gridf = std::min(ntodo, p->num_cus);
+            hipLaunchKernelGGL(kf, dim3(std::max(gridf, 1)), dim3(kWave * kWF), ldsf, p->stream, tb, p->hpx, p->tiling,
+                               (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
+                               (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
+                               (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, out, tile_counter,
+                               (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
+                               p->k1_tile_lo, p->k1_tile_n, p->overflow);
+            HIP_TRY(hipGetLastError());
+            return BFGX_OK;
+        }
+    }
+    const int grid = std::min(ntodo, 2 * p->num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)p->tile_count, (const int32_t *)p->tile_count_b,
@@ -490,6 +510,17 @@ static void build_tiling(int64_t nside, bool paint, int &BR, int &W, std::vector
 extern "C" {
 
 int bfgx_abi_version(void) { return BFGX_ABI_VERSION; }
+
+#if BFGX_K1F_PROF
+// variant builds only (scripts/k1f_prof.py): the fluid kernel's shader-clock accounting, summed over waves and launches since the last reset
+int bfgx_debug_k1f_prof(unsigned long long *out8, int reset)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    if (out8) HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(bfgx::g_k1f_prof), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(bfgx::g_k1f_prof), z, sizeof(z))); }
+    return BFGX_OK;
+}
+#endif
 
 
 const char *bfgx_last_error(void) { return g_err.c_str(); }

@@ -266,6 +266,208 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     o.v2 = ez;
 }
 
+// ---------------------------------------------------------------------------------- one chunk of a tile's entry list
+// What a wave does with one chunk -- the entries [ebeg, ebeg + ecnt), ecnt <= kChunk2 -- of a tile's narrow-halo list: entries -> ring rows -> pairs, accumulated into the tile's
+// LDS planes `acc`.  Shared by the barrier-per-tile kernel (tile_scatter2_kernel) and the fluid kernel (tile_scatter2f_kernel).
+template <int MODE, typename real, int NP>
+__device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__restrict__ rowrecs, const PairRecT<real> *__restrict__ pairrecs,
+                                         const FbRec *__restrict__ fbrecs, const int32_t *__restrict__ ea, const int32_t *__restrict__ eb,
+                                         int na, int ebeg, int ecnt, int i0, int i1, int nphi, int wsh, int wmask, int PL,
+                                         double *acc, Wave2Lds<real> &L, const TileRow *rowtab, const RingC2<real> *ringc, int lane,
+                                         unsigned long long &npairs)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // ---- lanes = entries of this chunk; the non-empty ones are compacted into L.ent / L.pair
+    int nrows = 0;
+    EntC2 en;
+    en.hidx = 0; en.prefix = 0; en.ring_lo = 0; en.fb = 0;
+    RowGeo gg;
+    gg.z0 = gg.s0 = gg.xa = gg.cosr = gg.phi0 = 0.0;
+    if (lane < ecnt) {
+        const int ei = ebeg + lane;
+        en.hidx = ei < na ? ea[ei] : eb[ei - na];
+        const RowRec &rr = rowrecs[en.hidx];
+        if (BFGX_K1_GEO) { gg.z0 = rr.z0; gg.s0 = rr.s0; gg.xa = rr.xa; gg.cosr = rr.cosr; gg.phi0 = rr.phi0; }
+        en.fb = rr.fb;
+        if (en.fb) nrows = 4;
+        else {
+            const int lo = max(rr.rfirst, i0), hi = min(rr.rlast, i1 - 1);
+            nrows = max(0, hi - lo + 1);
+            en.ring_lo = lo;
+        }
+    }
+    const int incl_e = wave_scan_incl(nrows, lane);
+    const int total_rows = __builtin_amdgcn_readlane(incl_e, kWave - 1);
+    en.prefix = incl_e - nrows;
+    if (lane < kChunk2) L.emask[lane] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    {
+        const unsigned long long nzE = __ballot(nrows > 0);
+        if (nrows > 0) {
+            const int slot = __popcll(nzE & lt);
+            L.ent[slot] = en;
+#if BFGX_K1_GEO
+            L.geo[slot] = gg;
+#endif
+            if (MODE != MODE_COUNT) L.pair[slot] = pairrecs[en.hidx];
+            atomicOr(&L.emask[en.prefix >> 6], 1ull << (en.prefix & 63));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // a row can hold two pixel runs only in a tile that spans whole rings (a disc across phi = 0): such tiles (the
+    // innermost polar bands) use 32 row lanes per pass so that the runs of one pass always fit the 64 row slots
+    const int rowlanes = (nphi == 1) ? 32 : kWave;
+    for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += rowlanes) {
+        // ---- lanes = ring rows (clipped to this tile)
+        const int R = rb + lane;
+        const bool rvalid = lane < rowlanes && R < total_rows;
+        int es = 0;                                            // the entry this row belongs to: set bits of emask at or below R, minus 1
+        {
+            const int wq = min(R, total_rows - 1) >> 6, bq = min(R, total_rows - 1) & 63;
+            for (int w = 0; w < wq; ++w) es += __popcll(L.emask[w]);          // at most 15 words; almost always 0 or 1
+            es += __popcll(L.emask[wq] & ((2ull << bq) - 1ull)) - 1;
+        }
+        const EntC2 ee = L.ent[es];
+        const int eh = ee.hidx, ep = ee.prefix, erl = ee.ring_lo, efb = ee.fb;
+        int kA = 0, cA = 0, cB = 0, rloc = 0;
+        double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0;
+        if (rvalid) {
+            const int q = R - ep;
+#if BFGX_K1_GEO
+            const RowGeo rr = L.geo[es];                       // (staged by the entry phase: one global read per halo instead of one per ring row)
+#else
+            const RowRec &rr = rowrecs[eh];
+#endif
+            if (efb) {
+                const int ring = fbrecs[eh].ring[q], fk = fbrecs[eh].k[q];
+                if (ring >= i0 && ring < i1) {
+                    const TileRow &tr = rowtab[ring - i0];
+                    rloc = ring - i0;
+                    dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
+                    if (fk >= tr.ks && fk < tr.ke) {
+                        kA = fk - tr.ks; cA = 1;
+                        x0A = fold_dphi(__builtin_fma((double)fk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
+                    }
+                }
+            } else {
+                const int ring = erl + q;
+                const TileRow &tr = rowtab[ring - i0];
+                int slo, scnt;
+                disc_row_span_narrow(tr.nr, tr.shifted != 0, tr.z, tr.fnr, rr.z0, rr.xa, rr.cosr, rr.phi0, slo, scnt);
+                rloc = ring - i0;
+                dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
+                const int nr = tr.nr, ks = tr.ks, ke = tr.ke;
+                const double xoff = (tr.shifted ? 0.5 : 0.0) * tr.dphi - rr.phi0;
+                const int endA = min(slo + scnt, nr);
+                const int firstA = max(slo, ks);
+                cA = max(0, min(endA, ke) - firstA);
+                kA = firstA - ks;
+                x0A = fold_dphi(__builtin_fma((double)firstA, tr.dphi, xoff));
+                const int endB = slo + scnt - nr;              // > 0 when the row wraps past phi = 2 pi: second run [ks, endB)
+                cB = max(0, min(endB, ke) - ks);
+                x0B = fold_dphi(__builtin_fma((double)ks, tr.dphi, xoff));
+            }
+        }
+        // pairs and row slots of this pass: one scan over (pairs | runs << 16)
+        const int nrun = (cA > 0 ? 1 : 0) + (cB > 0 ? 1 : 0);
+        const int incl = wave_scan_incl((cA + cB) | (nrun << 16), lane);
+        const int tot2 = __builtin_amdgcn_readlane(incl, kWave - 1);
+        const int total = tot2 & 0xFFFF;
+        npairs += (unsigned long long)total;
+        if (MODE == MODE_COUNT || total == 0 || BFGX_ABL2 == 3) continue;
+        {
+            // compact the runs into row slots and mark each run's first pair in a bit mask
+            const int excl = incl - ((cA + cB) | (nrun << 16));
+            const int pre = excl & 0xFFFF, slot = excl >> 16;
+            const int nwords = (total + kWave - 1) / kWave + 2;
+            for (int wI = lane; wI < nwords; wI += kWave) L.mask[wI] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            const int rot = ((rloc & 7) << wsh) >> 3;                  // ring r is rotated by (r & 7) W / 8 columns
+            if (cA > 0) {
+                RowC2<real> rc;
+                rc.pk = (uint32_t)pre | ((uint32_t)((kA + rot) & wmask) << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
+                rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)x0A;
+                L.rows[slot] = rc;
+                atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
+            }
+            if (cB > 0) {
+                const int preB = pre + cA;
+                RowC2<real> rc;
+                rc.pk = (uint32_t)preB | ((uint32_t)(rot & wmask) << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
+                rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)x0B;
+                L.rows[slot + (cA > 0 ? 1 : 0)] = rc;
+                atomicOr(&L.mask[preB >> 6], 1ull << (preB & 63));
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- lanes = (halo, pixel) pairs, NP per lane per trip: the evaluations are straight-line code so that
+            // the LDS reads and table loads of the NP pairs are in flight together
+            int base = 0;                                      // rows started before the current 64 pairs
+            // the mask word and the row record of the NEXT trip are fetched while this trip computes
+            unsigned long long m_nx = wave_uniform64(L.mask[0]);
+            RowC2<real> rc_nx[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const unsigned long long m = (u == 0) ? m_nx : wave_uniform64(L.mask[u]);
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int row = base + below + (int)((m >> lane) & 1ull) - 1;
+                base += __popcll(m);
+                rc_nx[u] = L.rows[(u * kWave + lane < total) ? row : 0];
+            }
+            for (int T0 = 0; T0 < (BFGX_ABL2 == 4 ? 0 : total); T0 += NP * kWave) {
+                PairEval<real> pv[NP];
+                RowC2<real> rc_cur[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) rc_cur[u] = rc_nx[u];
+                const int T1 = T0 + NP * kWave;
+                if (T1 < total) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const unsigned long long m = wave_uniform64(L.mask[(T1 >> 6) + u]);
+                        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int row = base + below + (int)((m >> lane) & 1ull) - 1;
+                        base += __popcll(m);
+                        rc_nx[u] = L.rows[(T1 + u * kWave + lane < total) ? row : 0];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int t = T0 + u * kWave + lane;
+                    pair_eval<MODE, real>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
+                }
+                if (MODE == MODE_OFFSETS && sizeof(real) == 4) {
+                    // pairs whose fp32 chord is within 4e-6 of the model-side cut (BaryonCorrection.py:381-382): decide in fp64 (rare)
+                    bool anyamb = false;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) anyamb = anyamb || pv[u].amb;
+                    if (__builtin_expect(__any(anyamb), 0)) {
+#pragma unroll
+                        for (int u = 0; u < NP; ++u)
+                            if (pv[u].amb) {
+                                const int rl = pv[u].la >> wsh;
+                                const bool in = exact_cut_test(rowtab[rl], rowrecs[pv[u].hidx], (pv[u].la - (((rl & 7) << wsh) >> 3)) & wmask);
+                                pv[u].ok = pv[u].ok_nocut && in;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    if (BFGX_ABL2 == 5) { if (pv[u].ok && pv[u].v0 == (real)1.2345e30) acc[pv[u].la] = (double)(pv[u].v1 + pv[u].v2); }
+                    else if (pv[u].ok) {
+                        atomicAdd(acc + pv[u].la, (double)pv[u].v0);                         // ds_add_f64
+                        if (MODE == MODE_OFFSETS) {
+                            atomicAdd(acc + PL + pv[u].la, (double)pv[u].v1);
+                            atomicAdd(acc + 2 * PL + pv[u].la, (double)pv[u].v2);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- the kernel
 template <int MODE, typename ACC, typename real, int NP>
 __global__ void __launch_bounds__(kWave * kW2, (sizeof(real) == 4 ? 4 : 2))
@@ -350,8 +552,6 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     const int nchunks = (BFGX_ABL2 == 1) ? 0 : (ne + csz - 1) / csz;
     WaveLds &L = wl[wid];
     unsigned long long npairs = 0;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    (void)lt;
 
     while (true) {
         int c = 0;
@@ -359,195 +559,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         c = __builtin_amdgcn_readfirstlane(c);
         if (c >= nchunks) break;
 
-        // ---- lanes = entries of this chunk; the non-empty ones are compacted into L.ent / L.pair
-        int nrows = 0;
-        EntC2 en;
-        en.hidx = 0; en.prefix = 0; en.ring_lo = 0; en.fb = 0;
-        RowGeo gg;
-        gg.z0 = gg.s0 = gg.xa = gg.cosr = gg.phi0 = 0.0;
-        if (lane < csz && c * csz + lane < ne) {
-            const int ei = c * csz + lane;
-            en.hidx = ei < na ? ea[ei] : eb[ei - na];
-            const RowRec &rr = rowrecs[en.hidx];
-            if (BFGX_K1_GEO) { gg.z0 = rr.z0; gg.s0 = rr.s0; gg.xa = rr.xa; gg.cosr = rr.cosr; gg.phi0 = rr.phi0; }
-            en.fb = rr.fb;
-            if (en.fb) nrows = 4;
-            else {
-                const int lo = max(rr.rfirst, i0), hi = min(rr.rlast, i1 - 1);
-                nrows = max(0, hi - lo + 1);
-                en.ring_lo = lo;
-            }
-        }
-        const int incl_e = wave_scan_incl(nrows, lane);
-        const int total_rows = __builtin_amdgcn_readlane(incl_e, kWave - 1);
-        en.prefix = incl_e - nrows;
-        if (lane < kChunk2) L.emask[lane] = 0ull;
-        __builtin_amdgcn_wave_barrier();
-        {
-            const unsigned long long nzE = __ballot(nrows > 0);
-            if (nrows > 0) {
-                const int slot = __popcll(nzE & lt);
-                L.ent[slot] = en;
-#if BFGX_K1_GEO
-                L.geo[slot] = gg;
-#endif
-                if (MODE != MODE_COUNT) L.pair[slot] = pairrecs[en.hidx];
-                atomicOr(&L.emask[en.prefix >> 6], 1ull << (en.prefix & 63));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // a row can hold two pixel runs only in a tile that spans whole rings (a disc across phi = 0): such tiles (the
-        // innermost polar bands) use 32 row lanes per pass so that the runs of one pass always fit the 64 row slots
-        const int rowlanes = (nphi == 1) ? 32 : kWave;
-        for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += rowlanes) {
-            // ---- lanes = ring rows (clipped to this tile)
-            const int R = rb + lane;
-            const bool rvalid = lane < rowlanes && R < total_rows;
-            int es = 0;                                            // the entry this row belongs to: set bits of emask at or below R, minus 1
-            {
-                const int wq = min(R, total_rows - 1) >> 6, bq = min(R, total_rows - 1) & 63;
-                for (int w = 0; w < wq; ++w) es += __popcll(L.emask[w]);          // at most 15 words; almost always 0 or 1
-                es += __popcll(L.emask[wq] & ((2ull << bq) - 1ull)) - 1;
-            }
-            const EntC2 ee = L.ent[es];
-            const int eh = ee.hidx, ep = ee.prefix, erl = ee.ring_lo, efb = ee.fb;
-            int kA = 0, cA = 0, cB = 0, rloc = 0;
-            double x0A = 0.0, x0B = 0.0, dzv = 0.0, dsv = 0.0;
-            if (rvalid) {
-                const int q = R - ep;
-#if BFGX_K1_GEO
-                const RowGeo rr = L.geo[es];                       // (staged by the entry phase: one global read per halo instead of one per ring row)
-#else
-                const RowRec &rr = rowrecs[eh];
-#endif
-                if (efb) {
-                    const int ring = fbrecs[eh].ring[q], fk = fbrecs[eh].k[q];
-                    if (ring >= i0 && ring < i1) {
-                        const TileRow &tr = rowtab[ring - i0];
-                        rloc = ring - i0;
-                        dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
-                        if (fk >= tr.ks && fk < tr.ke) {
-                            kA = fk - tr.ks; cA = 1;
-                            x0A = fold_dphi(__builtin_fma((double)fk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
-                        }
-                    }
-                } else {
-                    const int ring = erl + q;
-                    const TileRow &tr = rowtab[ring - i0];
-                    int slo, scnt;
-                    disc_row_span_narrow(tr.nr, tr.shifted != 0, tr.z, tr.fnr, rr.z0, rr.xa, rr.cosr, rr.phi0, slo, scnt);
-                    rloc = ring - i0;
-                    dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
-                    const int nr = tr.nr, ks = tr.ks, ke = tr.ke;
-                    const double xoff = (tr.shifted ? 0.5 : 0.0) * tr.dphi - rr.phi0;
-                    const int endA = min(slo + scnt, nr);
-                    const int firstA = max(slo, ks);
-                    cA = max(0, min(endA, ke) - firstA);
-                    kA = firstA - ks;
-                    x0A = fold_dphi(__builtin_fma((double)firstA, tr.dphi, xoff));
-                    const int endB = slo + scnt - nr;              // > 0 when the row wraps past phi = 2 pi: second run [ks, endB)
-                    cB = max(0, min(endB, ke) - ks);
-                    x0B = fold_dphi(__builtin_fma((double)ks, tr.dphi, xoff));
-                }
-            }
-            // pairs and row slots of this pass: one scan over (pairs | runs << 16)
-            const int nrun = (cA > 0 ? 1 : 0) + (cB > 0 ? 1 : 0);
-            const int incl = wave_scan_incl((cA + cB) | (nrun << 16), lane);
-            const int tot2 = __builtin_amdgcn_readlane(incl, kWave - 1);
-            const int total = tot2 & 0xFFFF;
-            npairs += (unsigned long long)total;
-            if (MODE == MODE_COUNT || total == 0 || BFGX_ABL2 == 3) continue;
-            {
-                // compact the runs into row slots and mark each run's first pair in a bit mask
-                const int excl = incl - ((cA + cB) | (nrun << 16));
-                const int pre = excl & 0xFFFF, slot = excl >> 16;
-                const int nwords = (total + kWave - 1) / kWave + 2;
-                for (int wI = lane; wI < nwords; wI += kWave) L.mask[wI] = 0ull;
-                __builtin_amdgcn_wave_barrier();
-                const int rot = ((rloc & 7) << wsh) >> 3;                  // ring r is rotated by (r & 7) W / 8 columns
-                if (cA > 0) {
-                    RowC2<real> rc;
-                    rc.pk = (uint32_t)pre | ((uint32_t)((kA + rot) & wmask) << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
-                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)x0A;
-                    L.rows[slot] = rc;
-                    atomicOr(&L.mask[pre >> 6], 1ull << (pre & 63));
-                }
-                if (cB > 0) {
-                    const int preB = pre + cA;
-                    RowC2<real> rc;
-                    rc.pk = (uint32_t)preB | ((uint32_t)(rot & wmask) << 12) | ((uint32_t)rloc << 18) | ((uint32_t)es << 24);
-                    rc.dz = (real)dzv; rc.ds = (real)dsv; rc.x0 = (real)x0B;
-                    L.rows[slot + (cA > 0 ? 1 : 0)] = rc;
-                    atomicOr(&L.mask[preB >> 6], 1ull << (preB & 63));
-                }
-                __builtin_amdgcn_wave_barrier();
-
-                // ---- lanes = (halo, pixel) pairs, NP per lane per trip: the evaluations are straight-line code so that
-                // the LDS reads and table loads of the NP pairs are in flight together
-                int base = 0;                                      // rows started before the current 64 pairs
-                // the mask word and the row record of the NEXT trip are fetched while this trip computes
-                unsigned long long m_nx = wave_uniform64(L.mask[0]);
-                RowC2<real> rc_nx[NP];
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    const unsigned long long m = (u == 0) ? m_nx : wave_uniform64(L.mask[u]);
-                    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    const int row = base + below + (int)((m >> lane) & 1ull) - 1;
-                    base += __popcll(m);
-                    rc_nx[u] = L.rows[(u * kWave + lane < total) ? row : 0];
-                }
-                for (int T0 = 0; T0 < (BFGX_ABL2 == 4 ? 0 : total); T0 += NP * kWave) {
-                    PairEval<real> pv[NP];
-                    RowC2<real> rc_cur[NP];
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) rc_cur[u] = rc_nx[u];
-                    const int T1 = T0 + NP * kWave;
-                    if (T1 < total) {
-#pragma unroll
-                        for (int u = 0; u < NP; ++u) {
-                            const unsigned long long m = wave_uniform64(L.mask[(T1 >> 6) + u]);
-                            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                            const int row = base + below + (int)((m >> lane) & 1ull) - 1;
-                            base += __popcll(m);
-                            rc_nx[u] = L.rows[(T1 + u * kWave + lane < total) ? row : 0];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        const int t = T0 + u * kWave + lane;
-                        pair_eval<MODE, real>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
-                    }
-                    if (MODE == MODE_OFFSETS && sizeof(real) == 4) {
-                        // pairs whose fp32 chord is within 4e-6 of the model-side cut (BaryonCorrection.py:381-382): decide in fp64 (rare)
-                        bool anyamb = false;
-#pragma unroll
-                        for (int u = 0; u < NP; ++u) anyamb = anyamb || pv[u].amb;
-                        if (__builtin_expect(__any(anyamb), 0)) {
-#pragma unroll
-                            for (int u = 0; u < NP; ++u)
-                                if (pv[u].amb) {
-                                    const int rl = pv[u].la >> wsh;
-                                    const bool in = exact_cut_test(rowtab[rl], rowrecs[pv[u].hidx], (pv[u].la - (((rl & 7) << wsh) >> 3)) & wmask);
-                                    pv[u].ok = pv[u].ok_nocut && in;
-                                }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        if (BFGX_ABL2 == 5) { if (pv[u].ok && pv[u].v0 == (real)1.2345e30) acc[pv[u].la] = (double)(pv[u].v1 + pv[u].v2); }
-                        else if (pv[u].ok) {
-                            atomicAdd(acc + pv[u].la, (double)pv[u].v0);                         // ds_add_f64
-                            if (MODE == MODE_OFFSETS) {
-                                atomicAdd(acc + PL + pv[u].la, (double)pv[u].v1);
-                                atomicAdd(acc + 2 * PL + pv[u].la, (double)pv[u].v2);
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+        k1_chunk<MODE, real, NP>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+                                 lane, npairs);
     }
     __syncthreads();
 
@@ -590,6 +603,340 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     }
     __syncthreads();                                   // the LDS tile is reused by the next tile
     }
+}
+
+
+// ---------------------------------------------------------------------------------- the fluid kernel (round 4)
+// The kernel above separates its tiles with workgroup barriers: 14 chunks over 8 waves leave two waves one chunk short, and every wave
+// waits at the end-of-tile barrier for the slowest (19 % of the wave time by the shader clock), then for the flush, the zero-fill and
+// the next tile's ring table.  Here ONE 1024-thread workgroup per CU (the same 16 waves and the same LDS as two workgroups of the
+// kernel above) owns TWO tile slots and no wave ever waits for another at a tile boundary: a wave that finds no chunk left in tile k
+// leaves it (one LDS counter) and goes on to tile k + 1 in the other slot.  The LAST wave to leave tile k flushes it on its own
+// (2048 pixels: 32 rows of one trip each, zeroing the planes as it reads them), draws the workgroup's tile k + 2, builds its ring
+// table and descriptor in the slot it has just emptied and publishes the slot's sequence number; a wave that reaches tile k + 2
+// earlier than that sleeps on the number.  Waits are bounded: a wave that has slept 2^22 times raises *err and leaves, so the grid
+// always drains.
+constexpr int kWF = 16;               // waves per workgroup of the fluid kernel
+#ifndef BFGX_K1F_PROF
+#define BFGX_K1F_PROF 0              // 1: shader-clock accounting of the fluid kernel's waves (variant builds only: scripts/k1f_prof.py)
+#endif
+#if BFGX_K1F_PROF
+__device__ unsigned long long g_k1f_prof[8];       // wait for a slot, chunks, flush + refill, whole wave, flushes
+#endif
+struct alignas(16) FluidSlot {
+    int32_t seq;                      // sequence number (per workgroup) of the tile this slot holds; -1: none yet
+    int32_t tile;                     // < 0: no tile left
+    int32_t next_chunk, done;
+    int32_t i0, i1, nphi, na;
+    int32_t ne, csz, nchunks, _pad;
+    const int32_t *ea, *eb;
+    int32_t flushing;                 // 1 while the slot's tile is being flushed: waves waiting for the slot take row groups
+    int32_t fl_next, fl_done;         // row groups handed out / finished
+    uint32_t om2;                     // largest |offset|^2 of the tile (bits of a non-negative float)
+    // the slot's NEXT tile, drawn and prepared while the current one is being worked on (stage_next), moved up by promote()
+    int32_t staged;                   // sequence number of the staged tile (-1: none)
+    int32_t nx_tile, nx_i0, nx_i1;
+    int32_t nx_nphi, nx_na, nx_ne, nx_pad;
+    const int32_t *nx_ea, *nx_eb;
+};
+
+template <typename real>
+__host__ __device__ inline size_t tile2f_lds_bytes(int BR, int W, int ncomp)
+{
+    size_t a = (size_t)ncomp * ((size_t)BR * W + kPlanePad) * sizeof(double);
+    a = (a + 15) & ~(size_t)15;
+    return 2 * a + sizeof(Wave2Lds<real>) * kWF + 2 * sizeof(FluidSlot) + 4 * (sizeof(TileRow) + sizeof(RingC2<real>)) * (size_t)BR;
+}
+
+template <int MODE, typename ACC, typename real>
+__global__ void __launch_bounds__(kWave * kWF, 1)
+tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
+                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
+                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
+                      const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a,
+                      ACC *__restrict__ out, unsigned int *__restrict__ tile_counter, unsigned int *__restrict__ omax2,
+                      int tile_lo, int tile_n, int32_t *__restrict__ err)
+{
+    static_assert(MODE == MODE_OFFSETS || MODE == MODE_PAINT, "the census runs in tile_scatter2_kernel");
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
+    const int PL = T.BR * T.W + kPlanePad;
+    const int wsh = __ffs(T.W) - 1, wmask = T.W - 1;
+    const size_t plane_bytes = ((size_t)NCOMP * PL * sizeof(double) + 15) & ~(size_t)15;
+    using WaveLds = Wave2Lds<real>;
+    size_t off = 2 * plane_bytes;
+    WaveLds *wl = reinterpret_cast<WaveLds *>(smem + off);
+    off += sizeof(WaveLds) * kWF;
+    FluidSlot *slots = reinterpret_cast<FluidSlot *>(smem + off);
+    off += 2 * sizeof(FluidSlot);
+    TileRow *rowtab_all = reinterpret_cast<TileRow *>(smem + off);
+    off += 4 * sizeof(TileRow) * (size_t)T.BR;        // [slot][parity of the slot's tile count]: the live table and the staged one
+    RingC2<real> *ringc_all = reinterpret_cast<RingC2<real> *>(smem + off);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int ntodo = tile_n < 0 ? T.ntiles : tile_n;
+
+    // draw_tile(): the workgroup's next tile from the device counter and what its descriptor needs from global memory
+    struct Drawn { int tile, band, nphi, tj, na, ne; const int32_t *ea, *eb; };
+    auto draw_tile = [&]() {
+        Drawn d;
+        d.tile = -1; d.band = 0; d.nphi = 1; d.tj = 0; d.na = 0; d.ne = 0; d.ea = entries; d.eb = entries;
+        int tile_idx = 0;
+        if (lane == 0) tile_idx = (int)atomicAdd(tile_counter, 1u);
+        tile_idx = __builtin_amdgcn_readfirstlane(tile_idx);
+        if (tile_idx < ntodo) {
+            const int tile = tile_n < 0 ? T.tile_order[tile_idx] : tile_lo + tile_idx;
+            d.tile = tile;
+            d.band = T.tile_band[tile];
+            d.nphi = T.band_nphi[d.band];
+            d.tj = tile - T.band_tile0[d.band];
+            // (the same list arithmetic as tile_scatter2_kernel: region A = the tile's fixed-capacity list, region B in the shared list)
+            const int64_t e0 = tile_start[tile];
+            const int na = entries_a ? min(cnt_a[tile], cap_a) : cnt_a[tile];
+            d.ea = entries_a ? entries_a + (int64_t)tile * cap_a : entries + e0;
+            const int64_t eb0 = e0 + (entries_a ? 0 : na);
+            int64_t nb64 = cnt_b[tile];
+            if (eb0 + nb64 > capacity) nb64 = capacity > eb0 ? capacity - eb0 : 0;
+            if (!entries_a && e0 + na > capacity) nb64 = 0;
+            d.na = na;
+            d.ne = (!entries_a && e0 + na > capacity) ? (int)(capacity > e0 ? capacity - e0 : 0) : na + (int)nb64;
+            d.eb = entries + eb0;
+        }
+        return d;
+    };
+    // ONE wave, right after it has published the slot's tile kk - 2: draw the slot's tile kk and prepare it beside the live one (ring table
+    // in the other half of the slot's table pair, descriptor in the nx_ fields), so that the chain of dependent global loads (tile counter
+    // -> tile order -> band -> list bounds) is over long before the live tile has been flushed
+    auto stage_next = [&](int s, int kk) {
+        FluidSlot &S = slots[s];
+        const Drawn d = draw_tile();
+        if (d.tile < 0) {
+            if (lane == 0) { S.nx_tile = -1; S.nx_ne = 0; }
+        } else {
+            const int i0 = 1 + d.band * T.BR;
+            const int i1 = min(i0 + T.BR, (int)(4 * h.nside));
+            const int par = (kk >> 1) & 1;
+            TileRow *rowtab = rowtab_all + (size_t)(2 * s + par) * T.BR;
+            RingC2<real> *ringc = ringc_all + (size_t)(2 * s + par) * T.BR;
+            if (lane < T.BR && i0 + lane < i1) {
+                const int ring = i0 + lane;
+                int64_t st, n64; bool shf;
+                TileRow tr;
+                ring_info_small(h, ring, st, n64, shf);
+                ring_z_sth(h, ring, tr.z, tr.sth);
+                tr.nr = (int)n64; tr.shifted = shf ? 1 : 0;
+                tr.dphi = kTwoPi / (double)tr.nr;
+                tr.fnr = (double)n64 * kInvTwoPi;
+                tr.ks = tile_ks(d.tj, tr.nr, d.nphi); tr.ke = tile_ks(d.tj + 1, tr.nr, d.nphi);
+                rowtab[lane] = tr;
+                RingC2<real> rg;
+                rg.sth = (real)tr.sth; rg.zf = (real)tr.z; rg.dphi = (real)tr.dphi; rg._pad = (real)0;
+                ringc[lane] = rg;
+            }
+            if (lane == 0) {
+                S.nx_tile = d.tile; S.nx_i0 = i0; S.nx_i1 = i1; S.nx_nphi = d.nphi; S.nx_na = d.na; S.nx_ne = d.ne;
+                S.nx_ea = d.ea; S.nx_eb = d.eb;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&S.staged, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // the staged tile kk becomes the slot's live tile (the slot is empty: flushed, planes zeroed); false: the staging never arrived
+    auto promote = [&](int s, int kk) -> bool {
+        FluidSlot &S = slots[s];
+        int spins = 0;
+        while (__hip_atomic_load(&S.staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != kk) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) return false;
+        }
+        if (lane == 0) {
+            S.tile = S.nx_tile; S.next_chunk = 0; S.done = 0;
+            S.i0 = S.nx_i0; S.i1 = S.nx_i1; S.nphi = S.nx_nphi; S.na = S.nx_na;
+            // entries per chunk: at most kChunk2, fewer when the list is short, so that every wave gets a chunk (a tile of a fine shell lists a
+            // few halos of hundreds of pixels each); full chunks from half a workgroup's worth of them.  Smaller chunks for long lists, or
+            // half chunks at the end of the list, measured slower.
+            S.ne = S.nx_ne; S.csz = S.nx_ne >= kChunk2 * kWF / 2 ? kChunk2 : max(1, min(kChunk2, (S.nx_ne + kWF - 1) / kWF));
+            S.nchunks = S.nx_tile < 0 ? 0 : (S.nx_ne + S.csz - 1) / S.csz; S._pad = 0;
+            S.ea = S.nx_ea; S.eb = S.nx_eb;
+            __hip_atomic_store(&S.seq, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return true;
+    };
+
+    {
+        double *accz = reinterpret_cast<double *>(smem);
+        const int nz = (int)(2 * plane_bytes / sizeof(double));
+        for (int i = tid; i < nz; i += kWave * kWF) accz[i] = 0.0;
+        if (tid < 2) { slots[tid].seq = -1; slots[tid].staged = -1; slots[tid].flushing = 0; slots[tid].fl_next = 1 << 30; slots[tid].fl_done = 0; slots[tid].om2 = 0u; }
+    }
+    __syncthreads();
+    if (wid < 2) { stage_next(wid, wid); promote(wid, wid); stage_next(wid, wid + 2); }
+
+    WaveLds &L = wl[wid];
+    unsigned long long npairs = 0;
+    bool ended = false;
+#if BFGX_K1F_PROF
+    unsigned long long pf_wait = 0, pf_chunk = 0, pf_flush = 0, pf_nfl = 0;
+    const unsigned long long pf_t0 = __builtin_readcyclecounter();
+#define PF_NOW() __builtin_readcyclecounter()
+#else
+#define PF_NOW() 0ull
+#endif
+    // The flush of a slot, in groups of four rows handed out by an LDS counter: to the last wave out of the tile, and to every wave that
+    // reaches the slot's NEXT tile while the flush is still going on (instead of sleeping).  A group: twelve LDS reads in flight (one pixel per
+    // lane and row; W <= 64), the planes zeroed as they are read, four stores; the group's largest |offset|^2 goes to the slot.
+    auto flush_groups = [&](int s, int par) {
+        FluidSlot &S = slots[s];
+        const int i0 = __builtin_amdgcn_readfirstlane(S.i0), nrow = __builtin_amdgcn_readfirstlane(S.i1) - i0;
+        const int ngroups = (nrow + 3) >> 2;
+        double *acc = reinterpret_cast<double *>(smem + (size_t)s * plane_bytes);
+        const TileRow *rowtab = rowtab_all + (size_t)(2 * s + par) * T.BR;
+        // (at most ngroups + 1 draws per caller: the loop is bounded whatever the counter holds)
+        for (int it = 0; it <= ngroups; ++it) {
+            int g = 0;
+            if (lane == 0) g = __hip_atomic_fetch_add(&S.fl_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g >= ngroups) break;
+            float om2 = 0.0f;
+            struct alignas(sizeof(ACC)) Px3 { ACC c[3]; };
+            ACC v[4][NCOMP];
+            bool on[4];
+            ACC *dp[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = min(4 * g + q, nrow - 1);
+                int64_t st, n64; bool shf;
+                ring_info_small(h, i0 + rr, st, n64, shf);
+                const TileRow &tr = rowtab[rr];
+                const int ks = tr.ks, npx = tr.ke - tr.ks;
+                double *src = acc + (rr << wsh);
+                const int ix = (lane + (((rr & 7) << wsh) >> 3)) & wmask;
+                on[q] = (4 * g + q < nrow) && lane < npx;
+                dp[q] = out + NCOMP * (st + ks + lane);
+#pragma unroll
+                for (int cc = 0; cc < NCOMP; ++cc) v[q][cc] = (ACC)0;
+                if (on[q]) {
+#pragma unroll
+                    for (int cc = 0; cc < NCOMP; ++cc) { v[q][cc] = (ACC)src[cc * PL + ix]; src[cc * PL + ix] = 0.0; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (NCOMP == 3) {
+                    if (on[q]) { Px3 w; w.c[0] = v[q][0]; w.c[1] = v[q][1]; w.c[2] = v[q][2]; *reinterpret_cast<Px3 *>(dp[q]) = w; }
+                    const float a = (float)v[q][0], b = (float)v[q][1], c = (float)v[q][NCOMP - 1];
+                    om2 = fmaxf(om2, fma_(a, a, fma_(b, b, c * c)));
+                } else if (on[q]) *dp[q] = v[q][0];
+            }
+            if (MODE == MODE_OFFSETS) {
+#pragma unroll
+                for (int sft = kWave >> 1; sft > 0; sft >>= 1) om2 = fmaxf(om2, __shfl_down(om2, sft, kWave));
+                if (lane == 0 && om2 > 0.0f) atomicMax(&S.om2, __float_as_uint(om2));
+            }
+            if (lane == 0) __hip_atomic_fetch_add(&S.fl_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+
+    for (int k = 0;; ++k) {
+        const int s = k & 1;
+        const unsigned long long pf_a = PF_NOW();
+        (void)pf_a;
+        FluidSlot &S = slots[s];
+        // wait for the slot to hold tile k of this workgroup (it held tile k - 2 until the last wave out of that one had flushed it), and
+        // help with that flush meanwhile
+        {
+            int spins = 0;
+            while (__hip_atomic_load(&S.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) {
+                if (__hip_atomic_load(&S.flushing, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 1) flush_groups(s, ((k >> 1) & 1) ^ 1);
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) {
+                    if (lane == 0) atomicOr(err, 4);
+                    return;
+                }
+            }
+        }
+        // The workgroup's two slots are refilled by different waves, so the draws of tiles k and k + 1 may come in either order: a slot
+        // without a tile is passed through like an empty tile (its successor may still hold one); two of them in a row end the
+        // sequence, because the tile counter only grows and every later draw follows one of those two.
+        const unsigned long long pf_b = PF_NOW();
+        (void)pf_b;
+#if BFGX_K1F_PROF
+        pf_wait += pf_b - pf_a;
+#endif
+        const int tile = __builtin_amdgcn_readfirstlane(S.tile);
+        if (tile < 0 && ended) break;
+        ended = tile < 0;
+        const int i0 = __builtin_amdgcn_readfirstlane(S.i0), i1 = __builtin_amdgcn_readfirstlane(S.i1);
+        const int nphi = __builtin_amdgcn_readfirstlane(S.nphi), na = __builtin_amdgcn_readfirstlane(S.na);
+        const int ne = __builtin_amdgcn_readfirstlane(S.ne), csz = __builtin_amdgcn_readfirstlane(S.csz);
+        const int nchunks = (BFGX_ABL2 == 1 || tile < 0) ? 0 : __builtin_amdgcn_readfirstlane(S.nchunks);
+        const int32_t *ea = reinterpret_cast<const int32_t *>(wave_uniform64((unsigned long long)S.ea));
+        const int32_t *eb = reinterpret_cast<const int32_t *>(wave_uniform64((unsigned long long)S.eb));
+        double *acc = reinterpret_cast<double *>(smem + (size_t)s * plane_bytes);
+        const TileRow *rowtab = rowtab_all + (size_t)(2 * s + ((k >> 1) & 1)) * T.BR;
+        const RingC2<real> *ringc = ringc_all + (size_t)(2 * s + ((k >> 1) & 1)) * T.BR;
+
+        while (true) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(&S.next_chunk, 1);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= nchunks) break;
+            k1_chunk<MODE, real, 1>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+                                    lane, npairs);
+        }
+#if BFGX_K1F_PROF
+        const unsigned long long pf_c = PF_NOW();
+        pf_chunk += pf_c - pf_b;
+#endif
+        // leave tile k; the last wave out starts the flush, takes part in it, and refills the slot when the last row group is done
+        int prev = 0;
+        if (lane == 0) prev = __hip_atomic_fetch_add(&S.done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        if (prev != kWF - 1) continue;
+        if (tile < 0) {
+            if (!promote(s, k + 2)) { if (lane == 0) atomicOr(err, 4); return; }
+            stage_next(s, k + 4);
+            continue;
+        }
+        // (no wave can still be inside flush_groups for this slot's previous tile: all sixteen have since entered and left tile k)
+        if (lane == 0) {
+            __hip_atomic_store(&S.fl_next, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&S.fl_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&S.om2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&S.flushing, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        flush_groups(s, (k >> 1) & 1);
+        {
+            const int ngroups = (i1 - i0 + 3) >> 2;
+            int spins = 0;
+            while (__hip_atomic_load(&S.fl_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ngroups) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) {
+                    if (lane == 0) atomicOr(err, 4);
+                    return;
+                }
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&S.flushing, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&S.fl_next, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        // a wave that still believes the flush is on draws no group of the NEXT tile (the slot's row count changes below)
+            const uint32_t ob = __hip_atomic_load(&S.om2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == MODE_OFFSETS && omax2 != nullptr && ob != 0u) atomicMax(omax2 + tile, __float_as_uint(__uint_as_float(ob) * 1.000001f));
+        }
+        if (!promote(s, k + 2)) { if (lane == 0) atomicOr(err, 4); return; }
+        stage_next(s, k + 4);
+#if BFGX_K1F_PROF
+        pf_flush += PF_NOW() - pf_c; pf_nfl += 1;
+#endif
+    }
+#if BFGX_K1F_PROF
+    if (lane == 0) {
+        atomicAdd(&g_k1f_prof[0], pf_wait); atomicAdd(&g_k1f_prof[1], pf_chunk); atomicAdd(&g_k1f_prof[2], pf_flush);
+        atomicAdd(&g_k1f_prof[3], PF_NOW() - pf_t0); atomicAdd(&g_k1f_prof[4], pf_nfl); atomicAdd(&g_k1f_prof[5], 1ull);
+    }
+#endif
 }
 
 }  // namespace bfgx
