@@ -617,6 +617,10 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 // earlier than that sleeps on the number.  Waits are bounded: a wave that has slept 2^22 times raises *err and leaves, so the grid
 // always drains.
 constexpr int kWF = 16;               // waves per workgroup of the fluid kernel
+#ifndef BFGX_CHUNKB
+#define BFGX_CHUNKB 2
+#endif
+constexpr int kChunkB = BFGX_CHUNKB;  // entries per chunk of region B
 #ifndef BFGX_K1F_PROF
 #define BFGX_K1F_PROF 0              // 1: shader-clock accounting of the fluid kernel's waves (variant builds only: scripts/k1f_prof.py)
 #endif
@@ -628,7 +632,7 @@ struct alignas(16) FluidSlot {
     int32_t tile;                     // < 0: no tile left
     int32_t next_chunk, done;
     int32_t i0, i1, nphi, na;
-    int32_t ne, csz, nchunks, _pad;
+    int32_t ne, csz, nchunks, _pad;      // (_pad: the chunks of region B)
     const int32_t *ea, *eb;
     int32_t flushing;                 // 1 while the slot's tile is being flushed: waves waiting for the slot take row groups
     int32_t fl_next, fl_done;         // row groups handed out / finished
@@ -638,6 +642,9 @@ struct alignas(16) FluidSlot {
     int32_t nx_tile, nx_i0, nx_i1;
     int32_t nx_nphi, nx_na, nx_ne, nx_pad;
     const int32_t *nx_ea, *nx_eb;
+#if BFGX_K1F_PROF
+    uint32_t pf_maxchunk, pf_pad[3];
+#endif
 };
 
 template <typename real>
@@ -757,8 +764,11 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             // entries per chunk: at most kChunk2, fewer when the list is short, so that every wave gets a chunk (a tile of a fine shell lists a
             // few halos of hundreds of pixels each); full chunks from half a workgroup's worth of them.  Smaller chunks for long lists, or
             // half chunks at the end of the list, measured slower.
-            S.ne = S.nx_ne; S.csz = S.nx_ne >= kChunk2 * kWF / 2 ? kChunk2 : max(1, min(kChunk2, (S.nx_ne + kWF - 1) / kWF));
-            S.nchunks = S.nx_tile < 0 ? 0 : (S.nx_ne + S.csz - 1) / S.csz; S._pad = 0;
+            // Region B of the list (discs over more than kRefMax tiles: the large ones) goes out FIRST and in chunks of kChunkB entries, so that
+            // the long items are not what the tile's waves finish on; then region A in chunks of csz.
+            S.ne = S.nx_ne; S.csz = S.nx_na >= kChunk2 * kWF / 2 ? kChunk2 : max(1, min(kChunk2, (S.nx_na + kWF - 1) / kWF));
+            S._pad = (S.nx_ne - S.nx_na + kChunkB - 1) / kChunkB;                      // chunks of region B
+            S.nchunks = S.nx_tile < 0 ? 0 : S._pad + (S.nx_na + S.csz - 1) / S.csz;
             S.ea = S.nx_ea; S.eb = S.nx_eb;
             __hip_atomic_store(&S.seq, kk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -769,7 +779,11 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
         double *accz = reinterpret_cast<double *>(smem);
         const int nz = (int)(2 * plane_bytes / sizeof(double));
         for (int i = tid; i < nz; i += kWave * kWF) accz[i] = 0.0;
-        if (tid < 2) { slots[tid].seq = -1; slots[tid].staged = -1; slots[tid].flushing = 0; slots[tid].fl_next = 1 << 30; slots[tid].fl_done = 0; slots[tid].om2 = 0u; }
+        if (tid < 2) { slots[tid].seq = -1; slots[tid].staged = -1; slots[tid].flushing = 0; slots[tid].fl_next = 1 << 30; slots[tid].fl_done = 0; slots[tid].om2 = 0u;
+#if BFGX_K1F_PROF
+            slots[tid].pf_maxchunk = 0u;
+#endif
+        }
     }
     __syncthreads();
     if (wid < 2) { stage_next(wid, wid); promote(wid, wid); stage_next(wid, wid + 2); }
@@ -778,7 +792,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
     unsigned long long npairs = 0;
     bool ended = false;
 #if BFGX_K1F_PROF
-    unsigned long long pf_wait = 0, pf_chunk = 0, pf_flush = 0, pf_nfl = 0;
+    unsigned long long pf_wait = 0, pf_chunk = 0, pf_flush = 0, pf_nfl = 0, pf_nchunk = 0, pf_maxsum = 0;
     const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #define PF_NOW() __builtin_readcyclecounter()
 #else
@@ -870,7 +884,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
         ended = tile < 0;
         const int i0 = __builtin_amdgcn_readfirstlane(S.i0), i1 = __builtin_amdgcn_readfirstlane(S.i1);
         const int nphi = __builtin_amdgcn_readfirstlane(S.nphi), na = __builtin_amdgcn_readfirstlane(S.na);
-        const int ne = __builtin_amdgcn_readfirstlane(S.ne), csz = __builtin_amdgcn_readfirstlane(S.csz);
+        const int ne = __builtin_amdgcn_readfirstlane(S.ne), csz = __builtin_amdgcn_readfirstlane(S.csz), nchb = __builtin_amdgcn_readfirstlane(S._pad);
         const int nchunks = (BFGX_ABL2 == 1 || tile < 0) ? 0 : __builtin_amdgcn_readfirstlane(S.nchunks);
         const int32_t *ea = reinterpret_cast<const int32_t *>(wave_uniform64((unsigned long long)S.ea));
         const int32_t *eb = reinterpret_cast<const int32_t *>(wave_uniform64((unsigned long long)S.eb));
@@ -883,8 +897,16 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             if (lane == 0) c = atomicAdd(&S.next_chunk, 1);
             c = __builtin_amdgcn_readfirstlane(c);
             if (c >= nchunks) break;
-            k1_chunk<MODE, real, 1>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+#if BFGX_K1F_PROF
+            const unsigned long long pf_c0 = PF_NOW();
+#endif
+            const int ebeg = c < nchb ? na + c * kChunkB : (c - nchb) * csz;
+            const int ecnt = c < nchb ? min(kChunkB, ne - ebeg) : min(csz, na - ebeg);
+            k1_chunk<MODE, real, 1>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
                                     lane, npairs);
+#if BFGX_K1F_PROF
+            if (lane == 0) { const unsigned d = (unsigned)(PF_NOW() - pf_c0); atomicMax(&S.pf_maxchunk, d); pf_nchunk += 1; }
+#endif
         }
 #if BFGX_K1F_PROF
         const unsigned long long pf_c = PF_NOW();
@@ -907,6 +929,9 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             __hip_atomic_store(&S.om2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&S.flushing, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#if BFGX_K1F_PROF
+        if (lane == 0) { pf_maxsum += S.pf_maxchunk; S.pf_maxchunk = 0u; }
+#endif
         flush_groups(s, (k >> 1) & 1);
         {
             const int ngroups = (i1 - i0 + 3) >> 2;
@@ -935,6 +960,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
     if (lane == 0) {
         atomicAdd(&g_k1f_prof[0], pf_wait); atomicAdd(&g_k1f_prof[1], pf_chunk); atomicAdd(&g_k1f_prof[2], pf_flush);
         atomicAdd(&g_k1f_prof[3], PF_NOW() - pf_t0); atomicAdd(&g_k1f_prof[4], pf_nfl); atomicAdd(&g_k1f_prof[5], 1ull);
+        atomicAdd(&g_k1f_prof[6], pf_nchunk); atomicAdd(&g_k1f_prof[7], pf_maxsum);
     }
 #endif
 }

@@ -39,8 +39,9 @@ for it in range(N):
     plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
 torch.cuda.synchronize()
 lib.bfgx_debug_k1f_prof(buf, 1)
-wait, chunk, flush, total, nfl, nw = [float(x) for x in buf[:6]]
+wait, chunk, flush, total, nfl, nw, nchunk, maxsum = [float(x) for x in buf[:8]]
 print("waves %d per launch, flushes %d per launch" % (nw / N, nfl / N))
 print("per wave (clock ticks): total %.0f  wait for slot %.0f (%.1f %%)  chunks %.0f (%.1f %%)  flush + refill %.0f (%.1f %%; %.0f per flush)  other %.1f %%"
       % (total / nw, wait / nw, 100 * wait / total, chunk / nw, 100 * chunk / total, flush / nw, 100 * flush / total, flush / max(nfl, 1),
          100 * (total - wait - chunk - flush) / total))
+print("chunks %d per launch (%.1f per tile): mean %.0f ticks, mean over tiles of the longest chunk %.0f ticks" % (nchunk / N, nchunk / max(nfl, 1), chunk / max(nchunk, 1), maxsum / max(nfl, 1)))
