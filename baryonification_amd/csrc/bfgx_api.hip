@@ -318,7 +318,9 @@ static int launch_place(bfgx_plan *p, const bfgx_catalog *c)
 static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool f64)
 {
     const size_t nt = (size_t)p->tiling.ntiles;
-    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * 7 * (nt + 1), p->stream));     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel, largest |offset|^2 per tile
+    // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel, largest |offset|^2 per tile, and the
+    // four control words of the regrid's far list behind them (entries, overflow, tiles left to the walking kernel)
+    HIP_TRY(hipMemsetAsync(p->tile_count, 0, sizeof(int32_t) * ((((size_t)7 * (nt + 1) + 3) & ~(size_t)3) + 4), p->stream));
     if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
     const int nt_i = p->tiling.ntiles, nsb = (nt_i + kScanTilesPerWg - 1) / kScanTilesPerWg;
@@ -680,7 +682,10 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             return 0;
         };
         void *d0 = nullptr, *d1 = nullptr, *d3 = nullptr, *d4 = nullptr, *d5 = nullptr, *d6 = nullptr;
-        if (dalloc(sizeof(int32_t) * 7 * (T.ntiles + 1), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
+        // the binning counters and, right behind them (16-byte aligned), the control words of the regrid's far list: ONE memset per step
+        // zeroes both (a length that is not a multiple of 16 bytes, or two buffers, cost a fill kernel each: 4.5 us)
+        const size_t n7p = ((size_t)7 * (T.ntiles + 1) + 3) & ~(size_t)3;
+        if (dalloc(sizeof(int32_t) * (n7p + (size_t)T.ntiles + 8), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
             dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
             dalloc(sizeof(unsigned long long), &d5) || dalloc(sizeof(TileRef) * (size_t)(max_halos > 0 ? max_halos : 1), &d6))
             return bail(fail(BFGX_ERR_HIP, "hipMalloc(binning workspace) failed"));
@@ -713,7 +718,8 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             // control words in one allocation: [0..7] entries listed, [8..11] overflow (full-map regrid), [12..15] tiles left to
             // the walking kernel (followed by their numbers), ... ; the banded regrid's overflow flag lives after the tile list
             void *f4 = nullptr;
-            if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 8), &f0) || dalloc(sizeof(int64_t) * (size_t)p->far.cap, &f1) ||
+            f0 = p->tile_count + n7p;
+            if (dalloc(sizeof(int64_t) * (size_t)p->far.cap, &f1) ||
                 dalloc(sizeof(double) * (size_t)p->far.cap, &f2) ||
                 dalloc(sizeof(int32_t) * 2 * (size_t)(T.ntiles + 1), &f3))
                 return bail(fail(BFGX_ERR_HIP, "hipMalloc(far list) failed"));
@@ -1265,7 +1271,8 @@ static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offse
     if (p->algo == 1) {
         // gathering form: every output pixel is stored once by the tile that owns it (no atomics, no zero-fill needed);
         // the few deposits that need the generic route are listed and added afterwards
-        HIP_TRY(hipMemsetAsync(p->far.count, 0, 4 * sizeof(int32_t), p->stream));      // entries, overflow, tiles left to the walking kernel
+        // entries, overflow, tiles left to the walking kernel (the fused call's binning step has zeroed them with its counters)
+        if (!from_k1) HIP_TRY(hipMemsetAsync(p->far.count, 0, 4 * sizeof(int32_t), p->stream));
         double *ts = sums_dev ? p->tile_sums : nullptr;
         if (acc_f64) launch_regrid_gather<double, double>(p, map_in_dev, (const double *)offsets_dev, map_out_dev, ts, from_k1, sums_dev);
         else launch_regrid_gather<float, float>(p, map_in_dev, (const float *)offsets_dev, map_out_dev, ts, from_k1, sums_dev);
