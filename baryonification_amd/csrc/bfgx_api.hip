@@ -106,6 +106,7 @@ struct bfgx_plan {
     // tile-owned accumulation (algo 1): tiling tables + halo -> tile binning workspace
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
+    int k1_fluid = 1;               // the fast kernel's fluid form (bfgx_scatter2.hpp): 1 = from 4 tiles per CU; BFGX_K1_FLUID at plan creation: 0 = never (the barrier-per-tile form), 2 = always (tests)
     Tiling tiling;
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
             *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
@@ -392,11 +393,10 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     const int ntodo = p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
     if constexpr (sizeof(real) == 4 && MODE != MODE_COUNT) {
-        // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 keeps the other
-        static const int fluid = [] { const char *e = std::getenv("BFGX_K1_FLUID"); return e ? std::atoi(e) : 1; }();
+        // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 at plan creation keeps the other
         const size_t ldsf = tile2f_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
         // (shells of a few hundred tiles -- NSIDE <= 256 -- keep the other form: half as many workgroups cannot balance so few tiles)
-        if (fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && ntodo >= 4 * p->num_cus) {
+        if (p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && (ntodo >= 4 * p->num_cus || p->k1_fluid == 2)) {
             auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
             HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             const int gridf = std::min(ntodo, p->num_cus);
@@ -675,6 +675,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         T.tile_order = (const int32_t *)dv;
         if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
         p->capacity = 8 * max_halos + 4096;
+        if (const char *e = std::getenv("BFGX_K1_FLUID")) p->k1_fluid = std::max(0, std::min(2, std::atoi(e)));
         if (const char *e = std::getenv("BFGX_ENTRY_CAP")) p->capacity = std::max<int64_t>(16, std::atoll(e));   // tests: force regrowth
         auto dalloc = [&](size_t bytes, void **ptr) {
             if (hipMalloc(ptr, bytes) != hipSuccess) return 1;

@@ -650,7 +650,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 int k = rw.ks + x;
                 if (k < 0) k += rw.nr;
                 if (k >= rw.nr) k -= rw.nr;
-                const int64_t p = rw.start + k;
+                const int64_t p = (BFGX_ABLK2 == 4) ? (int64_t)((rw.start + k) & 4095) : rw.start + k;      // (4: every tile reads the same 4096 pixels -- what the loads' latency costs)
                 sx.own = (r >= R) && (r < R + (i1 - i0)) && (x >= 0) && (x < span);
                 if (PASS != 1 || sx.own) {
                     sx.ok = true; sx.ti = r + 1; sx.x = x;
@@ -818,7 +818,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     };
     if (BFGX_K2LEAN_U == 2) {
         // two window pixels per lane and trip: the four loads are in flight before either pixel is evaluated
-        for (int idx = tid; idx < NR * LWs; idx += 512) {
+        for (int idx = tid; idx < (BFGX_ABLK2 == 3 ? 0 : NR * LWs); idx += 512) {
             const Src a = fetch(idx), b = fetch(idx + 256);
             handle(a);
             handle(b);

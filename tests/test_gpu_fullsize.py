@@ -764,3 +764,56 @@ def test_tile_lists_overflow_into_the_shared_list(gpu, monkeypatch, cap):
     s = sums.cpu().numpy()
     assert np.isclose(s[1], s[0]) and np.isclose(out.sum().item(), hmap.sum())
     small.close(); plan.close()
+
+
+@pytest.mark.parametrize('paint', [False, True])
+def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint):
+    """the fast kernel's two forms -- one 1024-thread workgroup per CU with two tile slots and no barrier between tiles (default from 1024
+    tiles; BFGX_K1_FLUID=2 at plan creation: always), and two 512-thread workgroups per CU with a barrier per tile (=0) -- run the same chunk code in a
+    different order: the same pair census, outputs equal to the last bits of the fp64 LDS sums, whole sphere and band-restricted passes
+    (few tiles per launch: slots without a tile, both draw orders at the end of the sequence), halos on the poles and across phi = 0"""
+    N, nside = 400_000, 512
+    monkeypatch.setenv('BFGX_K1_FLUID', '2')
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=paint)
+    cat['dec'][:4] = [90.0 - 1e-7, -90.0 + 1e-7, 89.9, 0.0]
+    cat['ra'][:4] = [0.0, 77.0, 359.9999, 1e-9]
+    npix = 12 * nside * nside
+    cd, keep1 = _cat_dev(torch, _lib, dev, cat)
+    from baryonification_amd import engine
+    monkeypatch.setenv('BFGX_K1_FLUID', '0')
+    model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, 10.0, 10.0, log_values=paint)
+    barrier = engine.ShellPlan(model, keep, nside, N, 0, torch.cuda.current_stream().cuda_stream)
+    monkeypatch.delenv('BFGX_K1_FLUID')
+
+    def full(pl):
+        out = torch.zeros(npix * (1 if paint else 3), dtype=torch.float64 if paint else torch.float32, device=dev)
+        if paint:
+            pl.paint(cd, out.data_ptr(), acc_f64=2)                # fp32 pair math into the fp64 map
+        else:
+            pl.offsets(cd, out.data_ptr(), False)
+        torch.cuda.synchronize()
+        pl.status()
+        return out
+
+    a, b = full(plan), full(barrier)
+    scale = a.abs().max().item()
+    assert scale > 0 and (a - b).abs().max().item() <= (1e-13 if paint else 2e-7) * scale
+    assert plan.count_pairs(cd, not paint) == barrier.count_pairs(cd, not paint) > 4e6
+    # band-restricted passes: 1, 2, 3 and 7 bands of 32 rings (a handful of tiles up to a few hundred per launch)
+    bounds = plan.bands()
+    nb = len(bounds) - 1
+    comp = 1 if paint else 3
+    for b0, b1 in ((0, 1), (nb // 2, nb // 2 + 2), (nb - 3, nb), (5, 12)):
+        p0, p1 = int(bounds[b0]), int(bounds[b1])
+        got = []
+        for pl in (plan, barrier):
+            sl = torch.full(((p1 - p0) * comp,), 7.0, dtype=a.dtype, device=dev)
+            if paint:
+                pl.paint_bands(cd, b0, b1, sl.data_ptr(), acc_f64=2)
+            else:
+                pl.offsets_bands(cd, b0, b1, sl.data_ptr(), False)
+            torch.cuda.synchronize()
+            pl.status()
+            got.append(sl)
+        assert (got[0] - got[1]).abs().max().item() <= (1e-13 if paint else 2e-7) * scale
+    plan.close(); barrier.close()
