@@ -568,12 +568,13 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             int64_t st, nr64; bool shf_;
             ring_info_small(h, ring, st, nr64, shf_);
             ring_z_sth(h, ring, rw.z, rw.sth);
-            rw.theta = atan2_generic(rw.sth, rw.z);
+            rw.theta = (BFGX_ABLK2 == 5) ? kHalfPi - rw.z : atan2_generic(rw.sth, rw.z);        // (5: timing only -- what the tables' trigonometry costs)
             rw.start = st; rw.nr = (int)nr64; rw.shf = shf_ ? 1 : 0;
             rw.dphi = kTwoPi / (double)rw.nr;
             rw.inv_dphi = (double)rw.nr * kInvTwoPi;
             rw.ks = tile_ks(tj, rw.nr, nphi);
             rw.ke = tile_ks(tj + 1, rw.nr, nphi);
+            if (BFGX_ABLK2 == 5) { rw.s0 = 0.0; rw.c0 = 1.0; } else
             sincos_bounded(((double)rw.ks + (shf_ ? 0.5 : 0.0)) * rw.dphi, rw.s0, rw.c0);
             // gathered <=> |o|^2 < lim2
             const double lim = fmin(fmin(reach.cap, 0.09 * rw.sth), 0.999 * fmin(rw.theta - reach.theta_first, reach.theta_last - rw.theta));
