@@ -450,7 +450,7 @@ static int ensure_entry_capacity(bfgx_plan *p, const bfgx_catalog *c)
     HIP_TRY(hipMemcpyAsync(&ov, p->overflow, sizeof(ov), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(&total, p->tile_start + p->tiling.ntiles, sizeof(total), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (!ov) return BFGX_OK;
+    if (!(ov & 1)) return BFGX_OK;             // (bit 2: the fluid kernel gave up -- bfgx_plan_status reports it)
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, sizeof(int32_t) * ((size_t)total + 16)));
     p->owned.push_back(d);                       // the old list is released with the plan
@@ -802,6 +802,12 @@ int bfgx_plan_status(bfgx_plan *p)
     int32_t ov = 0;
     HIP_TRY(hipMemcpyAsync(&ov, p->overflow, sizeof(ov), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (ov & 4) {
+        // the fluid form of the fast kernel: a wave waited 2^22 sleeps for a tile slot / a flush / a staged tile of its own workgroup and
+        // left (the grid drained); never seen outside fault injection
+        HIP_TRY(hipMemsetAsync(p->overflow, 0, sizeof(int32_t), p->stream));
+        return fail(BFGX_ERR_HIP, "tile_scatter2f_kernel: a wave gave up waiting inside its workgroup; results are incomplete (BFGX_K1_FLUID=0 selects the other form)");
+    }
     if (ov) return fail(BFGX_ERR_INVALID, "halo->tile entry list overflowed its capacity (%lld); results are incomplete",
                         (long long)p->capacity);
     int32_t fov = 0;
