@@ -621,6 +621,9 @@ constexpr int kWF = 16;               // waves per workgroup of the fluid kernel
 #define BFGX_CHUNKB 2
 #endif
 constexpr int kChunkB = BFGX_CHUNKB;  // entries per chunk of region B
+#ifndef BFGX_K1F_SLEEP
+#define BFGX_K1F_SLEEP 2              // s_sleep argument (x 64 clocks) of a wave that polls for its next tile slot
+#endif
 #ifndef BFGX_K1F_PROF
 #define BFGX_K1F_PROF 0              // 1: shader-clock accounting of the fluid kernel's waves (variant builds only: scripts/k1f_prof.py)
 #endif
@@ -864,7 +867,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             int spins = 0;
             while (__hip_atomic_load(&S.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) {
                 if (__hip_atomic_load(&S.flushing, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 1) flush_groups(s, ((k >> 1) & 1) ^ 1);
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(BFGX_K1F_SLEEP);
                 if (++spins > (1 << 22)) {
                     if (lane == 0) atomicOr(err, 4);
                     return;

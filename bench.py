@@ -1100,10 +1100,12 @@ def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None):
     table = table or args.table
     dom = force or ('paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0))
     real = 'double' if args.acc_f64 else 'float'
-    names = {"offsets": ("tile_scatter2_kernel<OFFSETS, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
+    # (fp32 pair math: the fluid form, one 1024-thread workgroup per CU with two tile slots; fp64 throughout: the barrier-per-tile form)
+    k1 = "tile_scatter2f_kernel" if real == 'float' and 12 * args.nside ** 2 >= 4 * 256 * 2048 else "tile_scatter2_kernel"
+    names = {"offsets": ("%s<OFFSETS, %s>" % (k1, real)) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
              # (<.., 0>: the lean gather, reach of one ring; <.., 2>: the walking kernel -- every tile on the S19 table)
              "regrid": ("tile_regrid3_kernel<%s, %s, %d>" % (real, real, 2 if table == 's19' else 0)) if args.algo == 1 else "regrid_kernel",
-             "paint": ("tile_scatter2_kernel<PAINT, double, %s>" % real) if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
+             "paint": ("%s<PAINT, double, %s>" % (k1, real)) if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
     ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
     traffic = valu = src = None
     if not args.acc_f64 and args.algo == 1:
@@ -1124,7 +1126,8 @@ def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None):
         return r
     r["note"] = ("tile-owned LDS accumulation, no global atomics, every output element stored once: the algorithmic HBM traffic is 12 B per "
                  "(halo, pixel) pair against ~115 vector instructions per pair (fp32 pair math; the fp64 ring-row phase adds ~350 per 64 rows), so the "
-                 "kernel sits below the HBM roof and is bounded by vector issue + latency at 4 waves/SIMD (DESIGN.md section 4)") if args.algo == 1 else \
+                 "kernel sits below the HBM roof and is bounded by vector issue + latency at 4 waves/SIMD; since round 4 (fluid form) no wave waits "
+                 "at a barrier between tiles: 74 % of a wave's time is chunk work, 17 % waiting for a tile slot (DESIGN.md section 4)") if args.algo == 1 else \
                 ("scatter-add path: the applicable ceiling for the atomic share is ~1300 GB/s (gfx950 memory-side float atomics), not the 8 TB/s stream peak")
     return r
 

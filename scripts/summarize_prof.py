@@ -18,7 +18,7 @@ def short(name):
             ('deposit_count_kernel', 'deposit_count'), ('deposit_tiles_kernel', 'deposit_tiles'), ('fft_c2c_strided_kernel<true', 'fft_c2c_strided+pk_bins'),
             ('fft_c2c_strided_kernel', 'fft_c2c_strided'),
             ('fft_r2c_lines_kernel', 'fft_r2c_lines'), ('pk_bin_kernel', 'pk_bin'),
-            ('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
+            ('tile_scatter2f_kernel', 'tile_scatter2'), ('tile_scatter2_kernel', 'tile_scatter2'), ('tile_scatter_kernel', 'tile_scatter(generic)'), ('tile_regrid3_kernel', 'tile_regrid3'),
             ('halo_prep_kernel', 'halo_prep'), ('halo_scatter_kernel', 'halo_scatter'), ('regrid_far_kernel', 'regrid_far'),
             ('regrid_kernel', 'regrid(algo0)'), ('sum2_kernel', 'sum2'), ('sum_tiles_kernel', 'sum_tiles'), ('tile_scan_kernel', 'tile_scan'),
             ('tile_place_kernel', 'tile_place'), ('tile_reach_kernel', 'tile_reach'), ('tile_apron_kernel', 'tile_apron'))

@@ -17,7 +17,8 @@ python3 - "$OUT" "$TAG" $((W + K)) "$*" <<'PY' | tee gpurun_out/traffic_$TAG.jso
 import csv, glob, json, sys, collections
 out, tag, nsteps, args = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 # bench.py kernel_ms key <- kernel name fragments (the groups bench.py times between one pair of events)
-GROUPS = {'offsets': ['tile_scatter2_kernel<0', 'tile_scatter2_kernel<(int)0', 'grid_gather_regrid_kernel'], 'paint': ['tile_scatter2_kernel<1', 'tile_scatter2_kernel<(int)1'],
+GROUPS = {'offsets': ['tile_scatter2_kernel<0', 'tile_scatter2_kernel<(int)0', 'tile_scatter2f_kernel<0', 'tile_scatter2f_kernel<(int)0', 'grid_gather_regrid_kernel'],
+          'paint': ['tile_scatter2_kernel<1', 'tile_scatter2_kernel<(int)1', 'tile_scatter2f_kernel<1', 'tile_scatter2f_kernel<(int)1'],
           'regrid': ['tile_regrid3_kernel', 'grid_copy_sum_kernel'], 'prep': ['halo_prep_kernel', 'grid_prep_kernel'],
           'deposit': ['deposit_keys', 'deposit_split', 'deposit_count', 'deposit_tiles', 'deposit_scan', 'deposit_atomic'],
           'pk': ['fft_r2c_lines', 'fft_c2c_strided'], 'displace': ['snap_displace_kernel']}
