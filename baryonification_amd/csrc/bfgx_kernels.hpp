@@ -527,6 +527,39 @@ struct Tab8T {
     int32_t nr, _pad;
 };
 
+// One slot per active lane in the list of its tile, with ONE returning atomic per run of consecutive lanes that name the same tile (the run's
+// first lane adds the run's length, the others take base + their place in the run).  A catalog in random order has runs of one lane, and the
+// cost is a dozen instructions; a catalog written patch by patch -- lightcone catalogs usually are -- has runs of tens of lanes, and without
+// this its halos add to ONE counter back to back: same-address atomics serialise at ~5 ns each (K0 0.13 -> 0.62 ms measured on a catalog in
+// (band, azimuth) order).  The counters of region A are kCntPad words apart for the same reason: atomics to one 64-byte LINE serialise too, and
+// a patch-ordered catalog keeps the ~1000 waves that run together on the ~25 lines of neighbouring tiles (0.25 ms with runs alone).  Every lane of the wave must call (shuffles); lanes with active == false get 0.
+// (in two halves, so that the atomic's latency overlaps whatever the caller computes in between: wave_run_issue returns what the run's first
+// lane got from the atomic -- not yet valid in the other lanes --, wave_run_resolve, called by every lane again, hands it round)
+constexpr int kCntPad = 32;           // words between the region-A counters of two tiles in the padded array (a 128-byte line each)
+struct RunSlot { int base, head, rank; };
+__device__ inline RunSlot wave_run_issue(int32_t *cnt, int tile, bool active)
+{
+    RunSlot r;
+    r.base = 0; r.head = 0; r.rank = 0;
+    if (__ballot(active) == 0ull) return r;                            // (wave-uniform)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int key = active ? tile : -1 - lane;                         // (an inactive lane is a run of its own, and does nothing)
+    const int prev = __shfl_up(key, 1, kWave);
+    const bool head = (lane == 0) || (key != prev);
+    const unsigned long long hm = __ballot(head);
+    r.head = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));                // first lane of this lane's run
+    const unsigned long long up = (lane == kWave - 1) ? 0ull : (hm >> (lane + 1));
+    const int next = up ? lane + __ffsll((long long)up) : kWave;                    // first lane of the next run
+    r.rank = active ? lane - r.head : -1;
+    if (head && active) r.base = (BFGX_ABL0 & 8) ? (tile & 1023) : atomicAdd(cnt + tile, next - lane);       // (8: timing only)
+    return r;
+}
+__device__ inline int wave_run_resolve(const RunSlot &r)
+{
+    const int b = __shfl(r.base, r.head, kWave);
+    return r.rank >= 0 ? b + r.rank : 0;
+}
+
 // ---------------------------------------------------------------------------------- K0
 // where K0 writes (device pointers; nullptr = not wanted)
 struct PrepOut {
@@ -552,7 +585,7 @@ struct PrepOut {
 // record.  `real` = precision of the fast kernel's pair records.  lnz1 / lnM (optional): ln(1 + z), ln M computed by the
 // caller (numpy on the host), so that halos on a table edge are classified exactly as the reference does (README.md:78-80).
 template <int NC, typename real>
-__device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, const double *gz, const double *gm,
+__device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, bool live, const double *gz, const double *gm,
                                               const double *__restrict__ M, const double *__restrict__ z,
                                               const double *__restrict__ ra, const double *__restrict__ dec,
                                               const double *__restrict__ ex0, const double *__restrict__ ex1,
@@ -560,7 +593,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
                                               int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow);
 
 template <int NC, typename real>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ M, const double *__restrict__ z,
                  const double *__restrict__ ra, const double *__restrict__ dec,
@@ -592,7 +625,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     }
     __syncthreads();                                       // (s_nslow)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nhalo) halo_prep_one<NC, real>(m, h, j, gz, gm, M, z, ra, dec, ex0, ex1, lnz1, lnM, fallback4, T, o, &s_nslow);
+    // (every lane runs it -- the binning shuffles across the wave --, the lanes beyond the catalog on its last halo and without any store)
+    halo_prep_one<NC, real>(m, h, j < nhalo ? j : nhalo - 1, j < nhalo, gz, gm, M, z, ra, dec, ex0, ex1, lnz1, lnM, fallback4, T, o, &s_nslow);
     if (o.slow_cnt) {
         __syncthreads();
         if (threadIdx.x == 0) o.slow_cnt[blockIdx.x] = s_nslow;
@@ -600,7 +634,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
 }
 
 template <int NC, typename real>
-__device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, const double *gz, const double *gm,
+__device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, bool live, const double *gz, const double *gm,
                                               const double *__restrict__ M, const double *__restrict__ z,
                                               const double *__restrict__ ra, const double *__restrict__ dec,
                                               const double *__restrict__ ex0, const double *__restrict__ ex1,
@@ -646,7 +680,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     double sr_ = 0.0;
     // a halo with a non-finite / non-positive disc radius or position can touch no pixel: give it an empty row range
     // (this also keeps every ring index below in range whatever the input columns hold)
-    const bool bad = !(radius > 0.0) || !isfinite(radius) || !(theta >= 0.0) || !(theta <= kPi) || !isfinite(phi);
+    const bool bad = !live || !(radius > 0.0) || !isfinite(radius) || !(theta >= 0.0) || !(theta <= kPi) || !isfinite(phi);
     if (bad) {
         r.cosr = 1.0; r.irmin = 1; r.irmax = 0; r.rfirst = 1; r.rlast = 0;
         r.z0 = 1.0; r.s0 = 0.0; r.xa = 1.0; r.phi0 = 0.0; r.cph0 = 1.0; r.sph0 = 0.0;
@@ -709,6 +743,8 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     // stores, so that the returning atomics (the longest latency of this kernel) are in flight while the rest is computed;
     // the TileRef that holds the slots is stored last.
     TileRef ref;
+    RunSlot run[kRefMax];
+    for (int i = 0; i < kRefMax; ++i) { run[i].base = 0; run[i].head = 0; run[i].rank = -1; }
     ref.n = 0; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
     for (int i = 0; i < kRefMax; ++i) { ref.few.tile[i] = 0; ref.few.slot[i] = 0; }
     if (o.tref && !(BFGX_ABL0 & 2)) {
@@ -719,17 +755,17 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
         int nt = 0;
         if (cls != kClsNone) for_each_tile(h, T, ds, [&](int t) { if (nt < kRefMax) tl[nt] = t; ++nt; });
         ref.n = nt; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
+        // narrow halos over at most kRefMax tiles take their slots now (returning atomics, one per run of lanes that name the same tile; the
+        // halo index is stored into the slot at the end of this function, when the atomic has long returned) -- every lane of the wave goes
+        // through wave_run_slot; wide ones are placed by cursor after the scan
+#pragma unroll
+        for (int i = 0; i < kRefMax; ++i) {
+            run[i] = wave_run_issue(o.cnt_a, o.entries_a ? tl[i] * kCntPad : tl[i], nt <= kRefMax && i < nt && cls == kClsNarrow);
+            if (nt <= kRefMax) { ref.few.tile[i] = (i < nt) ? tl[i] : 0; ref.few.slot[i] = 0; }
+        }
         if (nt <= kRefMax) {
-            // narrow halos take their slot now (returning atomic; the halo index is stored into the slot at the end of this function, when
-            // the atomic has long returned); wide ones are placed by cursor after the scan
-            for (int i = 0; i < kRefMax; ++i) {
-                ref.few.tile[i] = (i < nt) ? tl[i] : 0;
-                ref.few.slot[i] = 0;
-                if (i < nt) {
-                    if (cls == kClsNarrow) ref.few.slot[i] = atomicAdd(o.cnt_a + tl[i], 1);
-                    else atomicAdd(o.cnt_w + tl[i], 1);
-                }
-            }
+            for (int i = 0; i < kRefMax; ++i)
+                if (i < nt && cls != kClsNarrow) atomicAdd(o.cnt_w + tl[i], 1);
         } else {
             ref.many.rfirst = r.rfirst; ref.many.rlast = r.rlast; ref.many.allphi = r.allphi; ref.many._p = 0;
             ref.many.flo = r.flo; ref.many.fhi = r.fhi;
@@ -753,10 +789,10 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
         for (int c = 0; c < 4; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
         RowSetX rx;
         for (int c = 0; c < kNCmax; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
-        o.rowsx[j] = rx;
+        if (live) o.rowsx[j] = rx;
     }
 
-    if (o.rec && (o.rec_all || cls == kClsWide)) o.rec[j] = r;
+    if (live && o.rec && (o.rec_all || cls == kClsWide)) o.rec[j] = r;
     if (cls == kClsNarrow && !(BFGX_ABL0 & 1)) {
         RowRec rr;
         rr.z0 = r.z0; rr.s0 = r.s0; rr.xa = r.xa; rr.cosr = r.cosr; rr.phi0 = r.phi0;
@@ -797,16 +833,21 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     }
     if (BFGX_ABL0 & 1) { if (r.cosr == 1.2345 && wv[0] == 0.5) o.rowrec[j].z0 = r.lnoff + r.rcut; }      // keep the values alive
     if (o.tref && !(BFGX_ABL0 & 2)) {                          // (the slots were reserved above, see there)
+#pragma unroll
+        for (int i = 0; i < kRefMax; ++i) {
+            const int sl = wave_run_resolve(run[i]);
+            if (ref.n <= kRefMax && ref.cls == kClsNarrow && i < ref.n) ref.few.slot[i] = sl;
+        }
         bool slow = (ref.cls != kClsNone) && (ref.n > kRefMax || ref.cls != kClsNarrow);
         if (ref.cls == kClsNarrow && ref.n <= kRefMax) {
             for (int i = 0; i < kRefMax; ++i) if (i < ref.n) {
                 const int sl = ref.few.slot[i];
-                if (o.entries_a && sl < o.cap_a) o.entries_a[(int64_t)ref.few.tile[i] * o.cap_a + sl] = (int32_t)j;
+                if (o.entries_a && sl < o.cap_a) { if (!(BFGX_ABL0 & 16)) o.entries_a[(int64_t)ref.few.tile[i] * o.cap_a + sl] = (int32_t)j; }
                 else if (o.entries_a) { ref.few.slot[i] = -1; atomicAdd(o.cnt_b + ref.few.tile[i], 1); slow = true; }      // the tile's fixed list is full: region B
                 else slow = true;                                                                                         // (no direct placement: every halo is listed)
             }
         }
-        if (slow || !o.slow_list) o.tref[j] = ref;
+        if (live && (slow || !o.slow_list)) o.tref[j] = ref;
         if (slow && o.slow_list) o.slow_list[(int64_t)blockIdx.x * 256 + atomicAdd(s_nslow, 1)] = (int32_t)j;
     }
 }

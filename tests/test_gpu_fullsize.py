@@ -817,3 +817,36 @@ def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint):
             got.append(sl)
         assert (got[0] - got[1]).abs().max().item() <= (1e-13 if paint else 2e-7) * scale
     plan.close(); barrier.close()
+
+
+def test_catalog_written_patch_by_patch_equals_shuffled(gpu):
+    """a catalog in (band of rings, azimuth) order -- what a lightcone pipeline usually writes -- makes consecutive threads of K0 name the
+    same tile: they take their slots with one atomic per run of lanes (wave_run_issue), on counters a cache line apart.  Same census, same
+    pix_offsets (to the last bits of the fp64 sums), same map as the same halos in shuffled order; full size, both accumulator types."""
+    N, nside = 1_000_000, 1024
+    torch, _lib, syn, cat, axes, table, plan, dev = _setup(N, nside, paint=False)
+    npix = 12 * nside * nside
+    zc = np.sin(np.radians(cat['dec']))
+    ring = np.where(np.abs(zc) <= 2 / 3, nside * (2 - 1.5 * zc), np.where(zc > 0, nside * np.sqrt(3 * (1 - np.abs(zc))), 4 * nside - nside * np.sqrt(3 * (1 - np.abs(zc)))))
+    order = np.argsort((ring.astype(np.int64) // 32) * 4096 + (cat['ra'] / 360.0 * 4096).astype(np.int64), kind='stable')
+    hmap = syn.make_map(nside)
+    d_map = torch.from_numpy(hmap).to(dev)
+    res = []
+    for idx in (None, order):
+        cd, keep1 = _cat_dev(torch, _lib, dev, cat, idx)
+        off64 = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+        plan.offsets(cd, off64.data_ptr(), True)
+        f_off = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+        out = torch.zeros(npix, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.baryonify(cd, d_map.data_ptr(), f_off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
+        torch.cuda.synchronize()
+        plan.status()
+        s = sums.cpu().numpy()
+        assert np.isclose(s[1], s[0])
+        res.append((off64, out, plan.count_pairs(cd, True)))
+    assert res[0][2] == res[1][2] == 53984077
+    scale = res[0][0].abs().max().item()
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-13 * scale
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-6 * hmap.mean()
+    plan.close()
