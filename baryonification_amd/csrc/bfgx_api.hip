@@ -114,7 +114,8 @@ struct bfgx_plan {
     // workgroup for the placement pass; tile_zeros: ntiles zeros (the shared entry list holds only the regions [B | wide] of a tile)
     int32_t *entries_a = nullptr, *slow_list = nullptr, *slow_cnt = nullptr, *tile_zeros = nullptr;
     int32_t entries_a_cap = 0;
-    int32_t *tile_count_pad = nullptr;      // region A's counters, one per 128-byte line (kCntPad words apart): see wave_run_issue
+    int32_t *tile_count_pad = nullptr;      // region A's counters, cnt_pad words apart (a 128-byte line each up to 8192 tiles): see wave_run_issue
+    int32_t cnt_pad = 1;
     TileRef *tref = nullptr;
     FarList far;                     // deposits of the gathering regrid that need the generic route (bfgx_regrid2.hpp)
     int32_t *far_overflow_full = nullptr;   // full-map regrid: overflow of the list is repaired in-stream (pass 1), not an error
@@ -291,7 +292,8 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
     o.rowrec = p->rowrec; o.pairrec = p->pairrec; o.fbrec = p->fbrec;
     if (bin) {
         o.tref = p->tref; o.cnt_a = p->tile_count; o.cnt_b = p->tile_count_b; o.cnt_w = p->tile_count_w;
-        if (o.fast && p->entries_a) o.cnt_a = p->tile_count_pad;          // (direct placement: the padded counters, kCntPad words apart)
+        if (o.fast && p->entries_a) o.cnt_a = p->tile_count_pad;          // (direct placement: the padded counters, cnt_pad words apart)
+        o.cnt_pad = p->cnt_pad;
         o.entries_a = o.fast ? p->entries_a : nullptr; o.cap_a = p->entries_a_cap; o.slow_list = p->slow_list; o.slow_cnt = p->slow_cnt;
     }
     o.ncell_m = p->model.tab.n[1] - 1; o.nrm1 = p->model.tab.n[2] - 1;
@@ -324,7 +326,7 @@ static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback
     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel, largest |offset|^2 per tile, and the
     // four control words of the regrid's far list behind them (entries, overflow, tiles left to the walking kernel)
     // (in front of them, in the same allocation: region A's counters padded to a line each)
-    HIP_TRY(hipMemsetAsync(p->tile_count_pad, 0, sizeof(int32_t) * (nt * kCntPad + (((size_t)7 * (nt + 1) + 3) & ~(size_t)3) + 4), p->stream));
+    HIP_TRY(hipMemsetAsync(p->tile_count_pad, 0, sizeof(int32_t) * (nt * (size_t)p->cnt_pad + (((size_t)7 * (nt + 1) + 3) & ~(size_t)3) + 4), p->stream));
     if (int rc = launch_prep(p, c, fallback4, true, f64, false)) return rc;
     KernelTimer kt(p, BFGX_K_BIN);
     const int nt_i = p->tiling.ntiles, nsb = (nt_i + kScanTilesPerWg - 1) / kScanTilesPerWg;
@@ -406,7 +408,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
             hipLaunchKernelGGL(kf, dim3(std::max(gridf, 1)), dim3(kWave * kWF), ldsf, p->stream, tb, p->hpx, p->tiling,
                                (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                                (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
-                               (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, out, tile_counter,
+                               (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, tile_counter,
                                (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
                                p->k1_tile_lo, p->k1_tile_n, p->overflow);
             HIP_TRY(hipGetLastError());
@@ -417,7 +419,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
-                       (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, out, p->pair_total, tile_counter,
+                       (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, p->pair_total, tile_counter,
                        (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
                        p->k1_tile_lo, p->k1_tile_n);
     HIP_TRY(hipGetLastError());
@@ -689,7 +691,10 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         // the binning counters and, right behind them (16-byte aligned), the control words of the regrid's far list: ONE memset per step
         // zeroes both (a length that is not a multiple of 16 bytes, or two buffers, cost a fill kernel each: 4.5 us)
         const size_t n7p = ((size_t)7 * (T.ntiles + 1) + 3) & ~(size_t)3;
-        const size_t npad = (size_t)T.ntiles * kCntPad;
+        // region A's counters: a line each while that array stays below 1 MB (atomics to one line serialise; a larger array costs misses)
+        p->cnt_pad = kCntPadMax;
+        while (p->cnt_pad > 1 && (size_t)T.ntiles * p->cnt_pad * sizeof(int32_t) > ((size_t)1 << 20)) p->cnt_pad >>= 1;
+        const size_t npad = (size_t)T.ntiles * p->cnt_pad;
         if (dalloc(sizeof(int32_t) * (npad + n7p + (size_t)T.ntiles + 8), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
             dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
             dalloc(sizeof(unsigned long long), &d5) || dalloc(sizeof(TileRef) * (size_t)(max_halos > 0 ? max_halos : 1), &d6))

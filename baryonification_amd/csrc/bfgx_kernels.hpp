@@ -531,33 +531,34 @@ struct Tab8T {
 // first lane adds the run's length, the others take base + their place in the run).  A catalog in random order has runs of one lane, and the
 // cost is a dozen instructions; a catalog written patch by patch -- lightcone catalogs usually are -- has runs of tens of lanes, and without
 // this its halos add to ONE counter back to back: same-address atomics serialise at ~5 ns each (K0 0.13 -> 0.62 ms measured on a catalog in
-// (band, azimuth) order).  The counters of region A are kCntPad words apart for the same reason: atomics to one 64-byte LINE serialise too, and
+// (band, azimuth) order).  The counters of region A are cnt_pad words apart (PrepOut) for the same reason: atomics to one 64-byte LINE serialise too, and
 // a patch-ordered catalog keeps the ~1000 waves that run together on the ~25 lines of neighbouring tiles (0.25 ms with runs alone).  Every lane of the wave must call (shuffles); lanes with active == false get 0.
 // (in two halves, so that the atomic's latency overlaps whatever the caller computes in between: wave_run_issue returns what the run's first
 // lane got from the atomic -- not yet valid in the other lanes --, wave_run_resolve, called by every lane again, hands it round)
-constexpr int kCntPad = 32;           // words between the region-A counters of two tiles in the padded array (a 128-byte line each)
-struct RunSlot { int base, head, rank; };
+constexpr int kCntPadMax = 32;        // words between the region-A counters of two tiles in the padded array: a 128-byte line each while the
+                                      // array stays below 1 MB (6208 tiles at NSIDE 1024), fewer for finer shells (bfgx_plan.cnt_pad)
+struct RunSlot { int base, hr; };       // hr: first lane of the run | (place in the run + 1) << 8, 0 in an inactive lane
 __device__ inline RunSlot wave_run_issue(int32_t *cnt, int tile, bool active)
 {
     RunSlot r;
-    r.base = 0; r.head = 0; r.rank = 0;
+    r.base = 0; r.hr = 0;
     if (__ballot(active) == 0ull) return r;                            // (wave-uniform)
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int key = active ? tile : -1 - lane;                         // (an inactive lane is a run of its own, and does nothing)
     const int prev = __shfl_up(key, 1, kWave);
     const bool head = (lane == 0) || (key != prev);
     const unsigned long long hm = __ballot(head);
-    r.head = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));                // first lane of this lane's run
+    const int hl = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));          // first lane of this lane's run
     const unsigned long long up = (lane == kWave - 1) ? 0ull : (hm >> (lane + 1));
     const int next = up ? lane + __ffsll((long long)up) : kWave;                    // first lane of the next run
-    r.rank = active ? lane - r.head : -1;
-    if (head && active) r.base = (BFGX_ABL0 & 8) ? (tile & 1023) : atomicAdd(cnt + tile, next - lane);       // (8: timing only)
+    r.hr = active ? (hl | ((lane - hl + 1) << 8)) : 0;
+    if (head && active) r.base = atomicAdd(cnt + tile, next - lane);
     return r;
 }
 __device__ inline int wave_run_resolve(const RunSlot &r)
 {
-    const int b = __shfl(r.base, r.head, kWave);
-    return r.rank >= 0 ? b + r.rank : 0;
+    const int b = __shfl(r.base, r.hr & 63, kWave);
+    return r.hr ? b + (r.hr >> 8) - 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------- K0
@@ -576,6 +577,7 @@ struct PrepOut {
     // (slow_list[block][256], slow_cnt[block]) for tile_place_kernel, which draws their slots from cursors after the scan.
     int32_t *entries_a, *slow_list, *slow_cnt;
     int32_t cap_a;
+    int32_t cnt_pad;              // words between two tiles' counters in cnt_a when entries_a is set (direct placement)
     int32_t fast;                 // 1: narrow halos are class kClsNarrow (fast kernel), 0: every halo is kClsWide (generic kernel)
     int32_t rec_all;              // 1: HaloRec for every halo (halo-centric algo 0)
     int32_t ncell_m, nrm1;        // (nm - 1), (nr - 1) of the interleaved table
@@ -744,7 +746,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     // the TileRef that holds the slots is stored last.
     TileRef ref;
     RunSlot run[kRefMax];
-    for (int i = 0; i < kRefMax; ++i) { run[i].base = 0; run[i].head = 0; run[i].rank = -1; }
+    for (int i = 0; i < kRefMax; ++i) { run[i].base = 0; run[i].hr = 0; }
     ref.n = 0; ref.cls = cls; ref._pad[0] = ref._pad[1] = 0;
     for (int i = 0; i < kRefMax; ++i) { ref.few.tile[i] = 0; ref.few.slot[i] = 0; }
     if (o.tref && !(BFGX_ABL0 & 2)) {
@@ -760,7 +762,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
         // through wave_run_slot; wide ones are placed by cursor after the scan
 #pragma unroll
         for (int i = 0; i < kRefMax; ++i) {
-            run[i] = wave_run_issue(o.cnt_a, o.entries_a ? tl[i] * kCntPad : tl[i], nt <= kRefMax && i < nt && cls == kClsNarrow);
+            run[i] = wave_run_issue(o.cnt_a, o.entries_a ? tl[i] * o.cnt_pad : tl[i], nt <= kRefMax && i < nt && cls == kClsNarrow);
             if (nt <= kRefMax) { ref.few.tile[i] = (i < nt) ? tl[i] : 0; ref.few.slot[i] = 0; }
         }
         if (nt <= kRefMax) {

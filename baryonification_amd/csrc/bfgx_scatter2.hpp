@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(kWave * kW2, (sizeof(real) == 4 ? 4 : 2))
 tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
-                     const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a,
+                     const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a, int cnt_pad,
                      ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
                      unsigned int *__restrict__ omax2, int tile_lo, int tile_n)
 {
@@ -537,7 +537,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     // the narrow halos of the tile: region A = the tile's fixed-capacity list K0 filled directly (entries_a[tile][cap_a]; without it: the
     // head of the shared list), region B = discs over more than kRefMax tiles and what did not fit A, at tile_start in the shared list
     const int64_t e0 = tile_start[tile];
-    const int na = entries_a ? min(cnt_a[(int64_t)tile * kCntPad], cap_a) : cnt_a[tile];      // (direct placement: padded counters)
+    const int na = entries_a ? min(cnt_a[(int64_t)tile * cnt_pad], cap_a) : cnt_a[tile];      // (direct placement: padded counters)
     const int32_t *ea = entries_a ? entries_a + (int64_t)tile * cap_a : entries + e0;
     const int64_t eb0 = e0 + (entries_a ? 0 : na);
     int64_t nb64 = cnt_b[tile];
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(kWave * kWF, 1)
 tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                       const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                       const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
-                      const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a,
+                      const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a, int cnt_pad,
                       ACC *__restrict__ out, unsigned int *__restrict__ tile_counter, unsigned int *__restrict__ omax2,
                       int tile_lo, int tile_n, int32_t *__restrict__ err)
 {
@@ -704,7 +704,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             d.tj = tile - T.band_tile0[d.band];
             // (the same list arithmetic as tile_scatter2_kernel: region A = the tile's fixed-capacity list, region B in the shared list)
             const int64_t e0 = tile_start[tile];
-            const int na = entries_a ? min(cnt_a[(int64_t)tile * kCntPad], cap_a) : cnt_a[tile];      // (direct placement: padded counters)
+            const int na = entries_a ? min(cnt_a[(int64_t)tile * cnt_pad], cap_a) : cnt_a[tile];      // (direct placement: padded counters)
             d.ea = entries_a ? entries_a + (int64_t)tile * cap_a : entries + e0;
             const int64_t eb0 = e0 + (entries_a ? 0 : na);
             int64_t nb64 = cnt_b[tile];
