@@ -25,6 +25,11 @@ constexpr int kDepChunk = 4096;                   // keys per workgroup in the s
 constexpr int kDepPer = kDepChunk / 256;
 constexpr int kDepTileThreads = 1024;             // 64 KB of LDS per tile: two workgroups per CU, so make them large
 constexpr int kDepEdgesLds = 2049;                // edges staged in LDS up to 2048 cells per axis
+#ifndef BFGX_DEP_PAD
+#define BFGX_DEP_PAD 16
+#endif
+constexpr int kDepPad = BFGX_DEP_PAD;             // words between two tiles' level-2 cursors (a workgroup adds to the ~128 cursors of its bucket, the ~128 workgroups of
+                                                  // that bucket run together: atomics to one cache line serialise)
 constexpr int kDepHist = 2048;                    // LDS histogram entries of a sort pass (buckets a workgroup ranks locally)
 
 struct DepGeom {
@@ -150,7 +155,7 @@ deposit_count_kernel(DepGeom g, const int32_t *__restrict__ nvalid, const uint32
         else atomicAdd(count2 + t, 1);
     }
     __syncthreads();
-    for (int i = tid; i < kDepHist; i += 256) if (hist[i]) atomicAdd(count2 + bmin + i, hist[i]);
+    for (int i = tid; i < kDepHist; i += 256) if (hist[i]) atomicAdd(count2 + bmin + i, hist[i]);        // (padding these like the cursors below: no gain)
 }
 
 // one level of the counting sort (see the header).  n_dev: number of input keys as a device scalar (LEVEL 2: the valid ones).
@@ -215,7 +220,7 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
             if (MASS) smass[slot] = mass_in[(base + q * 256 + tid) * mstride];
         } else if (rank[q] == -2) {                 // bucket beyond the local table (almost empty buckets only)
             const int b = dep_bucket<LEVEL>(g, key[q]);
-            const int64_t dst = (int64_t)start[b] + atomicAdd(cursor + b, 1);
+            const int64_t dst = (int64_t)start[b] + atomicAdd(cursor + (int64_t)b * (LEVEL == 2 ? kDepPad : 1), 1);
             keys_out[dst] = key[q];
             if (MASS) mass_out[dst] = mass_in[base + q * 256 + tid];
         }
@@ -226,7 +231,7 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     for (int e = 0; e < kOwn; ++e) {
         const int i = tid * kOwn + e;
         if (cnt[e]) hist[i] = (LEVEL == 1 ? start[(int64_t)i * gridDim.x + blockIdx.x]          // scanned per-workgroup histogram
-                                           : start[bmin + i] + atomicAdd(cursor + bmin + i, cnt[e])) - lpre[e];
+                                           : start[bmin + i] + atomicAdd(cursor + (int64_t)(bmin + i) * kDepPad, cnt[e])) - lpre[e];
     }
     __syncthreads();
     const int total = part[255];

@@ -204,12 +204,13 @@ snap_halo_fill_kernel(SnapGeom g, int64_t nh, const SnapHaloRec *__restrict__ re
 constexpr int kScanPerBlock = 4 * kTabThreads;
 
 __global__ void __launch_bounds__(kTabThreads)
-scan_blocks_kernel(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out, int32_t *__restrict__ block_sums)
+scan_blocks_kernel(int64_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out, int32_t *__restrict__ block_sums, int in_stride)
 {
+    // in_stride: words between two counts (counters that many workgroups add to sit a cache line apart)
     __shared__ int sh[kTabThreads];
     const int64_t base = (int64_t)blockIdx.x * kScanPerBlock + 4 * (int64_t)threadIdx.x;
     int v[4], s = 0;
-    for (int q = 0; q < 4; ++q) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    for (int q = 0; q < 4; ++q) { v[q] = (base + q < n) ? in[(base + q) * in_stride] : 0; s += v[q]; }
     int tot;
     int pre = block_excl_scan_int(s, sh, tot);
     for (int q = 0; q < 4; ++q) { if (base + q < n) out[base + q] = pre; pre += v[q]; }
