@@ -16,6 +16,9 @@
 #include <stdint.h>
 #include "bfgx_math.hpp"
 
+#ifndef BFGX_ABLPK
+#define BFGX_ABLPK 0                  // 1: timing only -- the last pass keeps its histogram to itself
+#endif
 namespace bfgx {
 
 constexpr int kFftBlock = 256;
@@ -337,7 +340,7 @@ fft_c2c_strided_kernel(double2 *__restrict__ data, int N, int log2n, int nz, int
     if (BIN) {
         __syncthreads();
         for (int i = tid; i < pb.nk; i += NT) {
-            if (BIN == 2) { if (hp[i] != 0.0) atomicAdd(pb.pk_sum + i, hp[i]); }
+            if (BIN == 2) { if (hp[i] != 0.0 && !BFGX_ABLPK) atomicAdd(pb.pk_sum + i, hp[i]); }
             else if (hc[i]) { atomicAdd(pb.pk_sum + i, hp[i]); atomicAdd(pb.k_sum + i, hk[i]); atomicAdd(pb.counts + i, hc[i]); }
         }
     }
