@@ -71,6 +71,27 @@ __device__ inline uint32_t dep_key(const DepGeom &g, int bx, int by, int bz)
 
 constexpr uint32_t kDepNoKey = 0xffffffffu;        // particle outside the edges: dropped (np.histogramdd)
 
+// hist[idx] += 1 for the active lanes of the wave, with ONE LDS atomic per run of consecutive lanes that name the same bin; returns the
+// lane's rank in the bin (the count before its own add; -1 for an inactive lane).  Particles in random order give runs of one lane (and
+// a dozen instructions more than a plain atomic); a snapshot as simulations write it -- ordered along a space-filling curve -- gives
+// whole waves one bin, which as 64 same-address LDS atomics cost the sort passes 70 - 130 us each.  Every lane must call.
+__device__ inline int lds_hist_rank(int *hist, int idx, bool active)
+{
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int key = active ? idx : -1 - lane;
+    const int prev = __shfl_up(key, 1, kWave);
+    const bool head = (lane == 0) || (key != prev);
+    const unsigned long long hm = __ballot(head);
+    if (__popcll(hm) > 40) return active ? atomicAdd(hist + idx, 1) : -1;          // (wave-uniform) hardly any runs: one atomic per lane as before
+    const int hl = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));
+    const unsigned long long up = (lane == kWave - 1) ? 0ull : (hm >> (lane + 1));
+    const int next = up ? lane + __ffsll((long long)up) : kWave;
+    int base = 0;
+    if (head && active) base = atomicAdd(hist + idx, next - lane);
+    base = __shfl(base, hl, kWave);
+    return active ? base + (lane - hl) : -1;
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(256)
 deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
@@ -102,17 +123,16 @@ deposit_keys_kernel(DepGeom g, int64_t n, const double *__restrict__ x, const do
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) {
                 const int64_t p = base + (q0 + q) * 256 + tid;
-                if (p >= n) continue;
+                const bool on = p < n;
                 int bx = histogram_bin(e, g.nb, vx[q], scale);
                 const int by = histogram_bin(e, g.nb, vy[q], scale);
                 const int bz = (DIM == 3) ? histogram_bin(e, g.nb, vz[q], scale) : 0;
                 uint32_t key = kDepNoKey;
                 bx = (bx >= g.plane_lo && bx < g.plane_lo + g.plane_n) ? bx - g.plane_lo : -1;
-                if (bx >= 0 && by >= 0 && bz >= 0) {
-                    key = dep_key(g, bx, by, bz);
-                    atomicAdd(hist + (int)((key >> kDepLocalBits) >> g.lB2), 1);
-                }
-                keys[p] = key;
+                const bool inside = on && bx >= 0 && by >= 0 && bz >= 0;
+                if (inside) key = dep_key(g, bx, by, bz);
+                lds_hist_rank(hist, (int)((key >> kDepLocalBits) >> g.lB2), inside);
+                if (on) keys[p] = key;
             }
         }
     };
@@ -149,10 +169,11 @@ deposit_count_kernel(DepGeom g, const int32_t *__restrict__ nvalid, const uint32
 #pragma unroll 4
     for (int q = 0; q < kDepPer; ++q) {
         const int64_t p = base + q * 256 + tid;
-        if (p >= n) break;
-        const int t = (int)(keys[p] >> kDepLocalBits), l = t - bmin;
-        if (l >= 0 && l < kDepHist) atomicAdd(hist + l, 1);
-        else atomicAdd(count2 + t, 1);
+        const bool on = p < n;
+        const int t = on ? (int)(keys[p] >> kDepLocalBits) : 0, l = t - bmin;
+        const bool local = on && l >= 0 && l < kDepHist;
+        lds_hist_rank(hist, l, local);
+        if (on && !local) atomicAdd(count2 + t, 1);
     }
     __syncthreads();
     for (int i = tid; i < kDepHist; i += 256) if (hist[i]) atomicAdd(count2 + bmin + i, hist[i]);        // (padding these like the cursors below: no gain)
@@ -186,11 +207,10 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     for (int q = 0; q < kDepPer; ++q) {
         const int64_t p = base + q * 256 + tid;
         key[q] = (p < n) ? keys_in[p] : kDepNoKey;
-        rank[q] = -1;
-        if (key[q] != kDepNoKey) {
-            const int l = dep_bucket<LEVEL>(g, key[q]) - bmin;
-            rank[q] = (l >= 0 && l < kDepHist) ? atomicAdd(hist + l, 1) : -2;
-        }
+        const int l = (key[q] != kDepNoKey) ? dep_bucket<LEVEL>(g, key[q]) - bmin : -1;
+        const bool local = l >= 0 && l < kDepHist;
+        rank[q] = lds_hist_rank(hist, l, local);                       // (-1: no key)
+        if (key[q] != kDepNoKey && !local) rank[q] = -2;
     }
     __syncthreads();
     // exclusive scan of the counts: thread t owns entries [8 t, 8 t + 8)
