@@ -344,7 +344,7 @@ def main_grid(args):
         elapsed = float(te.item())
     ev_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in lst])) for k, lst in ev.items() if lst}      # (the timed region's events)
     sorted_companion = None
-    if snapshot and not args.sorted_particles:
+    if snapshot and not args.sorted_particles and not args.no_extras:
         # the same flow on the same particles in the order snapshot files stored along a space-filling curve have (raster order of 64^3
         # coarse cells): the displacement's look-ups then fall into lines the neighbouring lanes touch too.  BaryonifySnapshot returns the
         # particles in the caller's order, so this costs the caller nothing but is not something the library may do to unsorted input.
