@@ -397,7 +397,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     unsigned int *tile_counter = (unsigned int *)(p->tile_count + 5 * ((size_t)p->tiling.ntiles + 1));
     const int ntodo = p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
-    if constexpr (sizeof(real) == 4 && MODE != MODE_COUNT) {
+    if constexpr (MODE != MODE_COUNT) {
         // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 at plan creation keeps the other
         const size_t ldsf = tile2f_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
         // (shells of a few hundred tiles -- NSIDE <= 256 -- keep the other form: half as many workgroups cannot balance so few tiles)
@@ -405,7 +405,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
             auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
             HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             const int gridf = std::min(ntodo, p->num_cus);
-            hipLaunchKernelGGL(kf, dim3(std::max(gridf, 1)), dim3(kWave * kWF), ldsf, p->stream, tb, p->hpx, p->tiling,
+            hipLaunchKernelGGL(kf, dim3(std::max(gridf, 1)), dim3(kWave * FluidWaves<real>::n), ldsf, p->stream, tb, p->hpx, p->tiling,
                                (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                                (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
                                (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, tile_counter,

@@ -616,7 +616,9 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 // table and descriptor in the slot it has just emptied and publishes the slot's sequence number; a wave that reaches tile k + 2
 // earlier than that sleeps on the number.  Waits are bounded: a wave that has slept 2^22 times raises *err and leaves, so the grid
 // always drains.
-constexpr int kWF = 16;               // waves per workgroup of the fluid kernel
+// waves per workgroup of the fluid kernel: sixteen (four per SIMD at <= 128 VGPRs) for fp32 pair math; twelve for fp64 pair math, whose waves need
+// ~155 VGPRs and 4.5 KB of LDS each: three per SIMD, against two for the barrier form (one 8-wave workgroup per CU: its LDS does not fit twice)
+template <typename real> struct FluidWaves { static constexpr int n = sizeof(real) == 4 ? 16 : 12; };
 #ifndef BFGX_CHUNKB
 #define BFGX_CHUNKB 2
 #endif
@@ -655,11 +657,11 @@ __host__ __device__ inline size_t tile2f_lds_bytes(int BR, int W, int ncomp)
 {
     size_t a = (size_t)ncomp * ((size_t)BR * W + kPlanePad) * sizeof(double);
     a = (a + 15) & ~(size_t)15;
-    return 2 * a + sizeof(Wave2Lds<real>) * kWF + 2 * sizeof(FluidSlot) + 4 * (sizeof(TileRow) + sizeof(RingC2<real>)) * (size_t)BR;
+    return 2 * a + sizeof(Wave2Lds<real>) * FluidWaves<real>::n + 2 * sizeof(FluidSlot) + 4 * (sizeof(TileRow) + sizeof(RingC2<real>)) * (size_t)BR;
 }
 
 template <int MODE, typename ACC, typename real>
-__global__ void __launch_bounds__(kWave * kWF, 1)
+__global__ void __launch_bounds__(kWave * FluidWaves<real>::n, 1)
 tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                       const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                       const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
@@ -668,6 +670,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
                       int tile_lo, int tile_n, int32_t *__restrict__ err)
 {
     static_assert(MODE == MODE_OFFSETS || MODE == MODE_PAINT, "the census runs in tile_scatter2_kernel");
+    constexpr int kWF = FluidWaves<real>::n;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
     const int PL = T.BR * T.W + kPlanePad;

@@ -766,11 +766,12 @@ def test_tile_lists_overflow_into_the_shared_list(gpu, monkeypatch, cap):
     small.close(); plan.close()
 
 
+@pytest.mark.parametrize('f64', [False, True])
 @pytest.mark.parametrize('paint', [False, True])
-def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint):
+def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint, f64):
     """the fast kernel's two forms -- one 1024-thread workgroup per CU with two tile slots and no barrier between tiles (default from 1024
     tiles; BFGX_K1_FLUID=2 at plan creation: always), and two 512-thread workgroups per CU with a barrier per tile (=0) -- run the same chunk code in a
-    different order: the same pair census, outputs equal to the last bits of the fp64 LDS sums, whole sphere and band-restricted passes
+    different order (fp64 pair math: twelve waves per workgroup): the same pair census, outputs equal to the last bits of the fp64 LDS sums, whole sphere and band-restricted passes
     (few tiles per launch: slots without a tile, both draw orders at the end of the sequence), halos on the poles and across phi = 0"""
     N, nside = 400_000, 512
     monkeypatch.setenv('BFGX_K1_FLUID', '2')
@@ -786,18 +787,19 @@ def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint):
     monkeypatch.delenv('BFGX_K1_FLUID')
 
     def full(pl):
-        out = torch.zeros(npix * (1 if paint else 3), dtype=torch.float64 if paint else torch.float32, device=dev)
+        out = torch.zeros(npix * (1 if paint else 3), dtype=torch.float64 if (paint or f64) else torch.float32, device=dev)
         if paint:
-            pl.paint(cd, out.data_ptr(), acc_f64=2)                # fp32 pair math into the fp64 map
+            pl.paint(cd, out.data_ptr(), acc_f64=(1 if f64 else 2))    # 2: fp32 pair math into the fp64 map
         else:
-            pl.offsets(cd, out.data_ptr(), False)
+            pl.offsets(cd, out.data_ptr(), f64)
         torch.cuda.synchronize()
         pl.status()
         return out
 
     a, b = full(plan), full(barrier)
     scale = a.abs().max().item()
-    assert scale > 0 and (a - b).abs().max().item() <= (1e-13 if paint else 2e-7) * scale
+    tol = 1e-13 if (paint or f64) else 2e-7
+    assert scale > 0 and (a - b).abs().max().item() <= tol * scale
     assert plan.count_pairs(cd, not paint) == barrier.count_pairs(cd, not paint) > 4e6
     # band-restricted passes: 1, 2, 3 and 7 bands of 32 rings (a handful of tiles up to a few hundred per launch)
     bounds = plan.bands()
@@ -809,13 +811,13 @@ def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint):
         for pl in (plan, barrier):
             sl = torch.full(((p1 - p0) * comp,), 7.0, dtype=a.dtype, device=dev)
             if paint:
-                pl.paint_bands(cd, b0, b1, sl.data_ptr(), acc_f64=2)
+                pl.paint_bands(cd, b0, b1, sl.data_ptr(), acc_f64=(1 if f64 else 2))
             else:
-                pl.offsets_bands(cd, b0, b1, sl.data_ptr(), False)
+                pl.offsets_bands(cd, b0, b1, sl.data_ptr(), f64)
             torch.cuda.synchronize()
             pl.status()
             got.append(sl)
-        assert (got[0] - got[1]).abs().max().item() <= (1e-13 if paint else 2e-7) * scale
+        assert (got[0] - got[1]).abs().max().item() <= tol * scale
     plan.close(); barrier.close()
 
 
