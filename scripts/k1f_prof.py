@@ -11,12 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from baryonification_amd import _lib, engine, synthetic as syn
 dev = torch.device('cuda', 0)
-halos, nside = 1_000_000, 1024
+paint = '--paint' in sys.argv
+halos, nside = 1_000_000, (2048 if paint else 1024)
 cat = syn.make_catalog(halos)
 z, M, r = syn.table_grid(cat)
-table = syn.displacement_table(z, M, r)
+table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
 axes = [np.log(1 + z), np.log(M), np.log(r)]
-model, keep = engine.model_from_tables(axes, table, syn.COSMO, 10.0, 10.0)
+with np.errstate(divide='ignore'):
+    model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, 10.0, 10.0, log_values=paint)
 t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}
 lnz, lnM = _lib.table_coords(cat['M'], cat['z'])
 t['lnz'], t['lnM'] = torch.from_numpy(lnz).to(dev), torch.from_numpy(lnM).to(dev)
@@ -29,14 +31,21 @@ out = torch.zeros(npix, dtype=torch.float64, device=dev)
 sums = torch.zeros(2, dtype=torch.float64, device=dev)
 lib = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_ulonglong * 8)()
+def step():
+    if paint:
+        plan.paint(cd, out.data_ptr(), acc_f64=2)
+    else:
+        plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
+
+
 for it in range(3):
-    plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    step()
 torch.cuda.synchronize()
 lib.bfgx_debug_k1f_prof(buf, 1)
 
 N = 10
 for it in range(N):
-    plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    step()
 torch.cuda.synchronize()
 lib.bfgx_debug_k1f_prof(buf, 1)
 wait, chunk, flush, total, nfl, nw, nchunk, maxsum = [float(x) for x in buf[:8]]
