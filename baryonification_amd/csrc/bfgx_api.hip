@@ -106,7 +106,7 @@ struct bfgx_plan {
     // tile-owned accumulation (algo 1): tiling tables + halo -> tile binning workspace
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
-    int k1_fluid = 1;               // the fast kernel's fluid form (bfgx_scatter2.hpp): 1 = from 4 tiles per CU; BFGX_K1_FLUID at plan creation: 0 = never (the barrier-per-tile form), 2 = always (tests)
+    int k1_fluid = 1;               // the fast kernel's fluid form (bfgx_scatter2.hpp): 1 = from 2 tiles per CU; BFGX_K1_FLUID at plan creation: 0 = never (the barrier-per-tile form), 2 = always (tests)
     Tiling tiling;
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
             *tile_cursor_w = nullptr, *entries = nullptr, *overflow = nullptr;
@@ -400,8 +400,8 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     if constexpr (MODE != MODE_COUNT) {
         // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 at plan creation keeps the other
         const size_t ldsf = tile2f_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
-        // (shells of a few hundred tiles -- NSIDE <= 256 -- keep the other form: half as many workgroups cannot balance so few tiles)
-        if (p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && (ntodo >= 4 * p->num_cus || p->k1_fluid == 2)) {
+        // (fewer than two tiles per CU -- NSIDE <= 256 -- keep the other form: half as many workgroups cannot balance so few tiles; a rank that owns an eighth of the NSIDE-1024 sphere, 776 tiles, is 4 % faster in the fluid form)
+        if (p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && (ntodo >= 2 * p->num_cus || p->k1_fluid == 2)) {
             auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
             HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             const int gridf = std::min(ntodo, p->num_cus);
