@@ -272,7 +272,7 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
 template <int MODE, typename real, int NP>
 __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__restrict__ rowrecs, const PairRecT<real> *__restrict__ pairrecs,
                                          const FbRec *__restrict__ fbrecs, const int32_t *__restrict__ ea, const int32_t *__restrict__ eb,
-                                         int na, int ebeg, int ecnt, int i0, int i1, int nphi, int wsh, int wmask, int PL,
+                                         int na, int ebeg, int ecnt, int estride, int i0, int i1, int nphi, int wsh, int wmask, int PL,
                                          double *acc, Wave2Lds<real> &L, const TileRow *rowtab, const RingC2<real> *ringc, int lane,
                                          unsigned long long &npairs)
 {
@@ -284,7 +284,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
     RowGeo gg;
     gg.z0 = gg.s0 = gg.xa = gg.cosr = gg.phi0 = 0.0;
     if (lane < ecnt) {
-        const int ei = ebeg + lane;
+        const int ei = ebeg + lane * estride;            // (estride > 1: the chunk takes every estride-th entry of region A, see the fluid kernel)
         en.hidx = ei < na ? ea[ei] : eb[ei - na];
         const RowRec &rr = rowrecs[en.hidx];
         if (BFGX_K1_GEO) { gg.z0 = rr.z0; gg.s0 = rr.s0; gg.xa = rr.xa; gg.cosr = rr.cosr; gg.phi0 = rr.phi0; }
@@ -559,7 +559,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         c = __builtin_amdgcn_readfirstlane(c);
         if (c >= nchunks) break;
 
-        k1_chunk<MODE, real, NP>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+        k1_chunk<MODE, real, NP>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), 1, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
                                  lane, npairs);
     }
     __syncthreads();
@@ -909,9 +909,14 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
 #if BFGX_K1F_PROF
             const unsigned long long pf_c0 = PF_NOW();
 #endif
-            const int ebeg = c < nchb ? na + c * kChunkB : (c - nchb) * csz;
-            const int ecnt = c < nchb ? min(kChunkB, ne - ebeg) : min(csz, na - ebeg);
-            k1_chunk<MODE, real, 1>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+            // region A is dealt out INTERLEAVED: chunk j takes the entries j, j + n, j + 2 n, ... (n = the number of chunks), so that whatever
+            // order the catalog came in -- heaviest halos first (a chunk of sixteen heavy ones: K1 + 7 %), patch by patch (sixteen
+            // neighbours adding to the same pixels: + 2 %) -- every chunk is a sample of the whole list
+            const int ncha = nchunks - nchb;
+            const int ebeg = c < nchb ? na + c * kChunkB : c - nchb;
+            const int ecnt = c < nchb ? min(kChunkB, ne - ebeg) : (na - ebeg + ncha - 1) / ncha;
+            const int estride = c < nchb ? 1 : ncha;
+            k1_chunk<MODE, real, 1>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, estride, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
                                     lane, npairs);
 #if BFGX_K1F_PROF
             if (lane == 0) { const unsigned d = (unsigned)(PF_NOW() - pf_c0); atomicMax(&S.pf_maxchunk, d); pf_nchunk += 1; }

@@ -55,8 +55,8 @@ def parse():
                          "along as `value_weak`), 'weak' = --halos per GPU")
     ap.add_argument('--config', type=int, default=0, choices=[0, 4],
                     help='4 = BASELINE config 4: 1e7 halos, NSIDE 2048, BaryonifyShell, strong scaling over the GPUs given (8 in the config)')
-    ap.add_argument('--catalog-order', choices=('shuffled', 'sky'), default='shuffled',
-                    help="order of the halos in the catalog (strong scaling / N = 1): 'shuffled' as Parallelize.py:255, 'sky' = patch by patch")
+    ap.add_argument('--catalog-order', choices=('shuffled', 'sky', 'mass'), default='shuffled',
+                    help="order of the halos in the catalog (strong scaling / N = 1): 'shuffled' as Parallelize.py:255, 'mass' = heaviest first, 'sky' = patch by patch")
     ap.add_argument('--no-extras', action='store_true', help='skip value_acc_f64 and end_to_end (N = 1 only)')
     ap.add_argument('--halos', type=int, default=1_000_000, help='halos per GPU (default: BASELINE config 2)')
     ap.add_argument('--nside', type=int, default=1024)
@@ -525,6 +525,8 @@ def shell_line(args, ctx, scaling, brief):
         from baryonification_amd.utils.Parallelize import shard_slices, shuffled_order
         full = syn.make_catalog(total_halos)
         mine = shuffled_order(total_halos, 42)[shard_slices(total_halos, world)[rank]]
+        if args.catalog_order == 'mass':                 # heaviest halos first, as halo finders write them
+            mine = mine[np.argsort(-full['M'][mine], kind='stable')]
         if args.catalog_order == 'sky':
             # a catalog written patch by patch (what a lightcone pipeline usually leaves): (band of 32 rings, azimuth) order.  The default
             # is the reference's own order for parallel runs -- shuffled with seed 42 (Parallelize.py:255)
@@ -1037,7 +1039,7 @@ def shell_line(args, ctx, scaling, brief):
                                        "Schneider19 (K4-K6 built)" if (args.table == 's19' and not paint) else "closed-form",
                                        "profile" if paint else "displacement"),
                        "halos_per_gpu": nh, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs, "table": ("closed-form" if paint else args.table),
-                       **({"catalog_order": "sky: (band of 32 rings, azimuth) order"} if args.catalog_order == 'sky' else {}),
+                       **({"catalog_order": {"sky": "sky: (band of 32 rings, azimuth) order", "mass": "mass: heaviest halos first"}[args.catalog_order]} if args.catalog_order != 'shuffled' else {}),
                        "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
                        "parallelism": ("single GPU" if world == 1 else
                                        "spatial sharding x%d: halos routed (RCCL all_to_all of catalog columns) to the ranks whose ring bands their discs "
