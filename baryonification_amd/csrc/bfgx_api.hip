@@ -691,9 +691,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         // the binning counters and, right behind them (16-byte aligned), the control words of the regrid's far list: ONE memset per step
         // zeroes both (a length that is not a multiple of 16 bytes, or two buffers, cost a fill kernel each: 4.5 us)
         const size_t n7p = ((size_t)7 * (T.ntiles + 1) + 3) & ~(size_t)3;
-        // region A's counters: a line each while that array stays below 1 MB (atomics to one line serialise; a larger array costs misses)
+        // region A's counters: a line each while that array stays below 4 MB (atomics to one line serialise; a larger array costs misses)
         p->cnt_pad = kCntPadMax;
-        while (p->cnt_pad > 1 && (size_t)T.ntiles * p->cnt_pad * sizeof(int32_t) > ((size_t)1 << 20)) p->cnt_pad >>= 1;
+        while (p->cnt_pad > 1 && (size_t)T.ntiles * p->cnt_pad * sizeof(int32_t) > ((size_t)4 << 20)) p->cnt_pad >>= 1;
         const size_t npad = (size_t)T.ntiles * p->cnt_pad;
         if (dalloc(sizeof(int32_t) * (npad + n7p + (size_t)T.ntiles + 8), &d0) || dalloc(sizeof(int32_t) * (T.ntiles + 1), &d1) ||
             dalloc(sizeof(int32_t) * (size_t)p->capacity, &d3) || dalloc(sizeof(int32_t), &d4) ||
