@@ -725,7 +725,12 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             // deposits listed for the generic route: four per pixel that moves beyond the gathering reach (15 rings = 9.9 / NSIDE rad).  At NSIDE
             // 1024 on the S19 table that is 0.2 % of the pixels; at NSIDE 2048 the same field in radians sends 8 % there (16 M entries), and a
             // list that overflows costs a second pass with the generic evaluation under divergence (25 ms): room for half the pixels, 1 GB at most
-            p->far.cap = std::min<int64_t>(std::max<int64_t>((int64_t)1 << 20, p->hpx.npix / 2), (int64_t)1 << 26);
+            // (round 4, second half: at config 4's REAL density -- 1e7 halos on one NSIDE-2048 shell, 43 discs over every pixel -- the S19
+            // displacements add up to 15 pixels on average and 58 % of the pixels move beyond the 15-ring reach: 1.4e8 listed deposits,
+            // 2.8 per pixel.  A list for half the pixels overflowed into the repair pass: K2 35 ms; with room for four deposits of EVERY
+            // pixel, 4.3 GB at most, 10 ms.)
+            p->far.cap = std::min<int64_t>(std::max<int64_t>((int64_t)1 << 20, 4 * p->hpx.npix), (int64_t)1 << 28);
+            if (const char *e = std::getenv("BFGX_FAR_CAP")) p->far.cap = std::max<int64_t>(1024, std::atoll(e));          // tests: force the overflow
             // control words in one allocation: [0..7] entries listed, [8..11] overflow (full-map regrid), [12..15] tiles left to
             // the walking kernel (followed by their numbers), ... ; the banded regrid's overflow flag lives after the tile list
             void *f4 = nullptr;

@@ -270,10 +270,11 @@ def _random_offsets(nside, scale_pix, seed):
 
 
 @pytest.mark.parametrize('nside,scale', [(128, 0.4), (128, 2.5), (128, 9.0), (128, 40.0), (64, 25.0), (512, 6.0), (512, 60.0)])
-def test_regrid_any_displacement_vs_oracle(gpu, nside, scale):
+def test_regrid_any_displacement_vs_oracle(gpu, monkeypatch, nside, scale):
     """K2 for displacements from a fraction of a pixel to tens of pixels (the gathering regrid sizes its aprons from the data;
     what it does not gather goes through the far list, and through the in-stream repair pass when that list overflows:
-    NSIDE 512 x 60 pixels lists ~8e6 deposits against a capacity of 1e6): fp64 route against the oracle's get_interpol
+    NSIDE 512 x 60 pixels lists ~8e6 deposits against a capacity forced down to 1e6 -- a plan's own list holds four deposits of every
+    pixel): fp64 route against the oracle's get_interpol
     regrid to 1e-10, fp32 route to the accuracy of fp32 weights; every pixel stored, mass conserved."""
     import torch
     from baryonification_amd import engine, synthetic as syn
@@ -287,6 +288,8 @@ def test_regrid_any_displacement_vs_oracle(gpu, nside, scale):
     z, M, r = syn.table_grid(cat)
     model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
     dev = torch.device('cuda:0')
+    if scale >= 60:
+        monkeypatch.setenv('BFGX_FAR_CAP', '1000000')
     plan = engine.ShellPlan(model, keep, nside, 1000, device=0, stream=torch.cuda.current_stream().cuda_stream)
     d_map = torch.from_numpy(hmap).to(dev)
     for f64, tol in ((True, 1e-10), (False, 3e-5 * max(1.0, scale))):
@@ -301,6 +304,8 @@ def test_regrid_any_displacement_vs_oracle(gpu, nside, scale):
         assert abs(sums[0].item() - hmap.sum()) <= 1e-9 * hmap.sum() and abs(sums[1].item() - sums[0].item()) <= 1e-9 * hmap.sum()
         assert abs(got.sum() - hmap.sum()) <= 1e-9 * hmap.sum()
         assert np.abs(got - ora).max() <= tol * np.abs(ora).max(), (f64, np.abs(got - ora).max() / np.abs(ora).max())
+        if scale >= 60:
+            assert plan.regrid_stats()['far_overflowed']                          # (the repair pass was what ran)
     plan.close()
 
 
