@@ -106,6 +106,7 @@ struct bfgx_plan {
     // tile-owned accumulation (algo 1): tiling tables + halo -> tile binning workspace
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
+    int64_t k1_nhalos = 0;          // halos of the catalog the binning step has just listed (the fast kernel's form follows their density)
     int k1_fluid = 1;               // the fast kernel's fluid form (bfgx_scatter2.hpp): 1 = from 2 tiles per CU; BFGX_K1_FLUID at plan creation: 0 = never (the barrier-per-tile form), 2 = always (tests)
     Tiling tiling;
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
@@ -322,6 +323,7 @@ static int launch_place(bfgx_plan *p, const bfgx_catalog *c)
 // halo -> tile entry lists: zero counters, K0 (counts), scan, fill
 static int launch_prep_and_bin(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool f64)
 {
+    p->k1_nhalos = c->n;
     const size_t nt = (size_t)p->tiling.ntiles;
     // cnt_a, cnt_b, cnt_w, cur_b, cur_w, tile counter of the fast kernel, largest |offset|^2 per tile, and the
     // four control words of the regrid's far list behind them (entries, overflow, tiles left to the walking kernel)
@@ -401,7 +403,12 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
         // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 at plan creation keeps the other
         const size_t ldsf = tile2f_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
         // (fewer than two tiles per CU -- NSIDE <= 256 -- keep the other form: half as many workgroups cannot balance so few tiles; a rank that owns an eighth of the NSIDE-1024 sphere, 776 tiles, is 4 % faster in the fluid form)
-        if (p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && (ntodo >= 2 * p->num_cus || p->k1_fluid == 2)) {
+        // ... and a sparse catalog (a patch of the sky, a few thousand halos: most tiles list nothing): sixteen waves walking through an
+        // empty slot and one wave's chain of dependent loads per drawn tile cost more than the barrier form's zero-and-store (1e4 halos at
+        // NSIDE 4096: 2.34 against 1.37 ms; 1e5 at NSIDE 2048: 0.68 against 0.58).  Work per tile follows the halo DENSITY (a halo's
+        // pixels grow with NSIDE^2 as the tiles do): the fluid form from 6e5 halos per sphere (5e5 at NSIDE 1024: 0.278 against 0.269 ms; 7e5: 0.319 against 0.342)
+        const bool dense = (double)p->k1_nhalos * (double)p->tiling.ntiles >= 6.0e5 * (double)ntodo;
+        if (p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && ((ntodo >= 2 * p->num_cus && dense) || p->k1_fluid == 2)) {
             auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
             HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             const int gridf = std::min(ntodo, p->num_cus);

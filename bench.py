@@ -1113,8 +1113,8 @@ def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None):
     table = table or args.table
     dom = force or ('paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0))
     real = 'double' if args.acc_f64 else 'float'
-    # (the fluid form: one workgroup per CU with two tile slots, 16 waves for fp32 pair math, 12 for fp64; shells of < 1024 tiles: the barrier form)
-    k1 = "tile_scatter2f_kernel" if 12 * args.nside ** 2 >= 2 * 256 * 2048 else "tile_scatter2_kernel"
+    # (the fluid form: one workgroup per CU with two tile slots, 16 waves for fp32 pair math, 12 for fp64; shells of < 512 tiles or fewer than 6e5 halos per sphere: the barrier form)
+    k1 = "tile_scatter2f_kernel" if (12 * args.nside ** 2 >= 2 * 256 * 2048 and nh >= 600000) else "tile_scatter2_kernel"
     names = {"offsets": ("%s<OFFSETS, %s>" % (k1, real)) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
              # (<.., 0>: the lean gather, reach of one ring; <.., 2>: the walking kernel -- every tile on the S19 table)
              "regrid": ("tile_regrid3_kernel<%s, %s, %d>" % (real, real, 2 if table == 's19' else 0)) if args.algo == 1 else "regrid_kernel",
