@@ -106,6 +106,8 @@ struct bfgx_plan {
     // tile-owned accumulation (algo 1): tiling tables + halo -> tile binning workspace
     int algo = 1;
     bool blocking_growth = false;   // one-shot host API: grow the entry list on overflow (needs a sync)
+    float *k0_work_est = nullptr;   // per K0 workgroup: estimated pixels of its narrow halos (k1_form_kernel)
+    int32_t *k1_form = nullptr;     // device word: the fast kernel's form when the halo count does not decide it (1 fluid, 0 barrier per tile)
     int64_t k1_nhalos = 0;          // halos of the catalog the binning step has just listed (the fast kernel's form follows their density)
     int k1_fluid = 1;               // the fast kernel's fluid form (bfgx_scatter2.hpp): 1 = from 2 tiles per CU; BFGX_K1_FLUID at plan creation: 0 = never (the barrier-per-tile form), 2 = always (tests)
     Tiling tiling;
@@ -295,6 +297,7 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
         o.tref = p->tref; o.cnt_a = p->tile_count; o.cnt_b = p->tile_count_b; o.cnt_w = p->tile_count_w;
         if (o.fast && p->entries_a) o.cnt_a = p->tile_count_pad;          // (direct placement: the padded counters, cnt_pad words apart)
         o.cnt_pad = p->cnt_pad;
+        o.work_est = o.fast ? p->k0_work_est : nullptr;
         o.entries_a = o.fast ? p->entries_a : nullptr; o.cap_a = p->entries_a_cap; o.slow_list = p->slow_list; o.slow_cnt = p->slow_cnt;
     }
     o.ncell_m = p->model.tab.n[1] - 1; o.nrm1 = p->model.tab.n[2] - 1;
@@ -399,6 +402,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     unsigned int *tile_counter = (unsigned int *)(p->tile_count + 5 * ((size_t)p->tiling.ntiles + 1));
     const int ntodo = p->k1_tile_n < 0 ? p->tiling.ntiles : std::max(p->k1_tile_n, 1);
     KernelTimer kt(p, MODE == MODE_OFFSETS ? BFGX_K_OFFSETS : (MODE == MODE_PAINT ? BFGX_K_PAINT : BFGX_K_COUNT));
+    int32_t *form = nullptr;               // non-NULL: both forms are launched and this device word says which one works
     if constexpr (MODE != MODE_COUNT) {
         // the fluid form (one 1024-thread workgroup per CU, two tile slots, no barrier between tiles): BFGX_K1_FLUID=0 at plan creation keeps the other
         const size_t ldsf = tile2f_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
@@ -406,9 +410,20 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
         // ... and a sparse catalog (a patch of the sky, a few thousand halos: most tiles list nothing): sixteen waves walking through an
         // empty slot and one wave's chain of dependent loads per drawn tile cost more than the barrier form's zero-and-store (1e4 halos at
         // NSIDE 4096: 2.34 against 1.37 ms; 1e5 at NSIDE 2048: 0.68 against 0.58).  Work per tile follows the halo DENSITY (a halo's
-        // pixels grow with NSIDE^2 as the tiles do): the fluid form from 6e5 halos per sphere (5e5 at NSIDE 1024: 0.278 against 0.269 ms; 7e5: 0.319 against 0.342)
+        // pixels grow with NSIDE^2 as the tiles do): 6e5 halos per sphere of the benchmark's catalog are the crossover (5e5 at NSIDE 1024: 0.278
+        // against 0.269 ms; 7e5: 0.319 against 0.342) -- 4800 pairs per tile.  A count of halos does not say how large they are, though (1e5
+        // halos at z < 0.05 hold 2300 pixels each: fluid 0.82 / 0.68 ms against 1.03 / 1.09 for displacement / painting): from 6e5 halos
+        // per sphere the fluid form is taken outright; below, K0's per-workgroup sums of the halos' estimated pixels decide ON THE DEVICE
+        // (k1_form_kernel) and both forms are launched -- the one not chosen returns at once (~5 us).
+        const bool eligible = p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && ntodo >= 2 * p->num_cus;
         const bool dense = (double)p->k1_nhalos * (double)p->tiling.ntiles >= 6.0e5 * (double)ntodo;
-        if (p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && ((ntodo >= 2 * p->num_cus && dense) || p->k1_fluid == 2)) {
+        const bool forced = p->k1_fluid == 2 && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave;
+        if (eligible && !dense && !forced && p->k0_work_est && p->k1_nhalos > 0) {
+            const int nblk = (int)((p->k1_nhalos + 255) / 256);
+            hipLaunchKernelGGL(k1_form_kernel, dim3(1), dim3(1024), 0, p->stream, nblk, (const float *)p->k0_work_est, 4800.0f * (float)ntodo, p->k1_form);
+            form = p->k1_form;
+        }
+        if (forced || (eligible && (dense || form))) {
             auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
             HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             const int gridf = std::min(ntodo, p->num_cus);
@@ -417,9 +432,9 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
                                (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
                                (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, tile_counter,
                                (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
-                               p->k1_tile_lo, p->k1_tile_n, p->overflow);
+                               p->k1_tile_lo, p->k1_tile_n, p->overflow, (const int32_t *)form, 1);
             HIP_TRY(hipGetLastError());
-            return BFGX_OK;
+            if (!form) return BFGX_OK;
         }
     }
     const int grid = std::min(ntodo, 2 * p->num_cus);
@@ -428,7 +443,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
                        (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
                        (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, p->pair_total, tile_counter,
                        (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
-                       p->k1_tile_lo, p->k1_tile_n);
+                       p->k1_tile_lo, p->k1_tile_n, (const int32_t *)form, 0);
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
 }
@@ -722,6 +737,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             if (const char *e = std::getenv("BFGX_TILE_LIST_CAP")) cap_a = std::max(1, std::atoi(e));        // tests: force the overflow into region B
             void *da = nullptr, *ds = nullptr, *dc = nullptr;
             const size_t nblk = ((size_t)std::max<int64_t>(max_halos, 1) + 255) / 256;
+            void *dw = nullptr, *df = nullptr;
+            if (dalloc(sizeof(float) * nblk, &dw) || dalloc(sizeof(int32_t) * 4, &df)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(work estimate) failed"));
+            p->k0_work_est = (float *)dw; p->k1_form = (int32_t *)df;
             if (dalloc(sizeof(int32_t) * (size_t)T.ntiles * cap_a, &da) || dalloc(sizeof(int32_t) * nblk * 256, &ds) || dalloc(sizeof(int32_t) * nblk, &dc))
                 return bail(fail(BFGX_ERR_HIP, "hipMalloc(tile lists) failed"));
             p->entries_a = (int32_t *)da; p->slow_list = (int32_t *)ds; p->slow_cnt = (int32_t *)dc; p->entries_a_cap = cap_a;

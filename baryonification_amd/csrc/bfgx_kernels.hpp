@@ -576,6 +576,8 @@ struct PrepOut {
     // pass.  Only the others (wide discs, discs over more than kRefMax tiles, slots beyond cap_a) are listed per K0 workgroup
     // (slow_list[block][256], slow_cnt[block]) for tile_place_kernel, which draws their slots from cursors after the scan.
     int32_t *entries_a, *slow_list, *slow_cnt;
+    float *work_est;              // per K0 workgroup: the sum of its narrow halos' estimated pixels (pi radius^2 / pixel area): what the fast
+                                  // kernel's form is chosen by when the halo count alone does not say (nullptr: not wanted)
     int32_t cap_a;
     int32_t cnt_pad;              // words between two tiles' counters in cnt_a when entries_a is set (direct placement)
     int32_t fast;                 // 1: narrow halos are class kClsNarrow (fast kernel), 0: every halo is kClsWide (generic kernel)
@@ -592,7 +594,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
                                               const double *__restrict__ ra, const double *__restrict__ dec,
                                               const double *__restrict__ ex0, const double *__restrict__ ex1,
                                               const double *__restrict__ lnz1, const double *__restrict__ lnM,
-                                              int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow);
+                                              int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow, float *s_work);
 
 template <int NC, typename real>
 __global__ void __launch_bounds__(256, 4)
@@ -604,7 +606,8 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  int fallback4, Tiling T, PrepOut o)
 {
     __shared__ int s_nslow;                               // halos of this workgroup left to the placement pass
-    if (threadIdx.x == 0) s_nslow = 0;
+    __shared__ float s_work;                              // estimated pixels of its narrow halos
+    if (threadIdx.x == 0) { s_nslow = 0; s_work = 0.0f; }
     // the (z, M) axes of the table go to LDS when they are short (the usual 10 - 30 nodes)
     constexpr int kAxisLds = 128;
     __shared__ double ax_lds[2 * kAxisLds];
@@ -628,10 +631,11 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     __syncthreads();                                       // (s_nslow)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // (every lane runs it -- the binning shuffles across the wave --, the lanes beyond the catalog on its last halo and without any store)
-    halo_prep_one<NC, real>(m, h, j < nhalo ? j : nhalo - 1, j < nhalo, gz, gm, M, z, ra, dec, ex0, ex1, lnz1, lnM, fallback4, T, o, &s_nslow);
+    halo_prep_one<NC, real>(m, h, j < nhalo ? j : nhalo - 1, j < nhalo, gz, gm, M, z, ra, dec, ex0, ex1, lnz1, lnM, fallback4, T, o, &s_nslow, &s_work);
     if (o.slow_cnt) {
         __syncthreads();
         if (threadIdx.x == 0) o.slow_cnt[blockIdx.x] = s_nslow;
+        if (threadIdx.x == 0 && o.work_est) o.work_est[blockIdx.x] = s_work;
     }
 }
 
@@ -641,7 +645,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
                                               const double *__restrict__ ra, const double *__restrict__ dec,
                                               const double *__restrict__ ex0, const double *__restrict__ ex1,
                                               const double *__restrict__ lnz1, const double *__restrict__ lnM,
-                                              int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow)
+                                              int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow, float *s_work)
 {
     HaloRec r;
     const double M_j = M[j], z_j = z[j];
@@ -744,6 +748,13 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     // tile binning, pass 1: reserve one slot per touched tile.  Issued HERE, before the model-side arithmetic and the record
     // stores, so that the returning atomics (the longest latency of this kernel) are in flight while the rest is computed;
     // the TileRef that holds the slots is stored last.
+    if (o.work_est) {
+        // pixels of the disc: pi radius^2 / (4 pi / npix); one add per wave (the waves of a workgroup share one LDS word)
+        float w = (cls == kClsNarrow) ? (r.fb ? 4.0f : (float)(radius * radius) * 0.25f * (float)h.npix) : 0.0f;
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) w += __shfl_xor(w, sft, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(s_work, w);
+    }
     TileRef ref;
     RunSlot run[kRefMax];
     for (int i = 0; i < kRefMax; ++i) { run[i].base = 0; run[i].hr = 0; }
@@ -967,6 +978,25 @@ route_blank_kernel(int32_t world, int32_t ncols, int64_t blockcap, double *__res
     const int64_t n = (int64_t)world * blockcap;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         rows[(i / blockcap) * ncols * blockcap + (i % blockcap)] = __builtin_nan("");
+}
+
+// The fast kernel's form when the halo count does not decide it: form[0] = 1 (fluid) if the catalog's estimated pairs per tile reach
+// `thr`, else 0 (barrier per tile).  One workgroup sums K0's per-workgroup estimates.
+__global__ void __launch_bounds__(1024)
+k1_form_kernel(int nblk, const float *__restrict__ work_est, float thr_total, int32_t *__restrict__ form)
+{
+    __shared__ float red[1024 / kWave];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < nblk; i += 1024) s += work_est[i];
+#pragma unroll
+    for (int sft = kWave >> 1; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 1024 / kWave; ++w) t += red[w];
+        form[0] = t >= thr_total ? 1 : 0;
+    }
 }
 
 // exclusive scan of the per-tile entry counts (one workgroup); start[ntiles] = total.  A tile's list is laid out as

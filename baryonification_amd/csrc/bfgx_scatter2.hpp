@@ -476,8 +476,10 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                      const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a, int cnt_pad,
                      ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
-                     unsigned int *__restrict__ omax2, int tile_lo, int tile_n)
+                     unsigned int *__restrict__ omax2, int tile_lo, int tile_n, const int32_t *__restrict__ form, int my_form)
 {
+    // (form: which of the fast kernel's two forms runs was left to the device -- both are launched, the other one returns here)
+    if (form != nullptr && *form != my_form) return;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
     // persistent workgroups (two per CU): tiles are drawn from a device counter in the order of T.tile_order -- heavy
@@ -667,8 +669,9 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
                       const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                       const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a, int cnt_pad,
                       ACC *__restrict__ out, unsigned int *__restrict__ tile_counter, unsigned int *__restrict__ omax2,
-                      int tile_lo, int tile_n, int32_t *__restrict__ err)
+                      int tile_lo, int tile_n, int32_t *__restrict__ err, const int32_t *__restrict__ form, int my_form)
 {
+    if (form != nullptr && *form != my_form) return;
     static_assert(MODE == MODE_OFFSETS || MODE == MODE_PAINT, "the census runs in tile_scatter2_kernel");
     constexpr int kWF = FluidWaves<real>::n;
     extern __shared__ __align__(16) unsigned char smem[];
