@@ -729,10 +729,10 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         p->entries = (int32_t *)d3; p->overflow = (int32_t *)d4; p->pair_total = (unsigned long long *)d5;
         {
             // capacity of a tile's fixed list: 16 x the mean entries per tile (a rank of an N-GPU run bins its share of the halos into 1 / N
-            // of the tiles; a sky patch does the same), a power of two in [64, 2048], the whole array at most 1 GB
+            // of the tiles; a sky patch does the same), a power of two in [64, 32768] (4 x the mean above 512 entries per tile: a catalog of 1e7 small halos lists 4200 per tile, and what does not fit takes the slow route -- K3 3.7 against 1.4 ms), the whole array at most 1 GB
             const double mean = 1.3 * (double)std::max<int64_t>(max_halos, 1) / (double)T.ntiles;
             int cap_a = 64;
-            while (cap_a < 2048 && (double)cap_a < 16.0 * mean + 64.0) cap_a <<= 1;
+            while (cap_a < 32768 && (double)cap_a < (mean > 512.0 ? 4.0 : 16.0) * mean + 64.0) cap_a <<= 1;
             while (cap_a > 64 && (size_t)T.ntiles * cap_a * sizeof(int32_t) > ((size_t)1 << 30)) cap_a >>= 1;
             if (const char *e = std::getenv("BFGX_TILE_LIST_CAP")) cap_a = std::max(1, std::atoi(e));        // tests: force the overflow into region B
             void *da = nullptr, *ds = nullptr, *dc = nullptr;
