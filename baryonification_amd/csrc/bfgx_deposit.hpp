@@ -191,7 +191,10 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     // mstride: doubles between consecutive masses of mass_in (1 unless level 1 reads a field of a record buffer)
     __shared__ int hist[kDepHist];                  // per bucket: count -> local prefix -> (global base - local prefix)
     __shared__ uint32_t skey[kDepChunk];
-    __shared__ double smass[MASS ? kDepChunk : 1];
+    // masses travel in rounds of kMassRound through 8 KB of LDS: staging all 4096 of a workgroup (32 KB) left room for two workgroups per
+    // CU, and the two passes took 0.93 ms each against 0.22 without masses
+    constexpr int kMassRound = 1024;
+    __shared__ double smass[MASS ? kMassRound : 1];
     __shared__ int part[256];
     __shared__ int bmin_s;
     const int tid = threadIdx.x;
@@ -232,17 +235,19 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     for (int e = 0; e < kOwn; ++e) { lpre[e] = pre; hist[tid * kOwn + e] = pre; pre += cnt[e]; }
     __syncthreads();
     // order the keys by bucket in LDS
+    int slotq[MASS ? kDepPer : 1];                  // (masses: where each of the thread's keys went)
 #pragma unroll
     for (int q = 0; q < kDepPer; ++q) {
+        if (MASS) slotq[q] = -1;
         if (rank[q] >= 0) {
             const int slot = hist[dep_bucket<LEVEL>(g, key[q]) - bmin] + rank[q];
             skey[slot] = key[q];
-            if (MASS) smass[slot] = mass_in[(base + q * 256 + tid) * mstride];
+            if (MASS) slotq[q] = slot;
         } else if (rank[q] == -2) {                 // bucket beyond the local table (almost empty buckets only)
             const int b = dep_bucket<LEVEL>(g, key[q]);
             const int64_t dst = (int64_t)start[b] + atomicAdd(cursor + (int64_t)b * (LEVEL == 2 ? kDepPad : 1), 1);
             keys_out[dst] = key[q];
-            if (MASS) mass_out[dst] = mass_in[base + q * 256 + tid];
+            if (MASS) mass_out[dst] = mass_in[(base + q * 256 + tid) * mstride];
         }
     }
     __syncthreads();
@@ -259,7 +264,20 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
         const uint32_t k = skey[i];
         const int64_t dst = (int64_t)hist[dep_bucket<LEVEL>(g, k) - bmin] + i;
         keys_out[dst] = k;
-        if (MASS) mass_out[dst] = smass[i];
+    }
+    if (MASS) {
+        for (int r0 = 0; r0 < total; r0 += kMassRound) {
+            __syncthreads();                                   // (the round before has been copied out)
+#pragma unroll
+            for (int q = 0; q < kDepPer; ++q)
+                if (slotq[q] >= r0 && slotq[q] < r0 + kMassRound) smass[slotq[q] - r0] = mass_in[(base + q * 256 + tid) * mstride];
+            __syncthreads();
+            const int nr = min(kMassRound, total - r0);
+            for (int i = tid; i < nr; i += 256) {
+                const uint32_t k = skey[r0 + i];
+                mass_out[(int64_t)hist[dep_bucket<LEVEL>(g, k) - bmin] + r0 + i] = smass[i];
+            }
+        }
     }
 }
 
