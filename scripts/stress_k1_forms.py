@@ -66,8 +66,6 @@ for c in range(cases):
         for pl, _ in plans:
             pl.close()
         continue
-    if True:
-        pass
     scale = max(outs[1].abs().max().item(), 1e-300)
     d = (outs[0] - outs[1]).abs().max().item() / scale
     bounds = plans[0][0].bands()
