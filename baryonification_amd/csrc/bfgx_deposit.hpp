@@ -266,11 +266,15 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
         keys_out[dst] = k;
     }
     if (MASS) {
+        // (the thread's sixteen masses are requested together, once; the rounds only move them through LDS)
+        double mq[kDepPer];
+#pragma unroll
+        for (int q = 0; q < kDepPer; ++q) mq[q] = (slotq[q] >= 0) ? mass_in[(base + q * 256 + tid) * mstride] : 0.0;
         for (int r0 = 0; r0 < total; r0 += kMassRound) {
             __syncthreads();                                   // (the round before has been copied out)
 #pragma unroll
             for (int q = 0; q < kDepPer; ++q)
-                if (slotq[q] >= r0 && slotq[q] < r0 + kMassRound) smass[slotq[q] - r0] = mass_in[(base + q * 256 + tid) * mstride];
+                if (slotq[q] >= r0 && slotq[q] < r0 + kMassRound) smass[slotq[q] - r0] = mq[q];
             __syncthreads();
             const int nr = min(kMassRound, total - r0);
             for (int i = tid; i < nr; i += 256) {
