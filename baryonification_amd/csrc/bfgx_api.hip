@@ -109,6 +109,7 @@ struct bfgx_plan {
     float *k0_work_est = nullptr;   // per K0 workgroup: estimated pixels of its narrow halos (k1_form_kernel)
     int32_t *k1_form = nullptr;     // device word: the fast kernel's form when the halo count does not decide it (1 fluid, 0 barrier per tile)
     int64_t k1_nhalos = 0;          // halos of the catalog the binning step has just listed (the fast kernel's form follows their density)
+    int k1_wide = 1;                // the fast kernel takes the WIDE discs too (a pole inside, pixels beyond 0.40 rad of the halo's azimuth: RowRec.fb bit 1) and the generic kernel's wide pass is not launched; BFGX_K1_WIDE=0 at plan creation: they go through the wide pass (tests: the two must agree)
     int k1_fluid = 1;               // the fast kernel's fluid form (bfgx_scatter2.hpp): 1 = from 2 tiles per CU; BFGX_K1_FLUID at plan creation: 0 = never (the barrier-per-tile form), 2 = always (tests)
     Tiling tiling;
     int32_t *tile_count = nullptr, *tile_count_b = nullptr, *tile_count_w = nullptr, *tile_start = nullptr, *tile_cursor = nullptr,
@@ -290,7 +291,7 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
     PrepOut o;
     std::memset(&o, 0, sizeof(o));
     o.rec = p->recs; o.rowsx = p->rowsx;
-    o.fast = (bin && use_fast(p)) ? 1 : 0;
+    o.fast = (bin && use_fast(p)) ? (p->k1_wide ? 2 : 1) : 0;
     o.rec_all = (rec_all || !o.fast) ? 1 : 0;
     o.rowrec = p->rowrec; o.pairrec = p->pairrec; o.fbrec = p->fbrec;
     if (bin) {
@@ -458,11 +459,11 @@ static int launch_tile_scatter(bfgx_plan *p, ACC *out)
             // acc_f64 = 2: the pair phase in fp32 (K0 wrote fp32 pair records), LDS accumulation and the stored map in fp64
             if (p->paint_pair_f32) {
                 if (int rc = launch_tile_scatter2<MODE, ACC, float>(p, out)) return rc;
-                return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);
+                return p->k1_wide ? BFGX_OK : launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);
             }
         }
         if (int rc = launch_tile_scatter2<MODE, ACC, real>(p, out)) return rc;
-        return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);
+        return p->k1_wide ? BFGX_OK : launch_tile_scatter_nc<MODE, ACC, 4>(p, out, true);      // (k1_wide: K0 classed no halo as wide)
     }
     if (p->NC == 4) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, false);
     if (MODE == MODE_COUNT) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, false);      // census never reads the rows
@@ -703,6 +704,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
         if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "stream sync failed"));
         p->capacity = 8 * max_halos + 4096;
         if (const char *e = std::getenv("BFGX_K1_FLUID")) p->k1_fluid = std::max(0, std::min(2, std::atoi(e)));
+        if (const char *e = std::getenv("BFGX_K1_WIDE")) p->k1_wide = std::atoi(e) != 0;
         if (const char *e = std::getenv("BFGX_ENTRY_CAP")) p->capacity = std::max<int64_t>(16, std::atoll(e));   // tests: force regrowth
         auto dalloc = [&](size_t bytes, void **ptr) {
             if (hipMalloc(ptr, bytes) != hipSuccess) return 1;

@@ -500,11 +500,12 @@ __device__ inline void for_each_tile(const Hpx &h, const Tiling &T, const DiscSp
 struct alignas(16) RowRec {                // what the ring-row phase needs of a halo
     double z0, s0, xa, cosr, phi0;         // query_disc pointing: cos / sin colatitude, 1 / sin, cos(radius), azimuth
     int32_t rfirst, rlast;                 // ring range of the disc (no pole inside: every row is phi-tested)
-    int32_t fb;                            // 1: the rows are the 4 fallback pixels of FbRec (HealpixRunner.py:309-310)
+    int32_t fb;                            // bit 0: the rows are the 4 fallback pixels of FbRec (HealpixRunner.py:309-310); bit 1: a WIDE disc (a pole
+                                           // inside, or pixels further than 0.40 rad from the halo's azimuth): general row spans, FbRec.ring[0..1] = irmin, irmax
     int32_t _pad;
     double cut2;                           // (rcut a / D)^2 in fp64, for the rare ambiguous fp32 cut decisions
 };
-struct FbRec { int32_t ring[4], k[4]; };   // the 4 get_interp_weights neighbours as (ring, index in ring)
+struct FbRec { int32_t ring[4], k[4]; };   // the 4 get_interp_weights neighbours as (ring, index in ring); a wide disc without them: ring[0..1] = irmin, irmax
 
 template <typename real>
 struct alignas(16) PairRecT {              // what the pair phase needs of a halo, in the precision of the pair math
@@ -580,7 +581,8 @@ struct PrepOut {
                                   // kernel's form is chosen by when the halo count alone does not say (nullptr: not wanted)
     int32_t cap_a;
     int32_t cnt_pad;              // words between two tiles' counters in cnt_a when entries_a is set (direct placement)
-    int32_t fast;                 // 1: narrow halos are class kClsNarrow (fast kernel), 0: every halo is kClsWide (generic kernel)
+    int32_t fast;                 // 1: narrow halos are class kClsNarrow (fast kernel), 0: every halo is kClsWide (generic kernel), 2: the fast kernel
+                                  // takes the wide discs too (RowRec.fb bit 1): no halo is left to the generic kernel's wide pass
     int32_t rec_all;              // 1: HaloRec for every halo (halo-centric algo 0)
     int32_t ncell_m, nrm1;        // (nm - 1), (nr - 1) of the interleaved table
 };
@@ -740,11 +742,13 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     // class: the fast kernel takes discs without a pole inside whose pixels all lie within 0.40 rad of the halo's azimuth
     // (fallback pixels: within one pixel of it, so rings of at least 64 pixels are narrow enough)
     int cls = kClsWide;
+    bool geo_wide = false;                 // (o.fast == 2) a disc the fast kernel takes through its general row spans and full-range sin / cos
     if (bad) cls = kClsNone;
     else if (o.fast && NC == 4 && !r.allphi && dmax <= 0.40) {
         cls = kClsNarrow;
         if (r.fb) for (int q = 0; q < 4; ++q) if (r.fb_ring[q] < 16 || r.fb_ring[q] > (int)nl4 - 16) cls = kClsWide;
     }
+    if (o.fast == 2 && NC == 4 && cls == kClsWide) { cls = kClsNarrow; geo_wide = true; }
     // tile binning, pass 1: reserve one slot per touched tile.  Issued HERE, before the model-side arithmetic and the record
     // stores, so that the returning atomics (the longest latency of this kernel) are in flight while the rest is computed;
     // the TileRef that holds the slots is stored last.
@@ -809,13 +813,13 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     if (cls == kClsNarrow && !(BFGX_ABL0 & 1)) {
         RowRec rr;
         rr.z0 = r.z0; rr.s0 = r.s0; rr.xa = r.xa; rr.cosr = r.cosr; rr.phi0 = r.phi0;
-        rr.rfirst = r.rfirst; rr.rlast = r.rlast; rr.fb = r.fb; rr._pad = 0;
+        rr.rfirst = r.rfirst; rr.rlast = r.rlast; rr.fb = (r.fb ? 1 : 0) | (geo_wide ? 2 : 0); rr._pad = 0;
         // r_sep / a < rcut  <=>  |u|^2 < (rcut a / D)^2,  u = diff / D.  Every pixel of the disc has a chord
         // D |u| <= 2 D sin(radius / 2); when that is below rcut a the cut can never fire (eps_model >= eps_runner)
         const double cut = r.rcut * a / D;
         rr.cut2 = cut * cut;
         double sh, chh;
-        sincos_bounded(0.5 * radius, sh, chh);
+        sincos_bounded(0.5 * fmin(radius, kPi), sh, chh);      // (the longest chord of a disc: 2 sin(radius / 2), 2 from radius = pi)
         const bool implied = (m.tab.logv != 0) || (!r.fb && cut >= 2.0 * sh * (1.0 + 1e-9));     // paint: no model-side cut at all
         o.rowrec[j] = rr;
         PairRecT<real> pr;
@@ -838,9 +842,10 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
         pr.oob = oob ? 1 : 0;
         pr.hidx = (int32_t)j; pr._pad = 0;
         reinterpret_cast<PairRecT<real> *>(o.pairrec)[j] = pr;
-        if (r.fb) {
+        if (r.fb || geo_wide) {
             FbRec f;
             for (int q = 0; q < 4; ++q) { f.ring[q] = r.fb_ring[q]; f.k[q] = r.fb_k[q]; }
+            if (!r.fb) { f.ring[0] = r.irmin; f.ring[1] = r.irmax; }
             o.fbrec[j] = f;
         }
     }

@@ -20,6 +20,7 @@
 // 4 waves/SIMD: <= 128 VGPRs, 76 KB of LDS per workgroup (fp32 pix_offsets).
 #pragma once
 #include "bfgx_kernels.hpp"
+#include <type_traits>
 
 namespace bfgx {
 
@@ -165,10 +166,28 @@ __device__ __noinline__ bool exact_cut_test(const TileRow &tr, const RowRec &rr,
     const int kk = tr.ks + kloc;
     const double xx = fold_dphi(__builtin_fma((double)kk + (tr.shifted ? 0.5 : 0.0), tr.dphi, -rr.phi0));
     double sh, ch;
-    sincos_small(0.5 * xx, sh, ch);
+    if (fabs(xx) <= 1.0) sincos_small(0.5 * xx, sh, ch);
+    else sincos_bounded(0.5 * xx, sh, ch);                              // (a wide disc: RowRec.fb bit 1)
     const double s2 = 2.0 * sh * ch, o2 = 2.0 * sh * sh;
     const double wx = (tr.sth - rr.s0) - tr.sth * o2, wy = tr.sth * s2, wz = tr.z - rr.z0;
     return (wx * wx + wy * wy + wz * wz) < rr.cut2;
+}
+
+// A WIDE disc (RowRec.fb bit 1: a pole inside, or pixels further than 0.40 rad from the halo's azimuth; a handful of polar halos in a
+// full-sky catalog) goes through the same chunk: its row spans by the general arithmetic of the generic kernel (polar-cap rows are whole
+// rings, atan2 over the full range), the sin / cos of its pairs over the full range.  Both are calls, so that the narrow path keeps its registers.
+__device__ __noinline__ int2 disc_row_span_wide(const TileRow &tr, int ring, const RowRec &rr, const FbRec &fr)
+{
+    int slo, scnt;
+    disc_row_span(tr.nr, tr.shifted != 0, tr.z, tr.fnr, ring, rr.z0, rr.xa, rr.cosr, rr.phi0, fr.ring[0], fr.ring[1], slo, scnt);
+    return make_int2(slo, scnt);
+}
+// (sin x, 1 - cos x) for any |x| <~ 1e3, through the half angle in fp64
+__device__ __noinline__ double2 sin_omc_wide(double x)
+{
+    double sh, ch;
+    sincos_bounded(0.5 * x, sh, ch);
+    return make_double2(2.0 * sh * ch, 2.0 * sh * sh);
 }
 
 __device__ inline unsigned long long wave_uniform64(unsigned long long v)
@@ -187,7 +206,7 @@ struct PairEval {
 };
 
 // Branch-free evaluation of pair t of the current row block.
-template <int MODE, typename real>
+template <int MODE, typename real, bool FAR = false>
 __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const RowC2<real> rc, const PairRecT<real> *pairs,
                                  const RingC2<real> *ringc, int t, bool act, int wsh, int wmask)
 {
@@ -201,6 +220,9 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     const real x = fma_((real)jj, rg.dphi, rc.x0);
     real sn, omc;
     PM::sin_omc(x, sn, omc);
+    if (FAR) {                                                         // (a row pass that holds pairs beyond 0.5 rad of their halo's azimuth: k1_chunk)
+        if (act && !(fabs((double)x) <= 0.5)) { const double2 w = sin_omc_wide((double)x); sn = (real)w.x; omc = (real)w.y; }
+    }
     const real ux = fma_(-rg.sth, omc, rc.ds), uy = rg.sth * sn, uz = rc.dz;   // (v_pix - v_halo) / D, HealpixRunner.py:314-316
     // |u|^2.  Painting needs nothing else of u, and with sin^2 x + (1 - cos x)^2 = 2 (1 - cos x):
     //   |u|^2 = ds^2 + dz^2 + 2 sth (sth - ds) (1 - cos x),   sth - ds = sin(theta_halo)
@@ -289,7 +311,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
         const RowRec &rr = rowrecs[en.hidx];
         if (BFGX_K1_GEO) { gg.z0 = rr.z0; gg.s0 = rr.s0; gg.xa = rr.xa; gg.cosr = rr.cosr; gg.phi0 = rr.phi0; }
         en.fb = rr.fb;
-        if (en.fb) nrows = 4;
+        if (en.fb & 1) nrows = 4;
         else {
             const int lo = max(rr.rfirst, i0), hi = min(rr.rlast, i1 - 1);
             nrows = max(0, hi - lo + 1);
@@ -317,7 +339,10 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
 
     // a row can hold two pixel runs only in a tile that spans whole rings (a disc across phi = 0): such tiles (the
     // innermost polar bands) use 32 row lanes per pass so that the runs of one pass always fit the 64 row slots
-    const int rowlanes = (nphi == 1) ? 32 : kWave;
+    // (and a WIDE disc can hold two runs of a row in any tile -- a span that leaves only a gap inside the tile's slice: a chunk that lists one does the same)
+    auto rows_and_pairs = [&](auto wide_tag) __attribute__((always_inline)) {
+    constexpr bool WIDE = decltype(wide_tag)::value;
+    const int rowlanes = (nphi == 1 || WIDE) ? 32 : kWave;
     for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += rowlanes) {
         // ---- lanes = ring rows (clipped to this tile)
         const int R = rb + lane;
@@ -339,7 +364,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
 #else
             const RowRec &rr = rowrecs[eh];
 #endif
-            if (efb) {
+            if (efb & 1) {
                 const int ring = fbrecs[eh].ring[q], fk = fbrecs[eh].k[q];
                 if (ring >= i0 && ring < i1) {
                     const TileRow &tr = rowtab[ring - i0];
@@ -354,7 +379,8 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
                 const int ring = erl + q;
                 const TileRow &tr = rowtab[ring - i0];
                 int slo, scnt;
-                disc_row_span_narrow(tr.nr, tr.shifted != 0, tr.z, tr.fnr, rr.z0, rr.xa, rr.cosr, rr.phi0, slo, scnt);
+                if (WIDE && (efb & 2)) { const int2 sp = disc_row_span_wide(tr, ring, rowrecs[eh], fbrecs[eh]); slo = sp.x; scnt = sp.y; }
+                else disc_row_span_narrow(tr.nr, tr.shifted != 0, tr.z, tr.fnr, rr.z0, rr.xa, rr.cosr, rr.phi0, slo, scnt);
                 rloc = ring - i0;
                 dzv = tr.z - rr.z0; dsv = tr.sth - rr.s0;
                 const int nr = tr.nr, ks = tr.ks, ke = tr.ke;
@@ -434,7 +460,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const int t = T0 + u * kWave + lane;
-                    pair_eval<MODE, real>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
+                    pair_eval<MODE, real, WIDE>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
                 }
                 if (MODE == MODE_OFFSETS && sizeof(real) == 4) {
                     // pairs whose fp32 chord is within 4e-6 of the model-side cut (BaryonCorrection.py:381-382): decide in fp64 (rare)
@@ -466,6 +492,11 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
             __builtin_amdgcn_wave_barrier();
         }
     }
+    };
+    // A chunk that lists a WIDE disc (RowRec.fb bit 1; a handful of polar halos in a full-sky catalog) takes a second copy of the row and pair
+    // phases -- general row spans, sin / cos over the full range where a pair lies beyond 0.5 rad of its halo's azimuth --, so that the
+    // copy every other chunk runs is the narrow code alone.
+    if (__builtin_expect(__any((en.fb & 2) != 0), 0)) rows_and_pairs(std::true_type{}); else rows_and_pairs(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------- the kernel

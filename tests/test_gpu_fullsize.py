@@ -826,6 +826,70 @@ def test_k1_fluid_form_equals_barrier_form(gpu, monkeypatch, paint, f64):
     plan.close(); barrier.close()
 
 
+@pytest.mark.parametrize('f64', [False, True])
+@pytest.mark.parametrize('paint', [False, True])
+def test_wide_discs_in_the_fast_kernel_equal_the_wide_pass(gpu, monkeypatch, paint, f64):
+    """wide discs -- a pole inside, pixels further than 0.40 rad from the halo's azimuth, the 4 fallback pixels on the first rings -- go
+    through the fast kernel's chunk (general row spans, full-range sin / cos; default) instead of the generic kernel's wide pass
+    (BFGX_K1_WIDE=0 at plan creation).  Same pair census; outputs equal to fp32 / fp64 rounding of the different pair arithmetic.  The catalog
+    holds halos on and around both poles, discs of 0.3 - 2.5 rad (z = 0.0003 .. 0.003: thousands of tiles each), a disc over the whole sphere and
+    tiny discs on the first rings, among 2e5 ordinary ones; both forms of the fast kernel."""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    N, nside = 200_000, 512
+    cat = syn.make_catalog(N)
+    rng = np.random.default_rng(77)
+    k = 64
+    cat['dec'][:k] = np.where(rng.random(k) < 0.5, 1.0, -1.0) * (90.0 - rng.random(k) ** 3 * 3.0)          # within 3 degrees of a pole
+    cat['dec'][:4] = [90.0 - 1e-7, -90.0 + 1e-7, 89.99, -89.999]
+    cat['ra'][:k] = rng.uniform(0, 360, k)
+    cat['M'][:k] = 10.0 ** rng.uniform(12.0, 15.0, k)
+    # large discs anywhere: the heaviest halo at z = 0.001 (radius > pi: the whole sphere) .. 0.02 (0.24 rad: wide at |dec| > 55 degrees)
+    cat['z'][k:k + 12] = np.geomspace(0.001, 0.02, 12)
+    cat['M'][k:k + 12] = cat['M'].max()
+    cat['dec'][k:k + 12] = rng.uniform(-90, 90, 12)
+    z, M, r = syn.table_grid(cat, pad=1e-9)
+    table = syn.paint_table(z, M, r) if paint else syn.displacement_table(z, M, r)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    dev = torch.device('cuda', 0)
+    npix = 12 * nside * nside
+    cd, keep1 = _cat_dev(torch, _lib, dev, cat)
+    keeps = []
+
+    def make_plan():
+        model, keep = engine.model_from_tables(axes, np.log(table) if paint else table, syn.COSMO, 10.0, 10.0, log_values=paint)
+        keeps.append(keep)
+        return engine.ShellPlan(model, keep, nside, N, 0, torch.cuda.current_stream().cuda_stream)
+
+    plan = make_plan()
+    monkeypatch.setenv('BFGX_K1_WIDE', '0')
+    passed = make_plan()
+    monkeypatch.delenv('BFGX_K1_WIDE')
+    monkeypatch.setenv('BFGX_K1_FLUID', '0')
+    barrier = make_plan()
+    monkeypatch.delenv('BFGX_K1_FLUID')
+
+    def full(pl):
+        out = torch.zeros(npix * (1 if paint else 3), dtype=torch.float64 if (paint or f64) else torch.float32, device=dev)
+        if paint:
+            pl.paint(cd, out.data_ptr(), acc_f64=(1 if f64 else 2))
+        else:
+            pl.offsets(cd, out.data_ptr(), f64)
+        torch.cuda.synchronize()
+        pl.status()
+        return out
+
+    a, b, c = full(plan), full(passed), full(barrier)
+    scale = b.abs().max().item()
+    tol = 1e-10 if f64 else 3e-6          # (fp32 pair math in both, arranged differently; fp64: the two routes' libm-free / libm trigonometry)
+    assert scale > 0
+    assert (a - b).abs().max().item() <= tol * scale, ((a - b).abs().max().item(), scale)
+    assert (c - b).abs().max().item() <= tol * scale
+    n_wide = passed.count_pairs(cd, not paint)
+    assert plan.count_pairs(cd, not paint) == n_wide == barrier.count_pairs(cd, not paint) > 2e6
+    plan.close(); passed.close(); barrier.close()
+
+
 def test_catalog_written_patch_by_patch_equals_shuffled(gpu):
     """a catalog in (band of rings, azimuth) order -- what a lightcone pipeline usually writes -- makes consecutive threads of K0 name the
     same tile: they take their slots with one atomic per run of lanes (wave_run_issue), on counters a cache line apart.  Same census, same
