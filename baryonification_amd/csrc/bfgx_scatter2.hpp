@@ -1,8 +1,10 @@
 // Fast tiled scatter for gfx950 (MI355X): K1 (BaryonifyShell halo loop, HealpixRunner.py:306-331) and K3
-// (PaintProfilesShell, HealpixRunner.py:432-445) for the common case -- "narrow" discs (no pole inside, every pixel within
-// 0.45 rad of the halo's azimuth), a 3-axis table with a uniform ln r axis.  Everything else (polar caps, very low
-// redshift, property-axis tables, non-uniform radial axes) stays on the generic tile kernel of bfgx_kernels.hpp, which
-// then only processes the "wide" region of every tile's entry list and adds into the stored tile.
+// (PaintProfilesShell, HealpixRunner.py:432-445) for a 3-axis table with a uniform ln r axis.  The code every chunk runs is
+// written for "narrow" discs (no pole inside, every pixel within 0.40 rad of the halo's azimuth); a chunk that lists a WIDE disc
+// (a pole inside, very low redshift: a handful of halos in a full-sky catalog) takes a second copy of the row and pair phases
+// with the generic kernel's row spans and full-range sin / cos (k1_chunk, rows_and_pairs).  Property-axis tables and non-uniform
+// radial axes stay on the generic tile kernel of bfgx_kernels.hpp (which, with BFGX_K1_WIDE=0, also takes the wide discs in a
+// "wide pass" that adds into the stored tiles: the arrangement up to round 4, kept for the tests).
 //
 // One 512-thread workgroup owns one tile (BR rings x <= W pixels) of the output: its accumulators are fp64 planes in LDS
 // (one plane per component, so that consecutive pixels hit consecutive banks), every pixel is stored exactly once.
