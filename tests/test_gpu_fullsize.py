@@ -887,6 +887,24 @@ def test_wide_discs_in_the_fast_kernel_equal_the_wide_pass(gpu, monkeypatch, pai
     assert (c - b).abs().max().item() <= tol * scale
     n_wide = passed.count_pairs(cd, not paint)
     assert plan.count_pairs(cd, not paint) == n_wide == barrier.count_pairs(cd, not paint) > 2e6
+    # band-restricted passes (what a rank of a spatially sharded run computes): the polar bands, a belt, the cap / belt boundary
+    bounds = plan.bands()
+    nb = len(bounds) - 1
+    comp = 1 if paint else 3
+    for b0, b1 in ((0, 2), (nb - 1, nb), (nb // 2 - 1, nb // 2 + 2), (nb // 4, nb // 4 + 3)):
+        p0, p1 = int(bounds[b0]), int(bounds[b1])
+        got = []
+        for pl in (plan, passed):
+            sl = torch.full(((p1 - p0) * comp,), 7.0, dtype=a.dtype, device=dev)
+            if paint:
+                pl.paint_bands(cd, b0, b1, sl.data_ptr(), acc_f64=(1 if f64 else 2))
+            else:
+                pl.offsets_bands(cd, b0, b1, sl.data_ptr(), f64)
+            torch.cuda.synchronize()
+            pl.status()
+            got.append(sl)
+        assert (got[0] - got[1]).abs().max().item() <= tol * scale
+        assert (got[0] - a[p0 * comp:p1 * comp]).abs().max().item() <= tol * scale
     plan.close(); passed.close(); barrier.close()
 
 
