@@ -653,7 +653,15 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 // always drains.
 // waves per workgroup of the fluid kernel: sixteen (four per SIMD at <= 128 VGPRs) for fp32 pair math; twelve for fp64 pair math, whose waves need
 // ~155 VGPRs and 4.5 KB of LDS each: three per SIMD, against two for the barrier form (one 8-wave workgroup per CU: its LDS does not fit twice)
-template <typename real> struct FluidWaves { static constexpr int n = sizeof(real) == 4 ? 16 : 12; };
+// (measured, config 2: 16 waves x 1 pair per lane 0.387 ms; 16 x 2: 0.410; 12 x 2 -- 132 VGPRs --: 0.431; 12 x 1: 0.444.  More than 16 waves would be
+// a second workgroup per CU, which LDS does not hold.)
+#ifndef BFGX_K1F_WAVES32
+#define BFGX_K1F_WAVES32 16
+#endif
+#ifndef BFGX_K1F_NP
+#define BFGX_K1F_NP 1
+#endif
+template <typename real> struct FluidWaves { static constexpr int n = sizeof(real) == 4 ? BFGX_K1F_WAVES32 : 12; };
 #ifndef BFGX_CHUNKB
 #define BFGX_CHUNKB 2
 #endif
@@ -952,7 +960,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             const int ebeg = c < nchb ? na + c * kChunkB : c - nchb;
             const int ecnt = c < nchb ? min(kChunkB, ne - ebeg) : (na - ebeg + ncha - 1) / ncha;
             const int estride = c < nchb ? 1 : ncha;
-            k1_chunk<MODE, real, 1>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, estride, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+            k1_chunk<MODE, real, (sizeof(real) == 4 ? BFGX_K1F_NP : 1)>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, estride, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
                                     lane, npairs);
 #if BFGX_K1F_PROF
             if (lane == 0) { const unsigned d = (unsigned)(PF_NOW() - pf_c0); atomicMax(&S.pf_maxchunk, d); pf_nchunk += 1; }
