@@ -727,8 +727,12 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     r.fb = 0; r._pad = 0;
     for (int q = 0; q < 4; ++q) { r.fb_ring[q] = 0; r.fb_k[q] = 0; }
     if (fallback4 && !bad && (r.rlast - r.rfirst) < 8) {
+        // (from the middle ring outwards -- mid, mid + 1, mid - 1, ... --: the longest rows come first, and a disc of 4 or more pixels is
+        // recognised after two rows instead of three or four from the edge; the slowest lane of a wave sets the trip count)
         int total = 0;
-        for (int ring = r.rfirst; ring <= r.rlast && total < 4; ++ring) {
+        const int span = r.rlast - r.rfirst, mid = (r.rfirst + r.rlast) >> 1;
+        for (int t = 0; t <= span && total < 4; ++t) {
+            const int ring = mid + ((t & 1) ? ((t + 1) >> 1) : -(t >> 1));
             RowSpan s;
             disc_row(h, ring, r.z0, r.xa, r.cosr, r.phi0, r.irmin, r.irmax, s);
             total += s.cnt;
