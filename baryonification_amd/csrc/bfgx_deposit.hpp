@@ -16,6 +16,7 @@
 //   deposit_tiles_kernel   workgroup per tile: LDS accumulate (ds_add_f64), store the tile
 #pragma once
 #include "bfgx_grid.hpp"
+#include <type_traits>
 
 namespace bfgx {
 
@@ -285,44 +286,54 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     }
 }
 
-// workgroup per tile: accumulate the tile's particles in LDS, store every cell of the tile once
+// workgroup per tile: accumulate the tile's particles in LDS, store every cell of the tile once.  Unit masses (MASS = false) are COUNTED:
+// 32-bit integer cells (ds_add_u32: 32 KB per tile instead of 64 KB of fp64 -- four workgroups of NT = 512 threads per CU instead of two of
+// 1024, half the zeroing and read-out), converted on the way out -- exact, like the fp64 sum of ones it replaces.
+#ifndef BFGX_DEP_TILE_NT
+#define BFGX_DEP_TILE_NT 512
+#endif
+template <bool MASS> struct DepTileThreads { static constexpr int n = MASS ? kDepTileThreads : BFGX_DEP_TILE_NT; };
 template <bool MASS>
-__global__ void __launch_bounds__(kDepTileThreads)
+__global__ void __launch_bounds__(DepTileThreads<MASS>::n)
 deposit_tiles_kernel(DepGeom g, const int32_t *__restrict__ start2, const uint32_t *__restrict__ keys, const double *__restrict__ mass,
                      double *__restrict__ out, double *__restrict__ out2, double *__restrict__ tile_sums)
 {
     // out2 / tile_sums (optional): a second copy of every cell and the tile's total -- what BaryonifyGrid's cell-owned pass starts from
     // (map_out = map_in, sum(map_in)), written here while the cell is in a register instead of by a pass over the finished map
-    __shared__ double acc[kDepTileCells];
+    constexpr int NT = DepTileThreads<MASS>::n;
+    using cell_t = typename std::conditional<MASS, double, uint32_t>::type;
+    __shared__ cell_t acc[kDepTileCells];
+    __shared__ double red[NT / kWave];
     const int tile = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < kDepTileCells; i += kDepTileThreads) acc[i] = 0.0;
+    for (int i = tid; i < kDepTileCells; i += NT) acc[i] = (cell_t)0;
     __syncthreads();
     const int s0 = start2[tile], s1 = start2[tile + 1];
-    for (int i = s0 + tid; i < s1; i += kDepTileThreads)
-        atomicAdd(acc + (keys[i] & (kDepTileCells - 1)), MASS ? mass[i] : 1.0);
+    for (int i = s0 + tid; i < s1; i += NT) {
+        if constexpr (MASS) atomicAdd(acc + (keys[i] & (kDepTileCells - 1)), mass[i]);
+        else atomicAdd(acc + (keys[i] & (kDepTileCells - 1)), 1u);
+    }
     __syncthreads();
     const int tz = tile % g.ntz, ty = (tile / g.ntz) % g.nty, tx = tile / (g.ntz * g.nty);
     const int x0 = tx * g.sx, y0 = ty * g.sy, z0 = tz * g.sz;
     double tsum = 0.0;
-    for (int l = tid; l < g.sx * g.sy * g.sz; l += kDepTileThreads) {
+    for (int l = tid; l < g.sx * g.sy * g.sz; l += NT) {
         const int lz = l & (g.sz - 1), ly = (l >> g.lsz) & (g.sy - 1), lx = l >> (g.lsz + g.lsy);
         const int bx = x0 + lx, by = y0 + ly, bz = z0 + lz;
         if (bx >= g.plane_n || by >= g.nb || (g.dim == 3 && bz >= g.nb)) continue;
         const int64_t flat = (g.dim == 3) ? ((int64_t)bx * g.nb + by) * g.nb + bz : (int64_t)bx * g.nb + by;
-        const double v = acc[l];
-        out[flat] = v;
+        const double v = (double)acc[l];
+        out[flat] = v;                                     // (non-temporal stores measured: this kernel 448 -> 487 us, the FFT's first pass 431 -> 417)
         if (out2) out2[flat] = v;
         tsum += v;
     }
     if (tile_sums) {
-        __syncthreads();                                   // acc is free: its first words hold the waves' partial sums
 #pragma unroll
         for (int sft = kWave >> 1; sft > 0; sft >>= 1) tsum += __shfl_down(tsum, sft, kWave);
-        if ((tid & (kWave - 1)) == 0) acc[tid / kWave] = tsum;
+        if ((tid & (kWave - 1)) == 0) red[tid / kWave] = tsum;
         __syncthreads();
         if (tid == 0) {
             double t = 0.0;
-            for (int w = 0; w < kDepTileThreads / kWave; ++w) t += acc[w];
+            for (int w = 0; w < NT / kWave; ++w) t += red[w];
             tile_sums[tile] = t;
         }
     }
