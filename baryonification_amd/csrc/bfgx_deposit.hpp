@@ -222,15 +222,15 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
     int cnt[kOwn], mine = 0;
 #pragma unroll
     for (int e = 0; e < kOwn; ++e) { cnt[e] = hist[tid * kOwn + e]; mine += cnt[e]; }
-    part[tid] = mine;
+    // (scan by shuffles inside the wave + the four wave totals through LDS: one barrier instead of the sixteen of a 256-entry Hillis-Steele scan)
+    const int lane_ = tid & (kWave - 1), wid_ = tid / kWave;
+    const int incl_ = wave_scan_incl(mine, lane_);
+    if (lane_ == kWave - 1) part[wid_] = incl_;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int a = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += a;
-        __syncthreads();
-    }
-    int pre = part[tid] - mine;
+    int wpre_ = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 256 / kWave; ++w) { const int pw = part[w]; total += pw; if (w < wid_) wpre_ += pw; }
+    int pre = wpre_ + incl_ - mine;
     int lpre[kOwn];
 #pragma unroll
     for (int e = 0; e < kOwn; ++e) { lpre[e] = pre; hist[tid * kOwn + e] = pre; pre += cnt[e]; }
@@ -260,7 +260,6 @@ deposit_split_kernel(DepGeom g, int64_t n_host, const int32_t *__restrict__ n_de
                                            : start[bmin + i] + atomicAdd(cursor + (int64_t)(bmin + i) * kDepPad, cnt[e])) - lpre[e];
     }
     __syncthreads();
-    const int total = part[255];
     for (int i = tid; i < total; i += 256) {
         const uint32_t k = skey[i];
         const int64_t dst = (int64_t)hist[dep_bucket<LEVEL>(g, k) - bmin] + i;

@@ -36,21 +36,25 @@ __device__ inline double block_excl_scan_sum(double v, double *sh /*[kTabThreads
     return r;
 }
 
+// (integers: shuffles inside the 64-lane wave, the 16 wave totals through LDS -- two barriers instead of the twenty-two of the scan above)
 __device__ inline int block_excl_scan_int(int v, int *sh, int &total)
 {
-    const int tid = threadIdx.x;
-    sh[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < kTabThreads; off <<= 1) {
-        const int u = (tid >= off) ? sh[tid - off] : 0;
-        __syncthreads();
-        sh[tid] += u;
-        __syncthreads();
+    constexpr int kW = 64;
+    const int tid = threadIdx.x, lane = tid & (kW - 1), wid = tid / kW;
+    int incl = v;
+#pragma unroll
+    for (int s = 1; s < kW; s <<= 1) {
+        const int u = __shfl_up(incl, s, kW);
+        if (lane >= s) incl += u;
     }
-    total = sh[kTabThreads - 1];
-    const int r = sh[tid] - v;
+    if (lane == kW - 1) sh[wid] = incl;
     __syncthreads();
-    return r;
+    int wpre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kTabThreads / kW; ++w) { const int pw = sh[w]; tot += pw; if (w < wid) wpre += pw; }
+    total = tot;
+    __syncthreads();                                    // (sh is the caller's to reuse)
+    return wpre + incl - v;
 }
 
 // ------------------------------------------------------------------ scipy PchipInterpolator
