@@ -89,7 +89,6 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
     // accumulators (ds_add_f64).
     using Blk = GatherBlk<DIM>;
     constexpr int S = Blk::S, CPT = Blk::per_thread;
-    constexpr int kRecWords = (int)(sizeof(GridHaloRec) / 4);
     __shared__ GridHaloRec R[kGatherBatch];
     __shared__ double oacc[Blk::cells * DIM];
     __shared__ uint16_t queue[kGatherBatch * Blk::cells];                // (halo of the batch << 12) | cell: cannot overflow

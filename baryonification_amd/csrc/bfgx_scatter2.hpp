@@ -937,7 +937,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
         ended = tile < 0;
         const int i0 = __builtin_amdgcn_readfirstlane(S.i0), i1 = __builtin_amdgcn_readfirstlane(S.i1);
         const int nphi = __builtin_amdgcn_readfirstlane(S.nphi), na = __builtin_amdgcn_readfirstlane(S.na);
-        const int ne = __builtin_amdgcn_readfirstlane(S.ne), csz = __builtin_amdgcn_readfirstlane(S.csz), nchb = __builtin_amdgcn_readfirstlane(S._pad);
+        const int ne = __builtin_amdgcn_readfirstlane(S.ne), nchb = __builtin_amdgcn_readfirstlane(S._pad);
         const int nchunks = (BFGX_ABL2 == 1 || tile < 0) ? 0 : __builtin_amdgcn_readfirstlane(S.nchunks);
         const int32_t *ea = reinterpret_cast<const int32_t *>(wave_uniform64((unsigned long long)S.ea));
         const int32_t *eb = reinterpret_cast<const int32_t *>(wave_uniform64((unsigned long long)S.eb));
