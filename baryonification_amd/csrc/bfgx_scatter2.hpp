@@ -216,7 +216,7 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     const int jj = t - (int)(rc.pk & 0xFFFu);
     const int rl = (int)((rc.pk >> 18) & 63u);
     o.la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);
-    const PairRecT<real> ph = pairs[(rc.pk >> 24) & 15u];
+    const PairRecT<real> ph = pairs[(rc.pk >> 24) & 31u];
     const RingC2<real> rg = ringc[rl];
     o.hidx = ph.hidx;
     const real x = fma_((real)jj, rg.dphi, rc.x0);
@@ -658,6 +658,9 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
 #ifndef BFGX_K1F_WAVES32
 #define BFGX_K1F_WAVES32 16
 #endif
+#ifndef BFGX_K1F_CSZ
+#define BFGX_K1F_CSZ kChunk2      // entries per chunk of a long list (<= kChunk2).  Measured, config 2: 10 / 12 / 14 / 16 entries 0.421 / 0.406 / 0.393 / 0.387 ms;
+#endif                            // BFGX_CHUNK2 = 18 / 20 (5 KB more LDS: the last that fits): 0.387 / 0.387 (config 3: 1.002 -> 0.987)
 #ifndef BFGX_K1F_NP
 #define BFGX_K1F_NP 1
 #endif
@@ -816,7 +819,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             // half chunks at the end of the list, measured slower.
             // Region B of the list (discs over more than kRefMax tiles: the large ones) goes out FIRST and in chunks of kChunkB entries, so that
             // the long items are not what the tile's waves finish on; then region A in chunks of csz.
-            S.ne = S.nx_ne; S.csz = S.nx_na >= kChunk2 * kWF / 2 ? kChunk2 : max(1, min(kChunk2, (S.nx_na + kWF - 1) / kWF));
+            S.ne = S.nx_ne; S.csz = S.nx_na >= kChunk2 * kWF / 2 ? BFGX_K1F_CSZ : max(1, min(kChunk2, (S.nx_na + kWF - 1) / kWF));
             // (painting: pairs are cheap, so a list of 128 - 384 entries is better cut into ~24 chunks than into 8 - 24 of sixteen entries --
             // config 3 lists 210 per tile: K3 1.058 -> 1.01 ms; the displacement kernel loses 2 % with the same rule)
             if (MODE == MODE_PAINT && S.nx_na >= kChunk2 * kWF / 2 && S.nx_na < 24 * kChunk2) S.csz = max(1, min(kChunk2, (S.nx_na + 23) / 24));
