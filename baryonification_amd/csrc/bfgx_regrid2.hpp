@@ -473,7 +473,10 @@ __device__ __noinline__ double regrid_far_pixel(
 // reach > 1).  PASS 1: the fall-back for an overflowing far list (every owner applies the deposits of its far pixels with
 // global atomics; runs after the map has been stored, does nothing unless the list overflowed).
 template <typename ACC, typename real, int PASS>
-__global__ void __launch_bounds__(256, 4)
+#ifndef BFGX_K2_OCC
+#define BFGX_K2_OCC 4             // waves per SIMD the regrid kernels are compiled for.  Measured, config 2 / S19 table (K2 in ms): 3: 0.240 / 0.514, 4: 0.201 / 0.354, 5: 0.228 / 0.412, 6: 0.261
+#endif
+__global__ void __launch_bounds__(256, BFGX_K2_OCC)
 tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
                     double *__restrict__ map_out, FarList far, ReachArgs reach, double *__restrict__ tile_sums, int tile_off, int ntiles,
                     int *__restrict__ todo, double *__restrict__ sums_out)
