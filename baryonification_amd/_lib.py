@@ -19,6 +19,18 @@ ABI_VERSION = 3        # include/bfgx.h BFGX_ABI_VERSION: 3 since bfgx_opts carr
 LIB_PATH = os.environ.get('BFGX_LIB', os.path.join(_HERE, 'csrc', 'libbfgx.so'))   # BFGX_LIB: ablation builds only
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS, ERR_ASSERT = 0, -1, -2, -3, -4, -5, -6
+# precision of the displacement path (include/bfgx.h BFGX_ACC_*)
+ACC_AUTO, ACC_F32, ACC_F64, ACC_PARITY = -1, 0, 1, 3
+
+
+def acc_mode(acc_f64):
+    """runner.acc_f64 -> BFGX_ACC_*: None / 'auto' = the plan chooses from the table, False = fp32 pair math, True = fp64 throughout,
+    'parity' / 3 = the parity-grade mode"""
+    if acc_f64 is None or acc_f64 == 'auto' or (acc_f64 is not True and acc_f64 is not False and acc_f64 == -1):
+        return ACC_AUTO
+    if acc_f64 == 'parity' or (acc_f64 is not True and acc_f64 == 3):
+        return ACC_PARITY
+    return ACC_F64 if bool(acc_f64) else ACC_F32
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -124,6 +136,7 @@ SYMBOLS = {
     'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_plan_set_algo': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_status': (C.c_int, [C.c_void_p]),
+    'bfgx_plan_precision': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     'bfgx_plan_regrid_stats': (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     'bfgx_plan_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_timing_read': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

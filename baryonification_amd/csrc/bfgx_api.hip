@@ -127,6 +127,12 @@ struct bfgx_plan {
     float *tile_omax = nullptr;      // largest |offset|^2 of every tile (K1's flush or tile_reach_kernel): the reach of the gathering regrid
     bool omax_from_k1 = false;       // set while a fused offsets + regrid call is in flight
     bool paint_pair_f32 = false;     // set while a paint call with acc_f64 = 2 is in flight: f32 pair math into the f64 map
+    // precision of the displacement path when the caller leaves it to the plan (BFGX_ACC_AUTO): chosen at plan creation from how far the
+    // TABLE can move a pixel (plan_pick_precision): fp32 pair math holds SURVEY 8(d)'s 1e-6 mean(map) while one halo moves a pixel by less
+    // than kAutoDispPixels; beyond that the parity-grade mode (BFGX_ACC_PARITY), or fp64 throughout where the fast kernel cannot take the table
+    int auto_acc = 0;
+    double table_disp_pixels = 0.0;  // largest |d| a / D_A of the table within its model-side cut, in pixel sides of this plan's NSIDE
+    float *offsets_lo = nullptr;     // set while a BFGX_ACC_PARITY call is in flight: the low halves of the split pix_offsets
     int k1_tile_lo = 0, k1_tile_n = -1;   // tiles K1 / K3 process (-1: the whole sphere); set by the *_bands_device entries
     int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
     int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
@@ -281,6 +287,16 @@ static int check_catalog(const bfgx_plan *p, const bfgx_catalog *c)
 
 static bool use_fast(const bfgx_plan *p) { return p->fast_ok && p->algo == 1; }
 
+// the precision a displacement call runs in: BFGX_ACC_AUTO -> what the plan chose from its table; BFGX_ACC_PARITY needs the fast tile kernel
+// (3-axis table, uniform ln r) with the wide discs in it and falls back to fp64 throughout (a superset of its accuracy) elsewhere
+static int resolve_acc(const bfgx_plan *p, int acc)
+{
+    if (acc == BFGX_ACC_AUTO) acc = p->auto_acc;
+    if (acc == BFGX_ACC_PARITY && !(use_fast(p) && p->k1_wide)) acc = BFGX_ACC_F64;
+    return acc;
+}
+static bool acc_valid(int acc) { return acc == BFGX_ACC_AUTO || acc == BFGX_ACC_F32 || acc == BFGX_ACC_F64 || acc == BFGX_ACC_PARITY; }
+
 // K0.  bin: also reserve the halo's slots in the tile entry lists; f64: precision of the fast kernel's pair records;
 // rec_all: write the full HaloRec of every halo (halo-centric kernels), otherwise only of the wide ones
 static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool bin, bool f64, bool rec_all)
@@ -387,12 +403,12 @@ static int launch_tile_scatter_nc(bfgx_plan *p, ACC *out, bool wide_only)
 }
 
 // fast kernel over the narrow-halo region of every tile (stores the tile)
-template <int MODE, typename ACC, typename real>
-static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
+template <int MODE, typename ACC, typename real, int PM = 0>
+static int launch_tile_scatter2(bfgx_plan *p, ACC *out, ACC *out_lo = nullptr)
 {
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
     const size_t lds = tile2_lds_bytes<real>(p->tiling.BR, p->tiling.W, NCOMP);
-    auto kern = tile_scatter2_kernel<MODE, ACC, real, BFGX_NP>;
+    auto kern = tile_scatter2_kernel<MODE, ACC, real, BFGX_NP, PM>;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     Tab8T<real> tb;
     tb.v = (sizeof(real) == 4) ? (const real *)p->tab8f : (const real *)p->tab8d;
@@ -425,13 +441,13 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
             form = p->k1_form;
         }
         if (forced || (eligible && (dense || form))) {
-            auto kf = tile_scatter2f_kernel<MODE, ACC, real>;
+            auto kf = tile_scatter2f_kernel<MODE, ACC, real, PM>;
             HIP_TRY(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf));
             const int gridf = std::min(ntodo, p->num_cus);
             hipLaunchKernelGGL(kf, dim3(std::max(gridf, 1)), dim3(kWave * FluidWaves<real>::n), ldsf, p->stream, tb, p->hpx, p->tiling,
                                (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                                (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
-                               (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, tile_counter,
+                               (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, out_lo, tile_counter,
                                (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
                                p->k1_tile_lo, p->k1_tile_n, p->overflow, (const int32_t *)form, 1);
             HIP_TRY(hipGetLastError());
@@ -442,7 +458,7 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWave * kW2), lds, p->stream, tb, p->hpx, p->tiling,
                        (const RowRec *)p->rowrec, (const PairRecT<real> *)p->pairrec, (const FbRec *)p->fbrec,
                        (const int32_t *)p->tile_start, (const int32_t *)(p->entries_a ? p->tile_count_pad : p->tile_count), (const int32_t *)p->tile_count_b,
-                       (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, p->pair_total, tile_counter,
+                       (const int32_t *)p->entries, p->capacity, (const int32_t *)p->entries_a, (int)p->entries_a_cap, (int)p->cnt_pad, out, out_lo, p->pair_total, tile_counter,
                        (MODE == MODE_OFFSETS && p->omax_from_k1) ? (unsigned int *)p->tile_omax : (unsigned int *)nullptr,
                        p->k1_tile_lo, p->k1_tile_n, (const int32_t *)form, 0);
     HIP_TRY(hipGetLastError());
@@ -455,6 +471,10 @@ static int launch_tile_scatter(bfgx_plan *p, ACC *out)
 {
     if (use_fast(p)) {
         using real = typename std::conditional<sizeof(ACC) == 8, double, float>::type;
+        if constexpr (MODE == MODE_OFFSETS && sizeof(ACC) == 4) {
+            // BFGX_ACC_PARITY: fp64 pair math (K0 wrote fp64 pair records) with the parity-grade functions, pix_offsets as two fp32 arrays
+            if (p->offsets_lo) return launch_tile_scatter2<MODE, ACC, double, 1>(p, out, (ACC *)p->offsets_lo);
+        }
         if constexpr (MODE == MODE_PAINT && sizeof(ACC) == 8) {
             // acc_f64 = 2: the pair phase in fp32 (K0 wrote fp32 pair records), LDS accumulation and the stored map in fp64
             if (p->paint_pair_f32) {
@@ -533,6 +553,49 @@ static void build_tiling(int64_t nside, bool paint, int &BR, int &W, std::vector
     tband.resize(tile0[nbands]);
     for (int b = 0; b < nbands; ++b)
         for (int t = tile0[b]; t < tile0[b + 1]; ++t) tband[t] = b;
+}
+
+
+// How far can this table move a pixel?  The largest |d(r)| a / D_A(z) over the table's (z, M) nodes within the model-side cut r < eps_model R
+// and the runner's disc, in pixel sides of the plan's NSIDE.  fp32 pair math carries ~4e-7 of every contribution, and the bilinear deposit turns
+// an error of e pixel sides in a source pixel's position into ~e of its value: 1e-6 mean(map) -- SURVEY 8(d)'s tolerance -- holds while a
+// halo moves a pixel by well under a pixel (measured: 2.4e-7 mean(map) at 0.2 pixels, 2.1e-5 at 20).  Beyond kAutoDispPixels the plan picks the
+// parity-grade mode.
+constexpr double kAutoDispPixels = 0.4;
+static void plan_pick_precision(bfgx_plan *p, const bfgx_model *model)
+{
+    const bfgx_table &t = model->table;
+    p->auto_acc = BFGX_ACC_F32;
+    p->table_disp_pixels = 0.0;
+    if (t.log_values) return;                                // a profile table: painting has its own modes
+    const Background bgr = make_background(model->cosmo_runner), bgm = make_background(model->cosmo_model);
+    const double pix = std::sqrt(4.0 * 3.14159265358979323846 / (double)p->hpx.npix);
+    const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2];
+    size_t nx = 1;
+    for (int d = 3; d < t.ndim; ++d) nx *= (size_t)t.n[d];
+    double worst = 0.0;
+    for (size_t iz = 0; iz < nz; ++iz) {
+        const double z = std::exp(t.axis[0][iz]) - 1.0, a = 1.0 / (1.0 + z);
+        const double D = z > 0.0 ? angular_diameter_distance(bgr, z) : 0.0;
+        for (size_t im = 0; im < nm; ++im) {
+            const double M = std::exp(t.axis[1][im]);
+            if (!(M > 0.0) || !(a > 0.0)) continue;
+            const double Rm = radius_delta(bgm, model->massdef_model, M, a) / a, Rr = radius_delta(bgr, model->massdef_runner, M, a) / a;
+            const double rcut = std::min(t.eps_model * Rm, model->eps_runner * Rr);          // comoving Mpc
+            for (size_t ir = 0; ir < nr; ++ir) {
+                const double r = std::exp(t.axis[2][ir]) * (t.rdelta_sampling ? Rm : 1.0);
+                double m = 0.0;
+                const double *v = t.values + ((iz * nm + im) * nr + ir) * nx;
+                for (size_t q = 0; q < nx; ++q) if (std::isfinite(v[q])) m = std::max(m, std::fabs(v[q]));
+                const double px = (D > 0.0) ? m * a / D / pix : (m > 0.0 ? 1.0e30 : 0.0);
+                worst = std::max(worst, px);
+                if (r >= rcut) break;                        // (the node that closes the interval holding the cut is the last that counts)
+            }
+        }
+    }
+    p->table_disp_pixels = worst;
+    if (worst > kAutoDispPixels) p->auto_acc = BFGX_ACC_PARITY;
+    if (const char *e = std::getenv("BFGX_AUTO_ACC")) { const int v = std::atoi(e); if (v == 0 || v == 1 || v == 3) p->auto_acc = v; }      // tests / A-B runs
 }
 
 }  // namespace
@@ -640,6 +703,7 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
 
     const bfgx_table &t = model->table;
     if (int rc = upload_model(p->owned, p->stream, model, true, p->model, p->NC)) return bail(rc);
+    plan_pick_precision(p, model);
     {
         void *d = nullptr;
         if (hipMalloc(&d, sizeof(HaloRec) * (size_t)(max_halos > 0 ? max_halos : 1)) != hipSuccess)
@@ -863,6 +927,15 @@ int bfgx_plan_status(bfgx_plan *p)
     return BFGX_OK;
 }
 
+int bfgx_plan_precision(bfgx_plan *p, int acc_requested, int32_t *acc_resolved, double *table_disp_pixels)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    if (!acc_valid(acc_requested)) return fail(BFGX_ERR_INVALID, "acc must be BFGX_ACC_AUTO (-1), 0 (f32), 1 (f64) or BFGX_ACC_PARITY (3)");
+    if (acc_resolved) *acc_resolved = resolve_acc(p, acc_requested);
+    if (table_disp_pixels) *table_disp_pixels = p->table_disp_pixels;
+    return BFGX_OK;
+}
+
 int bfgx_plan_bands(bfgx_plan *p, int32_t *nbands, int64_t *band_first_pixel)
 {
     if (!p || !nbands) return fail(BFGX_ERR_INVALID, "NULL argument");
@@ -927,10 +1000,15 @@ int bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings)
 
 // reset_far = false: the far-deposit list keeps what earlier calls have listed (the one-shot host entry regrids the sphere in several
 // band ranges while the map is still arriving, and applies one list at the end)
+// offsets_lo_dev != NULL: split pix_offsets (the parity-grade mode; the one-shot host entry), the low halves of the same pixels [olo, ohi);
+// otherwise acc_f64 says whether the one array is fp32 or fp64 (BFGX_ACC_PARITY / AUTO: as bfgx_offsets_bands_device resolves them)
 static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
-                             int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev, bool reset_far)
+                             int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev, bool reset_far,
+                             const float *offsets_lo_dev = nullptr)
 {
     if (!p) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
+    acc_f64 = offsets_lo_dev ? 0 : (resolve_acc(p, acc_f64) != BFGX_ACC_F32 ? 1 : 0);
     if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "banded regrid needs the tiled algorithm (algo 1)");
     int64_t need_lo = 0, need_hi = 0;
     if (int rc = bfgx_plan_band_apron(p, band0, band1, &need_lo, &need_hi)) return rc;
@@ -951,7 +1029,8 @@ static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const d
     const int t0 = p->band_tile0_host[band0], t1 = p->band_tile0_host[band1];
     {
         KernelTimer kt(p, BFGX_K_REGRID);
-        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, acc_f64 ? sizeof(double) : sizeof(float), p->band_reach > 1);
+        const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, (acc_f64 || offsets_lo_dev) ? sizeof(double) : sizeof(float), p->band_reach > 1,
+                                             offsets_lo_dev ? sizeof(float) : 0);
         // virtual bases: the kernel indexes every array by global pixel number
         double *out_base = out_slice_dev - p0;
         // every rank gathers with the same fixed reach (so that all of them classify a source pixel the same way)
@@ -961,18 +1040,24 @@ static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const d
         double *ts = sums_dev ? p->tile_sums : nullptr;
         const dim3 grid(t1 - t0), blk(256);
         int *none = nullptr;
-        if (acc_f64) {
+        if (offsets_lo_dev) {
+            const float *o = (const float *)offsets_dev - 3 * olo, *ol = offsets_lo_dev - 3 * olo;
+            if (p->band_reach == 1)
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, double, 0, true>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, ol, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
+            else
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, double, 2, true>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, ol, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
+        } else if (acc_f64) {
             const double *o = (const double *)offsets_dev - 3 * olo;
             if (p->band_reach == 1)
-                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
+                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, (decltype(o))nullptr, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
             else
-                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
+                hipLaunchKernelGGL((tile_regrid3_kernel<double, double, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, (decltype(o))nullptr, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
         } else {
             const float *o = (const float *)offsets_dev - 3 * olo;
             if (p->band_reach == 1)
-                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 0>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, (decltype(o))nullptr, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
             else
-                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
+                hipLaunchKernelGGL((tile_regrid3_kernel<float, float, 2>), grid, blk, lds, p->stream, p->hpx, p->tiling, map_in_dev, o, (decltype(o))nullptr, out_base, p->far, reach, ts, t0, t1 - t0, none, (double *)nullptr);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1059,10 +1144,18 @@ int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev
     if (int rc = check_catalog(p, cat)) return rc;
     if (!offsets_dev) return fail(BFGX_ERR_INVALID, "offsets pointer is NULL");
     if (p->model.tab.logv) return fail(BFGX_ERR_INVALID, "displacement read-out needs a table with log_values = 0");
+    if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 must be BFGX_ACC_AUTO (-1), 0 (f32), 1 (f64) or BFGX_ACC_PARITY (3)");
+    acc_f64 = resolve_acc(p, acc_f64);
     HIP_TRY(hipSetDevice(p->device));
     if (p->algo == 1) {      // tile-owned: every element of offsets is overwritten, no zero-fill needed
         if (int rc = launch_prep_and_bin(p, cat, 1, acc_f64 != 0)) return rc;
         if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
+        if (acc_f64 == BFGX_ACC_PARITY) {      // (resolve_acc: the fast kernel takes this table) hi [npix][3], then lo [npix][3]
+            p->offsets_lo = (float *)offsets_dev + 3 * (size_t)p->hpx.npix;
+            const int rc = launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)offsets_dev);
+            p->offsets_lo = nullptr;
+            return rc;
+        }
         if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)offsets_dev);
         return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)offsets_dev);
     }
@@ -1088,6 +1181,10 @@ static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, i
     p->k1_tile_lo = p->band_tile0_host[band0];
     p->k1_tile_n = p->band_tile0_host[band1] - p->k1_tile_lo;
     struct Reset { bfgx_plan *p; ~Reset() { p->k1_tile_lo = 0; p->k1_tile_n = -1; } } reset{p};
+    if (!paint) {        // the banded entries keep one array of pix_offsets: the parity-grade mode is served by fp64 throughout there
+        if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
+        acc_f64 = resolve_acc(p, acc_f64) != BFGX_ACC_F32 ? 1 : 0;
+    }
     if (acc_f64 < 0 || acc_f64 > (paint ? 2 : 1)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
     const bool mixed = paint && acc_f64 == 2 && use_fast(p);
     if (int rc = launch_prep_and_bin(p, cat, paint ? 0 : 1, acc_f64 != 0 && !mixed)) return rc;
@@ -1140,7 +1237,7 @@ int bfgx_max_offset2_device(bfgx_plan *p, const void *offsets_dev, int64_t npixe
     HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), p->stream));
     if (npixels > 0) {
         const unsigned grid = (unsigned)std::min<int64_t>((npixels + 255) / 256, 1024);
-        if (acc_f64) hipLaunchKernelGGL(max_offset_kernel<double>, dim3(grid), dim3(256), 0, p->stream, npixels, (const double *)offsets_dev, (unsigned *)out_dev);
+        if (acc_valid(acc_f64) && resolve_acc(p, acc_f64) != BFGX_ACC_F32) hipLaunchKernelGGL(max_offset_kernel<double>, dim3(grid), dim3(256), 0, p->stream, npixels, (const double *)offsets_dev, (unsigned *)out_dev);
         else hipLaunchKernelGGL(max_offset_kernel<float>, dim3(grid), dim3(256), 0, p->stream, npixels, (const float *)offsets_dev, (unsigned *)out_dev);
         HIP_TRY(hipGetLastError());
     }
@@ -1279,10 +1376,11 @@ int bfgx_paint_device(bfgx_plan *p, const bfgx_catalog *cat, void *map_out_dev, 
 
 // the gathering regrid (algo 1): [largest |offset|^2 per tile unless K1 left it], aprons, lean gather, gather with the ring
 // walk over the tiles that need it, far list / repair
-template <typename ACC, typename real>
-static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const ACC *o, double *map_out_dev, double *ts, bool from_k1, double *sums_dev)
+template <typename ACC, typename real, bool SPLIT = false>
+static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const ACC *o, const ACC *o_lo, double *map_out_dev, double *ts, bool from_k1, double *sums_dev)
 {
-    const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real)), lds_walk = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real), true);
+    const size_t lds = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real)),
+                 lds_walk = regrid3_lds_bytes(p->tiling.BR, p->tiling.W, sizeof(real), true, SPLIT ? sizeof(ACC) : sizeof(real));
     FarList far = p->far;
     far.overflow = p->far_overflow_full;
     const int nt = p->tiling.ntiles, nfix = std::min(nt, 2 * p->num_cus), nwalk = std::min(nt, 4 * p->num_cus);
@@ -1291,14 +1389,14 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
         hipLaunchKernelGGL(tile_reach_kernel<ACC>, dim3(nt), dim3(256), 0, p->stream, p->hpx, p->tiling, o, p->tile_omax);
     hipLaunchKernelGGL(tile_apron_kernel, dim3((nt + 255) / 256), dim3(256), 0, p->stream, p->hpx, p->tiling, (const float *)p->tile_omax, 0,
                        reach.cap, 0, nt, p->tile_apron, p->regrid_todo);
-    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0>), dim3(nt), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0, SPLIT>), dim3(nt), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
-    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2>), dim3(nwalk), dim3(256), lds_walk, p->stream, p->hpx, p->tiling, map_in_dev, o,
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2, SPLIT>), dim3(nwalk), dim3(256), lds_walk, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
     // the two sums of the mass check: added up by the last launch, or -- above 16384 tiles, where that single workgroup's loop
     // takes 0.2 - 0.6 ms -- by 64 workgroups afterwards
     const bool many = nt > 16384 && sums_dev != nullptr && ts != nullptr;
-    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 1>), dim3(nfix), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o,
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 1, SPLIT>), dim3(nfix), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, many ? (double *)nullptr : sums_dev);
     if (many) {
         (void)hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream);
@@ -1314,6 +1412,8 @@ static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offse
                        bool from_k1)
 {
     if (!p || !map_in_dev || !offsets_dev || !map_out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 must be BFGX_ACC_AUTO (-1), 0 (f32), 1 (f64) or BFGX_ACC_PARITY (3)");
+    acc_f64 = resolve_acc(p, acc_f64);
     HIP_TRY(hipSetDevice(p->device));
     {
     KernelTimer kt(p, BFGX_K_REGRID);
@@ -1323,8 +1423,11 @@ static int regrid_impl(bfgx_plan *p, const double *map_in_dev, const void *offse
         // entries, overflow, tiles left to the walking kernel (the fused call's binning step has zeroed them with its counters)
         if (!from_k1) HIP_TRY(hipMemsetAsync(p->far.count, 0, 4 * sizeof(int32_t), p->stream));
         double *ts = sums_dev ? p->tile_sums : nullptr;
-        if (acc_f64) launch_regrid_gather<double, double>(p, map_in_dev, (const double *)offsets_dev, map_out_dev, ts, from_k1, sums_dev);
-        else launch_regrid_gather<float, float>(p, map_in_dev, (const float *)offsets_dev, map_out_dev, ts, from_k1, sums_dev);
+        if (acc_f64 == BFGX_ACC_PARITY)      // pix_offsets as two fp32 arrays (hi, then lo behind the npix high triples), fp64 geometry
+            launch_regrid_gather<float, double, true>(p, map_in_dev, (const float *)offsets_dev, (const float *)offsets_dev + 3 * (size_t)p->hpx.npix,
+                                                      map_out_dev, ts, from_k1, sums_dev);
+        else if (acc_f64) launch_regrid_gather<double, double>(p, map_in_dev, (const double *)offsets_dev, (const double *)nullptr, map_out_dev, ts, from_k1, sums_dev);
+        else launch_regrid_gather<float, float>(p, map_in_dev, (const float *)offsets_dev, (const float *)nullptr, map_out_dev, ts, from_k1, sums_dev);
     } else {
         const unsigned grid = (unsigned)((p->hpx.npix + 255) / 256);
         if (acc_f64)
@@ -1730,6 +1833,7 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     std::memset(&o, 0, sizeof(o));
     o.check_mass = 1;
     o.algo = 1;
+    o.acc_offsets_f64 = BFGX_ACC_AUTO;
     if (opts) o = *opts;
     if (o.algo != 0 && o.algo != 1) return fail(BFGX_ERR_INVALID, "opts.algo must be 0 or 1");
     if (cat->n < 0) return fail(BFGX_ERR_INVALID, "catalog size < 0");
@@ -1743,7 +1847,10 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
     drain.s[0] = &p->stream; drain.s[1] = &e->copy_stream; drain.s[2] = &e->out_stream; drain.null_stream = (p->stream == nullptr);
 
     const size_t npix = (size_t)p->hpx.npix;
-    const size_t acc_bytes = npix * 3 * (o.acc_offsets_f64 ? sizeof(double) : sizeof(float));
+    if (!acc_valid(o.acc_offsets_f64)) return fail(BFGX_ERR_INVALID, "opts.acc_offsets_f64 must be BFGX_ACC_AUTO (-1), 0 (f32), 1 (f64) or BFGX_ACC_PARITY (3)");
+    const int acc = resolve_acc(p, o.acc_offsets_f64);       // (BFGX_ACC_AUTO: what the plan chose from the model's table)
+    const bool off_split = (acc == BFGX_ACC_PARITY);         // pix_offsets as two fp32 arrays: hi [npix][3], then lo [npix][3]
+    const size_t acc_bytes = npix * 3 * (acc != BFGX_ACC_F32 ? sizeof(double) : sizeof(float));
     std::vector<double> hostlog;
     bfgx_catalog dcat;
     if (!e->copy_stream) {
@@ -1761,7 +1868,7 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
         HIP_TRY(hipMemsetAsync(e->out.p, 0, npix * sizeof(double), p->stream));
     }
     p->omax_from_k1 = (o.algo == 1);                         // K1's flush leaves the largest |offset|^2 of every tile for K2's aprons
-    const int rc_off = bfgx_offsets_device(p, &dcat, e->off.p, o.acc_offsets_f64);
+    const int rc_off = bfgx_offsets_device(p, &dcat, e->off.p, acc);
     p->omax_from_k1 = false;
     if (rc_off) return rc_off;
     double sums[2] = {0, 0};
@@ -1834,8 +1941,9 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
                     if (need >= sent) break;
                     HIP_TRY(hipStreamWaitEvent(p->stream, e->ev_in[need], 0));
                     const int64_t lo = bfp[cb[next]], n = bfp[cb[next + 1]] - lo;
-                    if (int rc = regrid_bands_impl(p, cb[next], cb[next + 1], (const double *)e->in.p, e->off.p, 0, (int64_t)npix, o.acc_offsets_f64,
-                                                   (double *)e->out.p + lo, dsums + 2 * next, next == 0)) return rc;
+                    if (int rc = regrid_bands_impl(p, cb[next], cb[next + 1], (const double *)e->in.p, e->off.p, 0, (int64_t)npix, acc,
+                                                   (double *)e->out.p + lo, dsums + 2 * next, next == 0,
+                                                   off_split ? (const float *)e->off.p + 3 * npix : nullptr)) return rc;
                     HIP_TRY(hipEventRecord(e->ev_k2[next], p->stream));
                     HIP_TRY(hipStreamWaitEvent(e->out_stream, e->ev_k2[next], 0));
                     HIP_TRY(hipMemcpyAsync(map_out + lo, (double *)e->out.p + lo, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->out_stream));
@@ -1882,7 +1990,7 @@ int bfgx_baryonify_shell(const bfgx_catalog *cat, const bfgx_model *model, int64
         if (!whole_map_sent) HIP_TRY(hipMemcpyAsync(e->in.p, map_in, npix * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
         HIP_TRY(hipEventRecord(e->ev[1], e->copy_stream));
         HIP_TRY(hipStreamWaitEvent(p->stream, e->ev[1], 0));
-        if (int rc = regrid_impl(p, (const double *)e->in.p, e->off.p, o.acc_offsets_f64, (double *)e->out.p, (double *)e->sums.p, o.algo == 1)) return rc;
+        if (int rc = regrid_impl(p, (const double *)e->in.p, e->off.p, acc, (double *)e->out.p, (double *)e->sums.p, o.algo == 1)) return rc;
         HIP_TRY(hipEventRecord(e->ev[2], p->stream));
         HIP_TRY(hipMemcpyAsync(map_out, e->out.p, npix * sizeof(double), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipMemcpyAsync(sums, e->sums.p, sizeof(sums), hipMemcpyDeviceToHost, p->stream));

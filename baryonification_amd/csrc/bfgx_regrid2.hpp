@@ -26,6 +26,26 @@ struct alignas(16) RegRowC {
     real c0, s0;                          // cos / sin of the azimuth of the tile's first pixel (ks) in this ring
     real inv_dth_up, inv_dth_dn;          // 1 / (theta_r - theta_{r-1}), 1 / (theta_{r+1} - theta_r); 0 where there is no such ring
 };
+// fp64 geometry reads the first six from the fp64 ring table itself (RegRow): only the two spacings are kept beside it -- 3 KB of LDS less per
+// workgroup, which is what lets FOUR workgroups of the walking kernel share a CU with split fp32 pix_offsets (42.9 -> 39.7 KB each; three: K2 0.62 ms)
+template <>
+struct alignas(16) RegRowC<double> { double inv_dth_up, inv_dth_dn; };
+// what the per-pixel code needs of one ring, in the precision of the geometry
+template <typename real> struct RowGeom { real z, sth, dphi, inv_dphi, c0, s0, inv_dth_up, inv_dth_dn; };
+__device__ inline RowGeom<float> row_geom(const RegRow *, const RegRowC<float> *rowc, int t)
+{
+    const RegRowC<float> c = rowc[t];
+    return RowGeom<float>{c.z, c.sth, c.dphi, c.inv_dphi, c.c0, c.s0, c.inv_dth_up, c.inv_dth_dn};
+}
+__device__ inline RowGeom<double> row_geom(const RegRow *rows, const RegRowC<double> *rowc, int t)
+{
+    const RegRow &r = rows[t];
+    const RegRowC<double> c = rowc[t];
+    return RowGeom<double>{r.z, r.sth, r.dphi, r.inv_dphi, r.c0, r.s0, c.inv_dth_up, c.inv_dth_dn};
+}
+__device__ inline float row_inv_dphi(const RegRow *, const RegRowC<float> *rowc, int t) { return rowc[t].inv_dphi; }
+__device__ inline double row_inv_dphi(const RegRow *rows, const RegRowC<double> *, int t) { return rows[t].inv_dphi; }
+__host__ __device__ inline size_t regrowc_bytes(size_t real_size) { return real_size == 4 ? sizeof(RegRowC<float>) : sizeof(RegRowC<double>); }
 
 // the 4 targets of one displaced pixel by the generic route: get_interpol (healpix_cxx) on (theta, phi) of v + o, fp64
 __device__ inline void regrid_targets_generic(const Hpx &h, const RegRow *rows, int LR, int rth0, int ti, int x,
@@ -129,6 +149,27 @@ template <> struct RMath<double> {
     static __device__ inline double atan_(double t) { return atan_small(t); }
 };
 
+// the parity-grade mode (SPLIT pix_offsets): the same small-angle pieces to ~1e-11 -- fp32 hardware seeds + one Newton step, series cut at the
+// bounds of a gathered pixel (|e| <= 0.045, t^2 <= 0.01, |q| <= 0.021, |t| <= 0.1).  A displaced position is needed to ~1e-7 of a pixel side at
+// displacements of up to 20: 5e-9 of the offset.
+struct RMathE {
+    static __device__ inline double rcp(double x) { const double y = (double)__builtin_amdgcn_rcpf((float)x); return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y); }
+    static __device__ inline double inv_norm(double e)
+    {
+        const double x = 1.0 + e, y = (double)__builtin_amdgcn_rsqf((float)x);
+        const double h = 0.5 * y, r = __builtin_fma(-x * y, h, 0.5);
+        return __builtin_fma(y, r, y);
+    }
+    // sqrt(1 + t^2) - 1 = t^2/2 - t^4/8 + t^6/16 - 5 t^8/128 + 7 t^10/256
+    static __device__ inline double sqrt1pm1(double t2) { return t2 * __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(t2, 7.0 / 256.0, -5.0 / 128.0), 0.0625), -0.125), 0.5); }
+    static __device__ inline double asin_(double q) { const double q2 = q * q; return q * __builtin_fma(q2, __builtin_fma(q2, __builtin_fma(q2, 15.0 / 336.0, 0.075), 1.0 / 6.0), 1.0); }
+    static __device__ inline double atan_(double t)
+    {
+        const double t2 = t * t;
+        return t * __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(t2, -1.0 / 11.0, 1.0 / 9.0), -1.0 / 7.0), 0.2), -1.0 / 3.0), 1.0);
+    }
+};
+
 // ---------------------------------------------------------------------------------- K2, gathering form (full-map regrid)
 // Every OUTPUT pixel is the property of one workgroup: a tile evaluates the displaced position of its own pixels AND of the
 // pixels in an apron around it, keeps only the deposits that land inside the tile (LDS), and stores the tile once with plain
@@ -201,11 +242,14 @@ struct ReachArgs {
 // wave a second queue for its own pixels that take the generic route, per ring of the window two thresholds of the scan
 constexpr int kWalkQ = 128;         // entries per wave: a wave pushes at most 64 onto fewer than 64
 constexpr int kWalkFar = (256 / kWave) * kWalkQ;      // per wave a second queue of kWalkQ positions: its own pixels that take the generic route
-__host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size, bool walk = false)
+// real_size: the type of the per-pixel geometry (ring tables); acc_size: the type pix_offsets are stored in (the walking kernel's queue holds
+// the offsets as they were read: with split fp32 pix_offsets + fp64 geometry the low halves are fetched when a survivor is evaluated)
+__host__ __device__ inline size_t regrid3_lds_bytes(int BR, int W, size_t real_size, bool walk = false, size_t acc_size = 0)
 {
-    const size_t base = (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + 8 * real_size) + 16;
+    if (acc_size == 0) acc_size = real_size;
+    const size_t base = (size_t)BR * W * sizeof(double) + (size_t)(BR + 2 * kReachMax + 2) * (sizeof(RegRow) + regrowc_bytes(real_size)) + 16;
     if (!walk) return base;
-    return base + (size_t)(BR + 2 * kReachMax + 2) * sizeof(RowScan) + (size_t)(256 / kWave) * kWalkQ * (sizeof(double) + sizeof(int32_t) + 3 * real_size)
+    return base + (size_t)(BR + 2 * kReachMax + 2) * sizeof(RowScan) + (size_t)(256 / kWave) * kWalkQ * (sizeof(double) + sizeof(int32_t) + 3 * acc_size)
            + (size_t)(kWalkFar + 4) * sizeof(int32_t);
 }
 
@@ -342,11 +386,13 @@ max_bits_kernel(int n, const unsigned *__restrict__ v, unsigned *__restrict__ ou
 // column) + weight.  The pixel must be a gathered one (see above).  Returns false
 // when the move leaves the ring tables (then no target lies in the tile).  x = column of the pixel relative to the tile's
 // first pixel of its ring (negative / beyond the tile for apron pixels).
-template <typename real, bool WALK>
+template <typename real, bool WALK, bool ECON = false>
 __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<real> *rowc, int NT, int ti, int x,
                                              real o0, real o1, real o2, int tt[4], int tk[4], real w[4])
 {
-    const RegRowC<real> rc = rowc[ti];
+    using RM = typename std::conditional<ECON, RMathE, RMath<real>>::type;
+    using PMx = typename std::conditional<ECON, PMathE, PMath<real>>::type;
+    const RowGeom<real> rc = row_geom(rows, rowc, ti);
     const RegRow &rw = rows[ti];
     // cos / sin of the pixel's azimuth: rotation of the tile's first pixel by x dphi (series), or Cody-Waite in fp64
     // where the tile spans more than 0.45 rad (polar bands)
@@ -354,7 +400,7 @@ __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<r
     const real alpha = (real)x * rc.dphi;
     if (abs_(alpha) <= (real)0.45) {
         real sa, oma;
-        PMath<real>::sin_omc(alpha, sa, oma);
+        PMx::sin_omc(alpha, sa, oma);
         c = rc.c0 - (rc.c0 * oma + rc.s0 * sa);
         s = rc.s0 - (rc.s0 * oma - rc.c0 * sa);
     } else {
@@ -364,13 +410,13 @@ __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<r
     }
     const real a = o0 * c + o1 * s, b = o1 * c - o0 * s;               // in-plane radial / azimuthal components of the offset
     const real xr = rc.sth + a;
-    const real t = b * RMath<real>::rcp(xr);
+    const real t = b * RM::rcp(xr);
     const real t2 = t * t;
     const real e = (real)2 * (rc.sth * a + rc.z * o2) + (a * a + b * b + o2 * o2);       // |v + o|^2 = 1 + e
-    const real invn = RMath<real>::inv_norm(e);
-    const real q = (fma_(a, rc.z, -(o2 * rc.sth)) + xr * rc.z * RMath<real>::sqrt1pm1(t2)) * invn;      // sin(theta_new - theta)
-    const real dth = RMath<real>::asin_(q);
-    const real dph = RMath<real>::atan_(t);
+    const real invn = RM::inv_norm(e);
+    const real q = (fma_(a, rc.z, -(o2 * rc.sth)) + xr * rc.z * RM::sqrt1pm1(t2)) * invn;      // sin(theta_new - theta)
+    const real dth = RM::asin_(q);
+    const real dph = RM::atan_(t);
     // ring above (t1) / below (t1 + 1) the new colatitude and the weight of the lower one
     const bool down = dth >= (real)0;
     const real wq = down ? dth * rc.inv_dth_dn : -dth * rc.inv_dth_up;      // fraction of the ring spacing moved
@@ -403,7 +449,7 @@ __device__ inline bool regrid_gather_targets(const RegRow *rows, const RegRowC<r
         const RegRow &rn = rows[tr];
         const double B = ((double)kown + (rw.shf ? 0.5 : 0.0)) * ((double)rn.nr * rw.dphi * kInvTwoPi) - (rn.shf ? 0.5 : 0.0);
         const double Bf = floor(B);
-        const real wall = (real)(B - Bf) + dph * rowc[tr].inv_dphi, f = __builtin_floor(wall);
+        const real wall = (real)(B - Bf) + dph * row_inv_dphi(rows, rowc, tr), f = __builtin_floor(wall);
         wj = wall - f; j = (int)Bf + (int)f;
     };
     const bool nr_ = !WALK || near;
@@ -472,18 +518,21 @@ __device__ __noinline__ double regrid_far_pixel(
 // ring walk compiled in, which a small persistent grid runs over that list (or over all tiles: banded regrid with a fixed
 // reach > 1).  PASS 1: the fall-back for an overflowing far list (every owner applies the deposits of its far pixels with
 // global atomics; runs after the map has been stored, does nothing unless the list overflowed).
-template <typename ACC, typename real, int PASS>
+// SPLIT (the parity-grade mode): pix_offsets are two fp32 arrays, offsets = hi and offsets_lo = (float)(o - hi), indexed alike; the scan decides on
+// hi alone (its thresholds are fp32 comparisons anyway), a survivor's low halves are fetched when it is evaluated -- in fp64 (real = double)
+template <typename ACC, typename real, int PASS, bool SPLIT = false>
 #ifndef BFGX_K2_OCC
 #define BFGX_K2_OCC 4             // waves per SIMD the regrid kernels are compiled for.  Measured, config 2 / S19 table (K2 in ms): 3: 0.240 / 0.514, 4: 0.201 / 0.354, 5: 0.228 / 0.412, 6: 0.261
 #endif
 __global__ void __launch_bounds__(256, BFGX_K2_OCC)
-tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets,
+tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets, const ACC *__restrict__ offsets_lo,
                     double *__restrict__ map_out, FarList far, ReachArgs reach, double *__restrict__ tile_sums, int tile_off, int ntiles,
                     int *__restrict__ todo, double *__restrict__ sums_out)
 {
     // map_in, offsets and map_out are indexed by GLOBAL pixel number.  tile_off < 0: all tiles, heavy ones first; tile_off >= 0
     // (a rank that owns a range of bands): tiles tile_off + blockIdx.x, and the caller passes offsets / map_out pointers
     // shifted so that only the pixels this rank holds (its bands + reach.rings rings either side / its bands) are touched.
+    static_assert(!SPLIT || (sizeof(ACC) == 4 && sizeof(real) == 8), "split pix_offsets: fp32 halves, fp64 geometry");
     extern __shared__ __align__(16) unsigned char smem[];
     const int NTmax = T.BR + 2 * kReachMax + 2;
     double *acc = reinterpret_cast<double *>(smem);            // [BR][W]: the tile's own pixels
@@ -589,8 +638,10 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     if (tid < NT) {
         const RegRow &rw = rows[tid];
         RegRowC<real> rc;
-        rc.z = (real)rw.z; rc.sth = (real)rw.sth; rc.dphi = (real)rw.dphi; rc.inv_dphi = (real)rw.inv_dphi;
-        rc.c0 = (real)rw.c0; rc.s0 = (real)rw.s0;
+        if constexpr (sizeof(real) == 4) {
+            rc.z = (real)rw.z; rc.sth = (real)rw.sth; rc.dphi = (real)rw.dphi; rc.inv_dphi = (real)rw.inv_dphi;
+            rc.c0 = (real)rw.c0; rc.s0 = (real)rw.s0;
+        }
         rc.inv_dth_up = (real)0; rc.inv_dth_dn = (real)0;
         if (rw.nr > 0) {
             if (tid > 0 && rows[tid - 1].nr > 0) rc.inv_dth_up = (real)(1.0 / (rw.theta - rows[tid - 1].theta));
@@ -641,10 +692,11 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     }
     const int LWs = maxspan + 2 * kap;
     const unsigned inv_lws = (unsigned)((0x100000000ull + (unsigned)LWs - 1u) / (unsigned)LWs);      // idx / LWs for idx < 2^16
-    struct Src { int ti, x; bool ok, own; double val; ACC o0, o1, o2; };
+    using OT = typename std::conditional<SPLIT, double, ACC>::type;      // a source pixel's offset as the lean / repair passes hold it
+    struct Src { int ti, x; bool ok, own; double val; OT o0, o1, o2; float hsq; };      // (hsq: |hi|^2 in fp32, what SPLIT classes a pixel by -- as the scan does)
     auto fetch = [&](int idx) {
         Src sx;
-        sx.ok = false; sx.own = false; sx.ti = 0; sx.x = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (ACC)0;
+        sx.ok = false; sx.own = false; sx.ti = 0; sx.x = 0; sx.val = 0.0; sx.o0 = sx.o1 = sx.o2 = (OT)0; sx.hsq = 0.0f;
         if (idx < NR * LWs) {
             const int r = (int)__umulhi((unsigned)idx, inv_lws), x = idx - r * LWs - kap;
             const RegRow &rw = rows[r + 1];
@@ -659,7 +711,14 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 if (PASS != 1 || sx.own) {
                     sx.ok = true; sx.ti = r + 1; sx.x = x;
                     sx.val = map_in[p];
+                    if (SPLIT) {
+                        const ACC h0 = offsets[3 * p + 0], h1 = offsets[3 * p + 1], h2 = offsets[3 * p + 2];
+                        const ACC l0 = offsets_lo[3 * p + 0], l1 = offsets_lo[3 * p + 1], l2 = offsets_lo[3 * p + 2];
+                        sx.o0 = (OT)((double)h0 + (double)l0); sx.o1 = (OT)((double)h1 + (double)l1); sx.o2 = (OT)((double)h2 + (double)l2);
+                        sx.hsq = (float)fma_(h0, h0, fma_(h1, h1, h2 * h2));
+                    } else {
                     sx.o0 = offsets[3 * p + 0]; sx.o1 = offsets[3 * p + 1]; sx.o2 = offsets[3 * p + 2];
+                    }
                 }
             }
         }
@@ -675,16 +734,26 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         const RowScan *scan = reinterpret_cast<const RowScan *>(rowc + NTmax);
         int32_t *nfar = reinterpret_cast<int32_t *>(const_cast<RowScan *>(scan) + NTmax), *farq = nfar + 4;
         double *qval = reinterpret_cast<double *>(farq + kWalkFar) + wid * kWalkQ;
-        real *qo = reinterpret_cast<real *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ) + wid * 3 * kWalkQ;
-        int32_t *qpos = reinterpret_cast<int32_t *>(reinterpret_cast<real *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ)
+        using QT = typename std::conditional<SPLIT, ACC, real>::type;          // the queue holds the offsets as read (SPLIT: the high halves)
+        QT *qo = reinterpret_cast<QT *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ) + wid * 3 * kWalkQ;
+        int32_t *qpos = reinterpret_cast<int32_t *>(reinterpret_cast<QT *>(reinterpret_cast<double *>(farq + kWalkFar) + (256 / kWave) * kWalkQ)
                                                     + (256 / kWave) * 3 * kWalkQ) + wid * kWalkQ;
         const float colslack = 2.5f + (float)nrmax / (float)nrmin;
         const int nown = i1 - i0, total = NR * LWs;
-        auto deposit = [&](int ti, int x, real o0, real o1, real o2, double val) {
+        auto deposit = [&](int ti, int x, QT q0, QT q1, QT q2, double val) {
             int tt[4], tk[4];
             real w[4];
             if (BFGX_ABLK2 == 1) return;
-            if (!regrid_gather_targets<real, true>(rows, rowc, NT, ti, x, o0, o1, o2, tt, tk, w)) return;
+            real o0 = (real)q0, o1 = (real)q1, o2 = (real)q2;
+            if (SPLIT) {                                                       // the low halves of this survivor (its pixel from the ring table)
+                const RegRow &rs_ = rows[ti];
+                int k = rs_.ks + x;
+                k += (k < 0) ? rs_.nr : 0;
+                k -= (k >= rs_.nr) ? rs_.nr : 0;
+                const int64_t p = rs_.start + k;
+                o0 += (real)offsets_lo[3 * p + 0]; o1 += (real)offsets_lo[3 * p + 1]; o2 += (real)offsets_lo[3 * p + 2];
+            }
+            if (!regrid_gather_targets<real, true, SPLIT>(rows, rowc, NT, ti, x, o0, o1, o2, tt, tk, w)) return;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
                 const int rr = tt[q4] - (R + 1);
@@ -705,7 +774,9 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             if (k < 0) k += rw.nr;
             if (k >= rw.nr) k -= rw.nr;
             const int64_t p = rw.start + k;
-            sum_out += regrid_far_pixel(h, rows, NT - 2, rth0, ti, x, (double)offsets[3 * p + 0], (double)offsets[3 * p + 1], (double)offsets[3 * p + 2], map_in[p], far);
+            double f0 = (double)offsets[3 * p + 0], f1 = (double)offsets[3 * p + 1], f2 = (double)offsets[3 * p + 2];
+            if (SPLIT) { f0 += (double)offsets_lo[3 * p + 0]; f1 += (double)offsets_lo[3 * p + 1]; f2 += (double)offsets_lo[3 * p + 2]; }
+            sum_out += regrid_far_pixel(h, rows, NT - 2, rth0, ti, x, f0, f1, f2, map_in[p], far);
         };
         int32_t *fq = farq + wid * kWalkQ;
         int fn = 0;                                                            // entries in this wave's queue of generic-route pixels
@@ -739,10 +810,10 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             for (int u = 0; u < U; ++u) {                                      // the two thresholds
                 const int x = cx[u];
                 if (cown[u]) sum_in += cval[u];
-                const real o0 = (real)ca0[u], o1 = (real)ca1[u], o2 = (real)ca2[u];
-                const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
+                const QT o0 = (QT)ca0[u], o1 = (QT)ca1[u], o2 = (QT)ca2[u];
+                const QT osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
                 const bool live = cin[u] && cval[u] > 0.0;                     // HealpixRunner.py:335
-                const bool gathered = osq < (real)clim2[u];
+                const bool gathered = osq < (QT)clim2[u];
                 const int dc = x < 0 ? -x : (x >= cspan[u] ? x - cspan[u] + 1 : 0);
                 const float g = (float)dc - colslack, of = (float)osq;
                 const bool reaches = cown[u] || (of >= cneed2[u] && (g <= 0.0f || of * ccf2[u] >= g * g));
@@ -755,7 +826,7 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
                 if (m == 0ull) continue;                                       // (wave-uniform)
                 if (cpush[u]) {
                     const int sl = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    qval[sl] = cval[u]; qo[sl] = (real)ca0[u]; qo[kWalkQ + sl] = (real)ca1[u]; qo[2 * kWalkQ + sl] = (real)ca2[u]; qpos[sl] = cpos[u];
+                    qval[sl] = cval[u]; qo[sl] = (QT)ca0[u]; qo[kWalkQ + sl] = (QT)ca1[u]; qo[2 * kWalkQ + sl] = (QT)ca2[u]; qpos[sl] = cpos[u];
                 }
                 qn += __popcll(m);
                 __builtin_amdgcn_wave_barrier();
@@ -792,12 +863,13 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
         const double val = cur.val;
         const real o0 = (real)cur.o0, o1 = (real)cur.o1, o2 = (real)cur.o2;
         const real osq = fma_(o0, o0, fma_(o1, o1, o2 * o2));
-        const bool gathered = (double)osq < rows[cur.ti].lim2;
+        // (whether a pixel is gathered is decided by the same arithmetic in every pass: SPLIT -- fp32 on the high halves, as the scan)
+        const bool gathered = SPLIT ? (cur.hsq < (float)rows[cur.ti].lim2) : ((double)osq < rows[cur.ti].lim2);
         if (gathered) {
             if (PASS == 1) return;
             int tt[4], tk[4];
             real w[4];
-            if (!regrid_gather_targets<real, false>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) return;
+            if (!regrid_gather_targets<real, false, SPLIT>(rows, rowc, NT, cur.ti, cur.x, o0, o1, o2, tt, tk, w)) return;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {                                 // regrid_pixels_hpix :64, deposits into this tile only
                 const int rr = tt[q4] - (R + 1);

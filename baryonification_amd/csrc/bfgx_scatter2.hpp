@@ -69,7 +69,6 @@ template <> struct PMath<double> {
     static constexpr double kHuge = 1.0e37;
     static __device__ inline double rsq(double x) { return fast_rsq(x); }
     static __device__ inline double half_ln(double x) { return 0.5 * fast_log(x); }
-    static __device__ inline double expv(double d) { return fast_exp(d); }
     static __device__ inline void sin_omc(double x, double &sn, double &omc)
     {
         double sh, ch;
@@ -77,9 +76,65 @@ template <> struct PMath<double> {
         sn = 2.0 * sh * ch;
         omc = 2.0 * sh * sh;
     }
+    static __device__ inline double expv(double d) { return fast_exp(d); }
     static __device__ inline bool finite(double v) { return __builtin_isfinite(v); }
     static __device__ inline double med3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 };
+
+// The PARITY-GRADE pair phase (acc mode 3, bfgx.h): fp64 data path whose elementary functions carry ~1e-11 instead of 4e-16 -- fp32 hardware
+// seeds and ONE Newton step, series cut where the truncation falls below 5e-11.  A displaced pixel needs its offset to ~1e-8 of itself for the
+// regridded map to hold SURVEY 8(d)'s 1e-6 mean(map) at displacements of 20 pixels (fp32 pair math: 4e-7, i.e. 2e-5 mean(map) there); the
+// 1e-10 parity path (acc mode 1) keeps PMath<double>.  Measured on the S19 table at config 2: K1 0.652 -> 0.606 ms, map within 1.7e-10 mean(map)
+// of the full-precision fp64 result.
+struct PMathE {
+    static constexpr double kHuge = 1.0e37;
+    static __device__ inline double rsq(double x)                        // x in [1e-37, ~4]: inside the fp32 range
+    {
+        const double y = (double)__builtin_amdgcn_rsqf((float)x);
+        const double h = 0.5 * y, e = __builtin_fma(-x * y, h, 0.5);
+        return __builtin_fma(y, e, y);                                   // 1.5 (1.5e-7)^2
+    }
+    static __device__ inline double half_ln(double x)
+    {
+        double m = __builtin_amdgcn_frexp_mant(x);
+        int e = __builtin_amdgcn_frexp_exp(x);
+        const bool lowm = m < 0.70710678118654752440;
+        m = lowm ? 2.0 * m : m;
+        e = lowm ? e - 1 : e;
+        const double den = m + 1.0;
+        double y = (double)__builtin_amdgcn_rcpf((float)den);
+        y = __builtin_fma(y, __builtin_fma(-den, y, 1.0), y);
+        const double s = (m - 1.0) * y, u = s * s;                       // |s| <= 0.1716: the series to s^11 leaves u^6 / 13 = 5e-11
+        double p = 1.0 / 11.0;
+        p = __builtin_fma(p, u, 1.0 / 9.0);
+        p = __builtin_fma(p, u, 1.0 / 7.0);
+        p = __builtin_fma(p, u, 1.0 / 5.0);
+        p = __builtin_fma(p, u, 1.0 / 3.0);
+        const double hl = __builtin_fma(s * u, p, s);                    // ln(m) / 2
+        return __builtin_fma((double)e, 0.34657359027997264, hl);
+    }
+    static __device__ inline double expv(double d) { return fast_exp(d); }
+    static __device__ inline void sin_omc(double x, double &sn, double &omc)      // |x| <= 0.5: x^11 / 11! and x^12 / 12! dropped (2e-11, 4e-12)
+    {
+        const double u = x * x;
+        double ps = 1.0 / 362880.0;
+        ps = __builtin_fma(ps, u, -1.0 / 5040.0);
+        ps = __builtin_fma(ps, u, 1.0 / 120.0);
+        ps = __builtin_fma(ps, u, -1.0 / 6.0);
+        sn = __builtin_fma(x * u, ps, x);
+        double pc = 1.0 / 3628800.0;
+        pc = __builtin_fma(pc, u, -1.0 / 40320.0);
+        pc = __builtin_fma(pc, u, 1.0 / 720.0);
+        pc = __builtin_fma(pc, u, -1.0 / 24.0);
+        pc = __builtin_fma(pc, u, 0.5);
+        omc = u * pc;
+    }
+    static __device__ inline bool finite(double v) { return __builtin_isfinite(v); }
+    static __device__ inline double med3(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+};
+// PM = 1: the parity-grade mode (PMathE pair math, pix_offsets stored as two fp32 arrays hi + lo); 0: the plain kernels
+template <typename real, int PM> struct PMSel { using type = PMath<real>; };
+template <> struct PMSel<double, 1> { using type = PMathE; };
 
 // ---------------------------------------------------------------------------------- LDS records
 // one clipped ring row (a contiguous pixel run inside the tile) as the pair phase sees it
@@ -98,15 +153,19 @@ struct RowGeo { double z0, s0, xa, cosr, phi0; };          // what the ring-row 
 #define BFGX_K1_GEO 0
 #endif
 
+// entries per chunk and row slots per pass, by the precision of the pair phase (LDS per wave: 2.9 KB fp32, 4.5 KB fp64 at 16 / 64)
+// (measured, fp64 pair math: sixteen waves per workgroup with chunks of 8 entries and 32 row slots -- what LDS then holds -- 0.739 ms against
+// 0.606 with twelve waves and 16 / 64: small chunks cost more than the fourth wave per SIMD hides)
+template <typename real> struct K1Cfg { static constexpr int chunk = kChunk2, rowl = kWave; };
 template <typename real>
 struct Wave2Lds {
-    PairRecT<real> pair[kChunk2];
-    RowC2<real> rows[kWave];
-    unsigned long long mask[kWave + 4];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
-    EntC2 ent[kChunk2];
-    unsigned long long emask[kChunk2];       // bit R set <=> row R of the chunk is the first row of an entry (<= 16 x 64 rows)
+    PairRecT<real> pair[K1Cfg<real>::chunk];
+    RowC2<real> rows[K1Cfg<real>::rowl];
+    unsigned long long mask[K1Cfg<real>::rowl + 4];      // bit t set <=> pair t is the first pair of a row (<= 64 rows x 64 pixels)
+    EntC2 ent[K1Cfg<real>::chunk];
+    unsigned long long emask[K1Cfg<real>::chunk];       // bit R set <=> row R of the chunk is the first row of an entry (<= 16 x 64 rows)
 #if BFGX_K1_GEO
-    RowGeo geo[kChunk2];
+    RowGeo geo[K1Cfg<real>::chunk];
 #endif
 };
 
@@ -208,11 +267,11 @@ struct PairEval {
 };
 
 // Branch-free evaluation of pair t of the current row block.
-template <int MODE, typename real, bool FAR = false>
+template <int MODE, typename real, bool FAR = false, int PM = 0>
 __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const RowC2<real> rc, const PairRecT<real> *pairs,
                                  const RingC2<real> *ringc, int t, bool act, int wsh, int wmask)
 {
-    using PM = PMath<real>;
+    using PMt = typename PMSel<real, PM>::type;
     const int jj = t - (int)(rc.pk & 0xFFFu);
     const int rl = (int)((rc.pk >> 18) & 63u);
     o.la = (rl << wsh) + (((int)((rc.pk >> 12) & 63u) + jj) & wmask);
@@ -221,7 +280,7 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     o.hidx = ph.hidx;
     const real x = fma_((real)jj, rg.dphi, rc.x0);
     real sn, omc;
-    PM::sin_omc(x, sn, omc);
+    PMt::sin_omc(x, sn, omc);
     if (FAR) {                                                         // (a row pass that holds pairs beyond 0.5 rad of their halo's azimuth: k1_chunk)
         if (act && !(fabs((double)x) <= 0.5)) { const double2 w = sin_omc_wide((double)x); sn = (real)w.x; omc = (real)w.y; }
     }
@@ -235,11 +294,11 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     // anyway); a halo outside the (z, M) table carries scale2 = +1e30 (K0), whose logarithm fails the range test: no flags of their own
     bool ok = act;
     const real u2s = (u2 > (real)1e-37) ? u2 : (real)1e-37;
-    const real rinv = PM::rsq(u2s);                                // 1 / |u|
-    const real lx = PM::half_ln(u2s * ph.scale2);                  // ln(r_sep / a) [- ln R when Rdelta]
+    const real rinv = PMt::rsq(u2s);                                // 1 / |u|
+    const real lx = PMt::half_ln(u2s * ph.scale2);                  // ln(r_sep / a) [- ln R when Rdelta]
     ok = ok && (lx >= tb.r0) && (lx <= tb.r1);                     // RGI fill_value = nan
     const real uu = (lx - tb.r0) * tb.inv_dr;
-    const real uc = PM::med3(uu, (real)0, (real)(tb.nr - 2));      // (clamped BEFORE the conversion: uu may be +-huge)
+    const real uc = PMt::med3(uu, (real)0, (real)(tb.nr - 2));      // (clamped BEFORE the conversion: uu may be +-huge)
     const int i = (int)uc;
     const real tr_ = uu - (real)i;
     const real *tp = tb.v + (unsigned)(ph.cell + i * 8);           // (cell >= 0: 32-bit offset from the uniform table base)
@@ -260,12 +319,12 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
     for (int k = 0; k < 4; ++k) d = fma_(ph.w[k], fma_(tr_, q[2 * k + 1], q[2 * k]), d);
     o.amb = false;
     if (MODE == MODE_PAINT) {
-        const real paint = PM::expv(d);                            // Tabulate.py:286
-        o.ok = o.ok_nocut = ok && PM::finite(paint) && paint != (real)0;       // :442
+        const real paint = PMt::expv(d);                            // Tabulate.py:286
+        o.ok = o.ok_nocut = ok && PMt::finite(paint) && paint != (real)0;       // :442
         o.v0 = paint; o.v1 = o.v2 = (real)0;
         return;
     }
-    ok = ok && PM::finite(d) && d != (real)0;                      // :323
+    ok = ok && PMt::finite(d) && d != (real)0;                      // :323
     o.ok_nocut = ok;
     // BaryonCorrection.py:381-382: r < eps R  <=>  t = |u|^2 / cut^2 - 1 < 0.  The pair record carries 1 / cut^2 (0 when the disc itself
     // implies r < eps R: t = -1, always inside, never ambiguous); the fp32 decision is re-made in fp64 where |t| <= 4e-6
@@ -293,7 +352,7 @@ __device__ inline void pair_eval(PairEval<real> &o, const Tab8T<real> &tb, const
 // ---------------------------------------------------------------------------------- one chunk of a tile's entry list
 // What a wave does with one chunk -- the entries [ebeg, ebeg + ecnt), ecnt <= kChunk2 -- of a tile's narrow-halo list: entries -> ring rows -> pairs, accumulated into the tile's
 // LDS planes `acc`.  Shared by the barrier-per-tile kernel (tile_scatter2_kernel) and the fluid kernel (tile_scatter2f_kernel).
-template <int MODE, typename real, int NP>
+template <int MODE, typename real, int NP, int PM = 0>
 __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__restrict__ rowrecs, const PairRecT<real> *__restrict__ pairrecs,
                                          const FbRec *__restrict__ fbrecs, const int32_t *__restrict__ ea, const int32_t *__restrict__ eb,
                                          int na, int ebeg, int ecnt, int estride, int i0, int i1, int nphi, int wsh, int wmask, int PL,
@@ -323,7 +382,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
     const int incl_e = wave_scan_incl(nrows, lane);
     const int total_rows = __builtin_amdgcn_readlane(incl_e, kWave - 1);
     en.prefix = incl_e - nrows;
-    if (lane < kChunk2) L.emask[lane] = 0ull;
+    if (lane < K1Cfg<real>::chunk) L.emask[lane] = 0ull;
     __builtin_amdgcn_wave_barrier();
     {
         const unsigned long long nzE = __ballot(nrows > 0);
@@ -344,7 +403,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
     // (and a WIDE disc can hold two runs of a row in any tile -- a span that leaves only a gap inside the tile's slice: a chunk that lists one does the same)
     auto rows_and_pairs = [&](auto wide_tag) __attribute__((always_inline)) {
     constexpr bool WIDE = decltype(wide_tag)::value;
-    const int rowlanes = (nphi == 1 || WIDE) ? 32 : kWave;
+    const int rowlanes = (nphi == 1 || WIDE) ? K1Cfg<real>::rowl / 2 : K1Cfg<real>::rowl;
     for (int rb = 0; rb < (BFGX_ABL2 == 2 ? 0 : total_rows); rb += rowlanes) {
         // ---- lanes = ring rows (clipped to this tile)
         const int R = rb + lane;
@@ -462,7 +521,7 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const int t = T0 + u * kWave + lane;
-                    pair_eval<MODE, real, WIDE>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
+                    pair_eval<MODE, real, WIDE, PM>(pv[u], tb, rc_cur[u], L.pair, ringc, t, t < total, wsh, wmask);
                 }
                 if (MODE == MODE_OFFSETS && sizeof(real) == 4) {
                     // pairs whose fp32 chord is within 4e-6 of the model-side cut (BaryonCorrection.py:381-382): decide in fp64 (rare)
@@ -502,15 +561,17 @@ __device__ __forceinline__ void k1_chunk(const Tab8T<real> &tb, const RowRec *__
 }
 
 // ---------------------------------------------------------------------------------- the kernel
-template <int MODE, typename ACC, typename real, int NP>
+template <int MODE, typename ACC, typename real, int NP, int PM = 0>
 __global__ void __launch_bounds__(kWave * kW2, (sizeof(real) == 4 ? 4 : 2))
 tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                      const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                      const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                      const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a, int cnt_pad,
-                     ACC *__restrict__ out, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
+                     ACC *__restrict__ out, ACC *__restrict__ out_lo, unsigned long long *__restrict__ pair_total, unsigned int *__restrict__ tile_counter,
                      unsigned int *__restrict__ omax2, int tile_lo, int tile_n, const int32_t *__restrict__ form, int my_form)
 {
+    // (PM = 1, the parity-grade mode: pix_offsets leave as two fp32 arrays, out = hi and out_lo = (float)(o - hi), indexed alike)
+    static_assert(PM == 0 || (MODE == MODE_OFFSETS && sizeof(ACC) == 4 && sizeof(real) == 8), "PM = 1: fp64 pair math into split fp32 pix_offsets");
     // (form: which of the fast kernel's two forms runs was left to the device -- both are launched, the other one returns here)
     if (form != nullptr && *form != my_form) return;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -583,7 +644,7 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
     // entries per chunk: at most kChunk2, fewer when the tile's list is short, so that every wave of the workgroup gets a chunk (a
     // large-NSIDE tile lists ~20 halos with hundreds of pixels each: in chunks of 16 entries two of the eight waves did all the
     // work).  One chunk per wave measured best (NSIDE 2048: K1 1.91 -> 1.56 ms, 8192: 56.8 -> 24.0 ms; 16 or 32 chunks per tile pack worse)
-    const int csz = max(1, min(kChunk2, (ne + kW2 - 1) / kW2));
+    const int csz = max(1, min(K1Cfg<real>::chunk, (ne + kW2 - 1) / kW2));
     const int nchunks = (BFGX_ABL2 == 1) ? 0 : (ne + csz - 1) / csz;
     WaveLds &L = wl[wid];
     unsigned long long npairs = 0;
@@ -594,8 +655,8 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
         c = __builtin_amdgcn_readfirstlane(c);
         if (c >= nchunks) break;
 
-        k1_chunk<MODE, real, NP>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), 1, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
-                                 lane, npairs);
+        k1_chunk<MODE, real, NP, PM>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, c * csz, min(csz, ne - c * csz), 1, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+                                     lane, npairs);
     }
     __syncthreads();
 
@@ -622,8 +683,14 @@ tile_scatter2_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__
             for (int px = lane; px < tr.ke - tr.ks; px += kWave) {
                 const int ix = (px + rot) & wmask;
                 Px v;
-                v.c[0] = (ACC)src[ix]; v.c[1] = (ACC)src[PL + ix]; v.c[2] = (ACC)src[2 * PL + ix];
+                const double d0 = src[ix], d1 = src[PL + ix], d2 = src[2 * PL + ix];
+                v.c[0] = (ACC)d0; v.c[1] = (ACC)d1; v.c[2] = (ACC)d2;
                 dpx[px] = v;
+                if (PM == 1) {
+                    Px w;
+                    w.c[0] = (ACC)(d0 - (double)v.c[0]); w.c[1] = (ACC)(d1 - (double)v.c[1]); w.c[2] = (ACC)(d2 - (double)v.c[2]);
+                    reinterpret_cast<Px *>(out_lo + NCOMP * (st + tr.ks))[px] = w;
+                }
                 const float a = (float)v.c[0], b = (float)v.c[1], c = (float)v.c[2];
                 om2 = fmaxf(om2, fma_(a, a, fma_(b, b, c * c)));
             }
@@ -706,17 +773,18 @@ __host__ __device__ inline size_t tile2f_lds_bytes(int BR, int W, int ncomp)
     return 2 * a + sizeof(Wave2Lds<real>) * FluidWaves<real>::n + 2 * sizeof(FluidSlot) + 4 * (sizeof(TileRow) + sizeof(RingC2<real>)) * (size_t)BR;
 }
 
-template <int MODE, typename ACC, typename real>
+template <int MODE, typename ACC, typename real, int PM = 0>
 __global__ void __launch_bounds__(kWave * FluidWaves<real>::n, 1)
 tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict__ rowrecs,
                       const PairRecT<real> *__restrict__ pairrecs, const FbRec *__restrict__ fbrecs,
                       const int32_t *__restrict__ tile_start, const int32_t *__restrict__ cnt_a, const int32_t *__restrict__ cnt_b,
                       const int32_t *__restrict__ entries, int64_t capacity, const int32_t *__restrict__ entries_a, int cap_a, int cnt_pad,
-                      ACC *__restrict__ out, unsigned int *__restrict__ tile_counter, unsigned int *__restrict__ omax2,
+                      ACC *__restrict__ out, ACC *__restrict__ out_lo, unsigned int *__restrict__ tile_counter, unsigned int *__restrict__ omax2,
                       int tile_lo, int tile_n, int32_t *__restrict__ err, const int32_t *__restrict__ form, int my_form)
 {
     if (form != nullptr && *form != my_form) return;
     static_assert(MODE == MODE_OFFSETS || MODE == MODE_PAINT, "the census runs in tile_scatter2_kernel");
+    static_assert(PM == 0 || (MODE == MODE_OFFSETS && sizeof(ACC) == 4 && sizeof(real) == 8), "PM = 1: fp64 pair math into split fp32 pix_offsets");
     constexpr int kWF = FluidWaves<real>::n;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NCOMP = (MODE == MODE_OFFSETS) ? 3 : 1;
@@ -819,10 +887,11 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             // half chunks at the end of the list, measured slower.
             // Region B of the list (discs over more than kRefMax tiles: the large ones) goes out FIRST and in chunks of kChunkB entries, so that
             // the long items are not what the tile's waves finish on; then region A in chunks of csz.
-            S.ne = S.nx_ne; S.csz = S.nx_na >= kChunk2 * kWF / 2 ? BFGX_K1F_CSZ : max(1, min(kChunk2, (S.nx_na + kWF - 1) / kWF));
+            constexpr int kCh = K1Cfg<real>::chunk;
+            S.ne = S.nx_ne; S.csz = S.nx_na >= kCh * kWF / 2 ? min(BFGX_K1F_CSZ, kCh) : max(1, min(kCh, (S.nx_na + kWF - 1) / kWF));
             // (painting: pairs are cheap, so a list of 128 - 384 entries is better cut into ~24 chunks than into 8 - 24 of sixteen entries --
             // config 3 lists 210 per tile: K3 1.058 -> 1.01 ms; the displacement kernel loses 2 % with the same rule)
-            if (MODE == MODE_PAINT && S.nx_na >= kChunk2 * kWF / 2 && S.nx_na < 24 * kChunk2) S.csz = max(1, min(kChunk2, (S.nx_na + 23) / 24));
+            if (MODE == MODE_PAINT && S.nx_na >= kCh * kWF / 2 && S.nx_na < 24 * kCh) S.csz = max(1, min(kCh, (S.nx_na + 23) / 24));
             S._pad = (S.nx_ne - S.nx_na + kChunkB - 1) / kChunkB;                      // chunks of region B
             S.nchunks = S.nx_tile < 0 ? 0 : S._pad + (S.nx_na + S.csz - 1) / S.csz;
             S.ea = S.nx_ea; S.eb = S.nx_eb;
@@ -871,9 +940,10 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             if (g >= ngroups) break;
             float om2 = 0.0f;
             struct alignas(sizeof(ACC)) Px3 { ACC c[3]; };
-            ACC v[4][NCOMP];
+            using VT = typename std::conditional<PM == 1, double, ACC>::type;      // (PM = 0: converted as it is read, as before)
+            VT vd[4][NCOMP];
             bool on[4];
-            ACC *dp[4];
+            ACC *dp[4], *dl[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int rr = min(4 * g + q, nrow - 1);
@@ -885,20 +955,28 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
                 const int ix = (lane + (((rr & 7) << wsh) >> 3)) & wmask;
                 on[q] = (4 * g + q < nrow) && lane < npx;
                 dp[q] = out + NCOMP * (st + ks + lane);
+                dl[q] = (PM == 1) ? out_lo + NCOMP * (st + ks + lane) : nullptr;
 #pragma unroll
-                for (int cc = 0; cc < NCOMP; ++cc) v[q][cc] = (ACC)0;
+                for (int cc = 0; cc < NCOMP; ++cc) vd[q][cc] = (VT)0;
                 if (on[q]) {
 #pragma unroll
-                    for (int cc = 0; cc < NCOMP; ++cc) { v[q][cc] = (ACC)src[cc * PL + ix]; src[cc * PL + ix] = 0.0; }
+                    for (int cc = 0; cc < NCOMP; ++cc) { vd[q][cc] = (VT)src[cc * PL + ix]; src[cc * PL + ix] = 0.0; }
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (NCOMP == 3) {
-                    if (on[q]) { Px3 w; w.c[0] = v[q][0]; w.c[1] = v[q][1]; w.c[2] = v[q][2]; *reinterpret_cast<Px3 *>(dp[q]) = w; }
-                    const float a = (float)v[q][0], b = (float)v[q][1], c = (float)v[q][NCOMP - 1];
+                    Px3 w;
+                    w.c[0] = (ACC)vd[q][0]; w.c[1] = (ACC)vd[q][1]; w.c[2] = (ACC)vd[q][NCOMP - 1];
+                    if (on[q]) *reinterpret_cast<Px3 *>(dp[q]) = w;
+                    if (PM == 1) {           // the part of the fp64 sum that its fp32 value drops
+                        Px3 wl;
+                        wl.c[0] = (ACC)((double)vd[q][0] - (double)w.c[0]); wl.c[1] = (ACC)((double)vd[q][1] - (double)w.c[1]); wl.c[2] = (ACC)((double)vd[q][NCOMP - 1] - (double)w.c[2]);
+                        if (on[q]) *reinterpret_cast<Px3 *>(dl[q]) = wl;
+                    }
+                    const float a = (float)w.c[0], b = (float)w.c[1], c = (float)w.c[2];
                     om2 = fmaxf(om2, fma_(a, a, fma_(b, b, c * c)));
-                } else if (on[q]) *dp[q] = v[q][0];
+                } else if (on[q]) *dp[q] = (ACC)vd[q][0];
             }
             if (MODE == MODE_OFFSETS) {
 #pragma unroll
@@ -963,7 +1041,7 @@ tile_scatter2f_kernel(Tab8T<real> tb, Hpx h, Tiling T, const RowRec *__restrict_
             const int ebeg = c < nchb ? na + c * kChunkB : c - nchb;
             const int ecnt = c < nchb ? min(kChunkB, ne - ebeg) : (na - ebeg + ncha - 1) / ncha;
             const int estride = c < nchb ? 1 : ncha;
-            k1_chunk<MODE, real, (sizeof(real) == 4 ? BFGX_K1F_NP : 1)>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, estride, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
+            k1_chunk<MODE, real, (sizeof(real) == 4 ? BFGX_K1F_NP : 1), PM>(tb, rowrecs, pairrecs, fbrecs, ea, eb, na, ebeg, ecnt, estride, i0, i1, nphi, wsh, wmask, PL, acc, L, rowtab, ringc,
                                     lane, npairs);
 #if BFGX_K1F_PROF
             if (lane == 0) { const unsigned d = (unsigned)(PF_NOW() - pf_c0); atomicMax(&S.pf_maxchunk, d); pf_nchunk += 1; }

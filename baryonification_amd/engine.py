@@ -166,6 +166,12 @@ class ShellPlan(object):
                                                       C.c_void_p(int(counts_ptr) or None), C.byref(tot)))
         return int(tot.value)
 
+    def precision(self, acc_f64=-1):
+        """(BFGX_ACC_* a request resolves to on this plan, largest displacement of the plan's table in pixel sides of its NSIDE)"""
+        r, d = C.c_int32(0), C.c_double(0.0)
+        _lib.check(_lib.load().bfgx_plan_precision(self._h, int(acc_f64), C.byref(r), C.byref(d)))
+        return int(r.value), float(d.value)
+
     def set_algo(self, algo):
         """1 = tile-owned LDS accumulators (default), 0 = one wave per halo + global float atomics"""
         _lib.check(_lib.load().bfgx_plan_set_algo(self._h, int(algo)))

@@ -33,6 +33,24 @@ extern "C" {
 #endif
 
 #define BFGX_ABI_VERSION 3
+
+/* Precision of the displacement path (the `acc_f64` argument of the *_device entries, bfgx_opts.acc_offsets_f64).  The reference computes in
+ * float64 throughout (HealpixRunner.py:289-341); SURVEY 8(d) states the tolerance a faster mode must hold: |d| <= 1e-6 mean(map) per pixel.
+ *   BFGX_ACC_F32    fp32 pair math and fp32 pix_offsets [npix][3] (fp64 ring-row geometry and accumulation).  Holds 1e-6 mean(map) while a halo moves
+ *                   a pixel by less than ~0.4 pixel sides; its error grows with displacement / pixel (2e-5 at 20 pixels).
+ *   BFGX_ACC_F64    fp64 throughout, pix_offsets double [npix][3]: the reference's own arithmetic, 1e-10 of the map scale.
+ *   BFGX_ACC_PARITY the parity-grade mode: fp64 pair math whose elementary functions carry 1e-11 (fp32 hardware seeds + one Newton step), pix_offsets
+ *                   as TWO fp32 arrays -- hi [npix][3], then lo [npix][3] = (float)(o - hi) behind it (24 bytes per pixel, as fp64) --, the regrid scans
+ *                   the high halves and evaluates survivors in fp64 on hi + lo.  Within 1e-9 mean(map) of BFGX_ACC_F64 at any displacement.  Needs the fast
+ *                   tile kernel (3-axis table, uniform ln r axis); elsewhere, and in the band-restricted entries, it runs as BFGX_ACC_F64.
+ *   BFGX_ACC_AUTO   the plan chooses from its table at creation: BFGX_ACC_F32 while the table cannot move a pixel by more than 0.4 pixel sides of the
+ *                   plan's NSIDE (largest |d| a / D_A over the table's (z, M) nodes inside the model-side cut), BFGX_ACC_PARITY beyond.  The default of
+ *                   the one-shot host entries and of the Python runners.  Scratch for pix_offsets must then hold 24 bytes per pixel.
+ * bfgx_plan_precision tells what a request resolves to and how far the table moves a pixel. */
+#define BFGX_ACC_AUTO   (-1)
+#define BFGX_ACC_F32    0
+#define BFGX_ACC_F64    1
+#define BFGX_ACC_PARITY 3
 #define BFGX_MAX_EXTRA 2          /* extra (per-halo parameter) table axes, model.p_keys */
 #define BFGX_MAX_DIM (3 + BFGX_MAX_EXTRA)
 
@@ -97,7 +115,8 @@ typedef struct bfgx_model {
 
 typedef struct bfgx_opts {
     int32_t device;                       /* HIP device ordinal */
-    int32_t acc_offsets_f64;              /* pix_offsets accumulator: 0 = f32 atomics (default), 1 = f64 */
+    int32_t acc_offsets_f64;              /* BaryonifyShell precision: BFGX_ACC_AUTO (-1; what a NULL opts selects), BFGX_ACC_F32 (0), BFGX_ACC_F64 (1) or
+                                             BFGX_ACC_PARITY (3), see above */
     int32_t acc_paint_f64;                /* painted map: 0 = f32 throughout, 1 = f64 throughout (default for host API),
                                              2 = f32 pair math, f64 accumulation and f64 map (2.3x faster, ~1e-5 relative) */
     int32_t check_mass;                   /* 1: enforce np.isclose(sum(new), sum(old)) like the reference */
@@ -181,7 +200,11 @@ void bfgx_plan_destroy(bfgx_plan *p);
 int  bfgx_plan_set_algo(bfgx_plan *p, int algo);
 /* blocking health check of the plan's workspace (entry-list capacity); call outside timed regions */
 int  bfgx_plan_status(bfgx_plan *p);
-/* K0 + K1: pix_offsets[npix][3] += per-halo unit-vector offsets; acc is f32 or f64 (acc_f64) */
+/* what `acc_requested` (BFGX_ACC_*) resolves to on this plan, and the largest displacement of the plan's table in pixel sides of its NSIDE
+ * (either pointer may be NULL); HealpixRunner.py has no counterpart: the reference knows one precision */
+int  bfgx_plan_precision(bfgx_plan *p, int acc_requested, int32_t *acc_resolved, double *table_disp_pixels);
+/* K0 + K1: pix_offsets[npix][3] = sum of the per-halo unit-vector offsets (HealpixRunner.py:291-331); acc_f64 = BFGX_ACC_* selects precision and
+ * layout (f32 / f64 [npix][3], or the split hi / lo arrays of BFGX_ACC_PARITY: 24 bytes per pixel) */
 int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offsets_dev, int acc_f64);
 /* K2: map_out[npix] (f64) = bilinear regrid of the displaced pixels.  algo 1: every pixel of map_out is stored exactly
  * once by the tile that owns it (no zero-fill needed); algo 0: map_out += (must be zeroed by the caller).
@@ -189,7 +212,7 @@ int  bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat_dev, void *offset
 int  bfgx_regrid_device(bfgx_plan *p, const double *map_in_dev, const void *offsets_dev, int acc_f64,
                         double *map_out_dev, double *sums_dev);
 /* K0 + K1 + K2 in one enqueue-only call (BaryonifyShell.process() on device buffers): offsets_work_dev[npix][3] is the
- * pix_offsets scratch (f32 or f64, every element overwritten), the other arguments as above.  Same results as
+ * pix_offsets scratch (12 bytes per pixel for BFGX_ACC_F32, 24 otherwise; every element overwritten), the other arguments as above.  Same results as
  * bfgx_offsets_device followed by bfgx_regrid_device; K1 hands the regrid the largest displacement of every tile, which
  * the separate calls have to find with one more pass over pix_offsets. */
 int  bfgx_baryonify_device(bfgx_plan *p, const bfgx_catalog *cat_dev, const double *map_in_dev, void *offsets_work_dev,
