@@ -43,6 +43,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# precision modes of the displacement path (include/bfgx.h BFGX_ACC_*)
+PRECISION_NAMES = {0: "f32", 1: "f64", 3: "parity"}
+DTYPES = {0: "f64 ring-row geometry + f64 LDS accumulation / map; f32 pair math, f32 pix_offsets, f32 regrid geometry",
+          1: "f64 throughout (fp64 pair math, fp64 pix_offsets, fp64 regrid): the reference's own arithmetic",
+          3: "f64 throughout in the parity-grade mode: f64 ring-row geometry, f64 pair math with 1e-11 elementary functions (fp32 seeds + one Newton step), "
+             "f64 LDS accumulation, pix_offsets stored as two f32 arrays (hi + lo), f64 regrid geometry, f64 map"}
 
 
 def parse():
@@ -61,7 +67,11 @@ def parse():
     ap.add_argument('--halos', type=int, default=1_000_000, help='halos per GPU (default: BASELINE config 2)')
     ap.add_argument('--nside', type=int, default=1024)
     ap.add_argument('--eps', type=float, default=10.0)
-    ap.add_argument('--acc-f64', action='store_true', help='fp64 pix_offsets accumulators instead of fp32')
+    ap.add_argument('--acc-f64', action='store_true', help='fp64 throughout (= --precision f64; paint: fp64 pair math)')
+    ap.add_argument('--precision', choices=['auto', 'f32', 'f64', 'parity'], default='auto',
+                    help="baryonify: 'auto' (default) = what the drop-in runners do: the plan picks fp32 pair math or the parity-grade mode from its "
+                         "table (include/bfgx.h BFGX_ACC_*: within SURVEY 8(d)'s 1e-6 mean(map) of the fp64 reference either way); 'f32' / 'f64' / "
+                         "'parity' force one")
     ap.add_argument('--algo', type=int, default=1, help='1 = LDS tiles (default), 0 = per-halo global atomics')
     ap.add_argument('--mode', choices=['baryonify', 'paint', 'grid3d', 'snapshot'], default='baryonify',
                     help="'paint' = PaintProfilesShell (BASELINE config 3 with --nside 2048); 'grid3d' = BASELINE config 5 "
@@ -76,9 +86,10 @@ def parse():
     ap.add_argument('--sorted-particles', action='store_true',
                     help='grid3d / snapshot: order the synthetic particles by coarse cell (as snapshot files stored along a space-filling '
                          'curve are) instead of uniformly random order')
-    ap.add_argument('--table', choices=['closed-form', 's19'], default='closed-form',
-                    help="'s19': displacement table built by the GPU table builders (K4-K6) from the Schneider19 one-halo "
-                         "profiles with the reference's default_config parameters (SURVEY 8d table (ii)); baryonify mode only")
+    ap.add_argument('--table', choices=['closed-form', 's19'], default='s19',
+                    help="'s19' (default since round 5): SURVEY 8(d) table (ii), the BENCHMARK table -- built by the GPU table builders (K4-K6) from the "
+                         "Schneider19 one-halo profiles with the reference's default_config parameters; 'closed-form': table (i), the plumbing table "
+                         "(displacements < 0.2 pixels; the headline of rounds 1-4, `value_closed_form` on the default line); baryonify mode only")
     ap.add_argument('--exchange', choices=['spatial', 'slices', 'reduce'], default='spatial',
                     help="N > 1: 'spatial' (default) = halos routed to the owners of the ring bands their discs touch, no accumulator "
                          "crosses a link; 'slices' = halo shards + all_to_all reduce-scatter of pix_offsets by pixel slices + banded regrid; "
@@ -568,6 +579,14 @@ def shell_line(args, ctx, scaling, brief):
     plan.set_algo(args.algo)
     n_pairs = plan.count_pairs(cat_dev, fallback4=not paint)
     plan.status()
+    # precision of the displacement path (include/bfgx.h BFGX_ACC_*): what the request resolves to on this plan (auto: from the table)
+    acc_req = _lib.ACC_F64 if args.acc_f64 else {'auto': _lib.ACC_AUTO, 'f32': _lib.ACC_F32, 'f64': _lib.ACC_F64, 'parity': _lib.ACC_PARITY}[args.precision]
+    if paint:
+        acc_res, disp_px = (1 if args.acc_f64 else 2), None
+    elif args.algo == 1:
+        acc_res, disp_px = plan.precision(acc_req)
+    else:
+        acc_res, disp_px = (_lib.ACC_F32 if acc_req in (_lib.ACC_AUTO, _lib.ACC_F32) else _lib.ACC_F64), None
 
     # N > 1: slice exchange (utils/Parallelize.py): all_to_all reduce-scatter of the accumulator by pixel slices, one-ring
     # halo exchange, every rank regrids the OUTPUT pixels of its bands, disjoint slices travel to rank 0.
@@ -633,8 +652,11 @@ def shell_line(args, ctx, scaling, brief):
                 stage_t[name] = stage_t.get(name, 0.0) + (now - sp_state['t_last']) * 1e3
                 sp_state['t_last'] = now
 
-    def run_steps(acc_f64):
-        """returns a closure doing one full pass of the hot path with the given accumulator type"""
+    def run_steps(acc):
+        """returns a closure doing one full pass of the hot path in the given precision: painting: True = fp64 pair math, False = the mixed mode;
+        displacement: BFGX_ACC_F32 / F64 / PARITY (24 bytes of pix_offsets per pixel unless fp32; the band-restricted entries of the N > 1
+        paths keep ONE array of pix_offsets and serve the parity-grade mode with fp64 throughout)"""
+        acc_f64 = bool(acc) if paint else (acc if (world == 1 and not slices and not spatial) else (1 if acc != _lib.ACC_F32 else 0))
         acc_dtype = torch.float64 if acc_f64 else torch.float32
         d_off = torch.zeros(npix * 3, dtype=acc_dtype, device=dev)
         x_recv = torch.empty(world * (p1 - p0) * (1 if paint else 3), dtype=torch.float64 if paint else acc_dtype, device=dev) if slices else None
@@ -839,7 +861,7 @@ def shell_line(args, ctx, scaling, brief):
             el = float(te.item())
         return el, kt
 
-    step = run_steps(args.acc_f64)
+    step = run_steps(args.acc_f64 if paint else acc_res)
     if slices or spatial:
         # one untimed trial step.  A rank that fails (out of memory, an overflowing entry list) may have left its peers inside a
         # collective, so nothing is agreed on afterwards and no fallback runs on the same communicator: the rank reports and exits
@@ -923,8 +945,8 @@ def shell_line(args, ctx, scaling, brief):
         if paint:
             pf.paint(cdf, ref.data_ptr(), acc_f64=(1 if args.acc_f64 else 2))
         else:
-            woff = torch.zeros(npix * 3, dtype=torch.float64 if args.acc_f64 else torch.float32, device=dev)
-            pf.baryonify(cdf, d_map.data_ptr(), woff.data_ptr(), ref.data_ptr(), 0, acc_f64=args.acc_f64)
+            woff = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+            pf.baryonify(cdf, d_map.data_ptr(), woff.data_ptr(), ref.data_ptr(), 0, acc_f64=acc_res)
         torch.cuda.synchronize()
         pf.status()
         got = d_fin if (slices or spatial) else d_out
@@ -947,68 +969,59 @@ def shell_line(args, ctx, scaling, brief):
         extra["value_acc_f64"] = {"value": total_halos / el64 * n64, "unit": "halos/s", "ms_per_step": el64 / n64 * 1e3, "steps": n64,
                                   "dtype": "f64 throughout (fp64 pair math, fp64 LDS accumulation, fp64 map)"}
         del step64
-    if world == 1 and not paint and not args.acc_f64 and args.algo == 1 and not args.no_extras and not brief:
-        # the same step with fp64 pix_offsets accumulators and fp64 pair math (1e-10 parity path)
-        step64 = run_steps(True)
-        for _ in range(3):
-            step64()
-        n64 = max(20, args.steps // 4)
-        el64, _ = timed(step64, n64, False)
-        extra["value_acc_f64"] = {"value": total_halos / el64 * n64, "unit": "halos/s", "ms_per_step": el64 / n64 * 1e3, "steps": n64,
-                                  "dtype": "f64 throughout (fp64 pair math, fp64 pix_offsets, fp64 regrid)"}
-        del step64
-        torch.cuda.empty_cache()
-        if args.table == 'closed-form':
-            # SURVEY 8(d) table (ii), the BENCHMARK table: the same step on the displacement table the GPU table builders (K4-K6) make from
-            # the Schneider19 one-halo profiles (default_config parameters, cdelta = 7, proj_cutoff = 50).  Its displacements are 1.9 pixels on
-            # average and 20 at most (the closed-form table's: < 0.2), so every tile of K2 runs in the walking kernel and 0.2 % of the
-            # pixels take the far list.  `value` stays the closed-form line so that rounds stay comparable.
-            table2 = syn.s19_displacement_table(z, M, r)
-            model2, keep2 = engine.model_from_tables(axes, table2, syn.COSMO, args.eps, args.eps)
-            plan2 = engine.ShellPlan(model2, keep2, nside, nh, device=local_rank, stream=stream)
-            plan2.set_algo(1)
-            d_off2 = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+    if world == 1 and not paint and args.algo == 1 and not args.no_extras and not brief:
+        def side_line(pl, acc, nsteps, table_name, what):
+            """the same step in another precision / on the other table: the timed region, then the same steps with kernel events (kernel_ms, roofline)"""
+            res, _ = pl.precision(acc)
+            w_off = torch.zeros(npix * 3, dtype=torch.float32 if res == _lib.ACC_F32 else torch.float64, device=dev)
 
-            def step_s19():
-                plan2.baryonify(cat_dev, d_map.data_ptr(), d_off2.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=False)
-            for _ in range(5):
-                step_s19()
-            n19 = max(20, args.steps // 2)
-            el19, _ = timed(step_s19, n19, False, tp=plan2)
-            el19e, kt19 = timed(step_s19, n19, True, tp=plan2)
-            plan2.status()
-            st19 = plan2.regrid_stats()
-            d_off2 = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
-
-            def step_s19_f64():
-                plan2.baryonify(cat_dev, d_map.data_ptr(), d_off2.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=True)
+            def st():
+                pl.baryonify(cat_dev, d_map.data_ptr(), w_off.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), acc_f64=res)
             for _ in range(3):
-                step_s19_f64()
-            n19d = max(20, args.steps // 4)
-            el19d, _ = timed(step_s19_f64, n19d, False, tp=plan2)
-            plan2.status()
-            step_s19()
-            torch.cuda.synchronize()
-            s19 = d_sums.cpu().numpy()
-            k19 = {k: (ms / n if n else None) for k, (ms, n) in kt19.items() if n}
-            extra["value_s19"] = {
-                "value": total_halos / el19 * n19, "unit": "halos/s", "ms_per_step": el19 / n19 * 1e3, "steps": n19,
-                "workload": "the same catalog, shell and step with the 10x10x500 Schneider19 one-halo displacement table built by K4-K6 "
-                            "(SURVEY 8d table (ii): default_config parameters, cdelta = 7, proj_cutoff = 50)",
-                "table_abs_max_mpc": float(np.abs(table2).max()), "kernel_ms": k19, "ms_per_step_with_kernel_events": el19e / n19 * 1e3,
-                "mass_conserved": bool(np.isclose(s19[1], s19[0])), "regrid": st19,
-                "acc_f64": {"value": total_halos / el19d * n19d, "unit": "halos/s", "ms_per_step": el19d / n19d * 1e3, "steps": n19d,
-                            "dtype": "f64 throughout (the 1e-10 parity path)"},
-                "tolerance_note": "default mode (f32 pair math, f32 pix_offsets) against the fp64 oracle on this table: 2.6e-5 mean(map) measured, "
-                                  "5e-5 stated (tests/test_gpu_fullsize.py::test_config2_s19_benchmark_table_full_size_vs_oracle): the error of a "
-                                  "bilinear deposit grows with displacement / pixel (20 pixels here, < 0.2 on the closed-form table: 1e-6); "
-                                  "acc_f64 meets 1e-10",
-                "roofline": roofline(args, k19, n_pairs, nh, npix, paint, table='s19'),
-                "roofline_regrid": roofline(args, k19, n_pairs, nh, npix, paint, table='s19', force='regrid')}
-            plan2.close()
-            del d_off2, plan2
-            step()                                   # (d_out / d_sums hold the closed-form result again)
-            torch.cuda.synchronize()
+                st()
+            el, _ = timed(st, nsteps, False, tp=pl)
+            el_e, kt_s = timed(st, nsteps, True, tp=pl)
+            pl.status()
+            ks = {k: (ms / n if n else None) for k, (ms, n) in kt_s.items() if n}
+            sm = d_sums.cpu().numpy()
+            o = {"value": total_halos / el * nsteps, "unit": "halos/s", "ms_per_step": el / nsteps * 1e3, "steps": nsteps, "what": what,
+                 "precision": PRECISION_NAMES[res], "dtype": DTYPES[res], "kernel_ms": ks, "ms_per_step_with_kernel_events": el_e / nsteps * 1e3,
+                 "mass_conserved": bool(np.isclose(sm[1], sm[0])), "regrid": pl.regrid_stats(),
+                 "roofline": roofline(args, ks, n_pairs, nh, npix, paint, table=table_name, acc=res),
+                 "roofline_regrid": roofline(args, ks, n_pairs, nh, npix, paint, table=table_name, acc=res, force='regrid')}
+            del w_off
+            return o
+        nside_steps = max(20, args.steps // 4)
+        if acc_res != _lib.ACC_F64:
+            # the reference's own arithmetic on the SAME table: fp64 throughout, the 1e-10 parity path -- with its kernel times and roofline
+            extra["value_acc_f64"] = side_line(plan, _lib.ACC_F64, nside_steps, args.table, "the headline step with fp64 throughout (--precision f64): fp64 pair math, fp64 pix_offsets, fp64 regrid")
+        if acc_res != _lib.ACC_F32:
+            # fp32 pair math on the same table: what rounds 1-4 ran by default.  Its error grows with displacement / pixel
+            extra["value_f32"] = side_line(plan, _lib.ACC_F32, nside_steps, args.table, "the headline step with fp32 pair math, fp32 pix_offsets and fp32 regrid geometry (--precision f32)")
+            extra["value_f32"]["tolerance_note"] = ("against the fp64 oracle on the Schneider19 table at config 2: 2.1e-5 mean(map) measured (the error of a bilinear deposit grows "
+                                                    "with displacement / pixel: 20 pixels on this table); SURVEY 8(d) states 1e-6, which --precision auto / parity / f64 meet "
+                                                    "(tests/test_gpu_fullsize.py::test_config2_s19_benchmark_table_full_size_vs_oracle)")
+        torch.cuda.empty_cache()
+        # the OTHER table of SURVEY 8(d) in the default precision: (i) the closed-form plumbing table (displacements < 0.2 pixels: K2 runs its lean
+        # one-ring kernel, the plan picks fp32 pair math) -- the headline of rounds 1-4 -- or (ii) the Schneider19 benchmark table
+        other = 'closed-form' if args.table == 's19' else 's19'
+        table2 = syn.displacement_table(z, M, r) if other == 'closed-form' else syn.s19_displacement_table(z, M, r)
+        model2, keep2 = engine.model_from_tables(axes, table2, syn.COSMO, args.eps, args.eps)
+        plan2 = engine.ShellPlan(model2, keep2, nside, nh, device=local_rank, stream=stream)
+        plan2.set_algo(1)
+        key2 = "value_closed_form" if other == 'closed-form' else "value_s19"
+        extra[key2] = side_line(plan2, acc_req, max(20, args.steps // 2), other,
+                                "the same catalog, shell and step on SURVEY 8(d) table (i), the closed-form plumbing table (rounds 1-4 quoted this as `value`)"
+                                if other == 'closed-form' else
+                                "the same catalog, shell and step with the 10x10x500 Schneider19 one-halo displacement table built by K4-K6 (SURVEY 8d table (ii))")
+        extra[key2]["table_disp_pixels"] = plan2.precision(acc_req)[1]
+        if plan2.precision(acc_req)[0] != _lib.ACC_F64:
+            f64o = side_line(plan2, _lib.ACC_F64, nside_steps, other, "fp64 throughout on that table")
+            extra[key2]["acc_f64"] = {k: f64o[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "kernel_ms")}
+        plan2.close()
+        del plan2
+        step()                                   # (d_out / d_sums hold the headline result again)
+        torch.cuda.synchronize()
         # the drop-in call from numpy arrays (BaryonifyShell.process(): PCIe both ways, plan cache warm after the first call)
         extra["end_to_end"] = end_to_end(args, cat, hmap, z, M, r, table)
 
@@ -1028,9 +1041,8 @@ def shell_line(args, ctx, scaling, brief):
             "value": total_halos / elapsed * args.steps, "unit": "halos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": ("f64" if args.acc_f64 else
-                      "f64 ring-row geometry + f64 LDS accumulation + f64 map; f32 pair math (chord, ln r, read-out, exp)" if paint else
-                      "f64 ring-row geometry + f64 LDS accumulation / map; f32 pair math, f32 pix_offsets, f32 regrid geometry"),
+            "dtype": (("f64" if args.acc_f64 else "f64 ring-row geometry + f64 LDS accumulation + f64 map; f32 pair math (chord, ln r, read-out, exp)") if paint else
+                      DTYPES[1 if (acc_res != _lib.ACC_F32 and (world > 1 or slices or spatial)) else acc_res]),
             "data": "synthetic",
             "config": {"workload": "%s: %d-halo synthetic catalog %s (SURVEY 8d seeds), %s, "
                                    "NSIDE=%d shell, epsilon_max=%g, 10x10x500 %s %s table (edges = catalog min/max)" % (
@@ -1040,7 +1052,9 @@ def shell_line(args, ctx, scaling, brief):
                                        "profile" if paint else "displacement"),
                        "halos_per_gpu": nh, "nside": nside, "npix": npix, "pairs_per_gpu": n_pairs, "table": ("closed-form" if paint else args.table),
                        **({"catalog_order": {"sky": "sky: (band of 32 rings, azimuth) order", "mass": "mass: heaviest halos first"}[args.catalog_order]} if args.catalog_order != 'shuffled' else {}),
-                       "accumulators": "f64 LDS tiles; global " + ("f64" if (args.acc_f64 or paint) else "f32 pix_offsets / f64 map"),
+                       "accumulators": "f64 LDS tiles; global " + ("f64" if paint else {0: "f32 pix_offsets / f64 map", 1: "f64 pix_offsets / f64 map", 3: "split f32 hi + lo pix_offsets / f64 map"}[acc_res]),
+                       **({} if paint else {"precision": PRECISION_NAMES[acc_res], "precision_requested": ("f64" if args.acc_f64 else args.precision),
+                                            "table_disp_pixels": disp_px}),
                        "parallelism": ("single GPU" if world == 1 else
                                        "spatial sharding x%d: halos routed (RCCL all_to_all of catalog columns) to the ranks whose ring bands their discs "
                                        "touch, every rank computes and regrids its own pixels (%s), disjoint slices -> rank 0"
@@ -1060,7 +1074,7 @@ def shell_line(args, ctx, scaling, brief):
             kernels = {k: (ms / n if n else None) for k, (ms, n) in kt.items() if n}
             out["ms_per_step_with_kernel_events"] = elapsed_ev / args.steps * 1e3
             out["kernel_ms"] = kernels
-            out["roofline"] = roofline(args, kernels, n_pairs, nh, npix, paint)
+            out["roofline"] = roofline(args, kernels, n_pairs, nh, npix, paint, acc=(None if paint else acc_res))
         out.update(extra)
         if check is not None:
             out["check"] = check
@@ -1096,34 +1110,39 @@ def committed_traffic(match, key, metric_has=None):
             c = tj.get('config', {})
             if metric_has is not None and metric_has not in (tj.get('metric') or ''):
                 continue
-            if all(c.get(k, 'closed-form' if k == 'table' else None) == v for k, v in match.items()) and key in tj.get('kernels', {}):
+            if all(c.get(k, {'table': 'closed-form', 'precision': 'f32'}.get(k)) == v for k, v in match.items()) and key in tj.get('kernels', {}):      # (files of rounds 1-4: closed-form unless said, fp32 pair math)
                 return tj['kernels'][key], tj.get('valu_wave_insts', {}).get(key), os.path.basename(f)
         except Exception:        # noqa: BLE001
             continue
     return None, None, None
 
 
-def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None):
+def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None, acc=None):
     """The dominant kernel (by measured time) against the HBM roof SURVEY 8(d) defines: algorithmic bytes per launch / average
     launch duration (HIP events on the launch stream over K steps).  traffic / VALU counts come from the committed rocprofv3 --pmc
     passes of this same configuration (profiles/traffic_latest.json)."""
-    acc_b = 8 if args.acc_f64 else 4
+    if acc is None:
+        acc = 1 if args.acc_f64 else 0
+    acc_b = 4 if acc == 0 else 8                 # (the parity-grade mode stores hi + lo: 8 bytes per component, like fp64)
     # SURVEY 8d: K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo; K2 60 B per map pixel (3 acc + 8 + 4 x 8 + 8); K3 8 B/pair
     alg = {'offsets': n_pairs * 3 * acc_b + nh * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8), 'paint': n_pairs * 8 + nh * 32 + npix * 8}
     table = table or args.table
     dom = force or ('paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0))
-    real = 'double' if args.acc_f64 else 'float'
+    real = 'float' if acc == 0 else 'double'
+    areal = 'double' if acc == 1 else 'float'    # the type pix_offsets are stored in
     # (the fluid form: one workgroup per CU with two tile slots, 16 waves for fp32 pair math, 12 for fp64; shells of < 512 tiles or fewer than 6e5 halos per sphere: the barrier form)
     k1 = "tile_scatter2f_kernel" if (12 * args.nside ** 2 >= 2 * 256 * 2048 and nh >= 600000) else "tile_scatter2_kernel"
-    names = {"offsets": ("%s<OFFSETS, %s>" % (k1, real)) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
+    names = {"offsets": ("%s<OFFSETS, %s, %s%s>" % (k1, areal, real, ", parity" if acc == 3 else "")) if args.algo == 1 else "halo_scatter_kernel<OFFSETS>",
              # (<.., 0>: the lean gather, reach of one ring; <.., 2>: the walking kernel -- every tile on the S19 table)
-             "regrid": ("tile_regrid3_kernel<%s, %s, %d>" % (real, real, 2 if table == 's19' else 0)) if args.algo == 1 else "regrid_kernel",
+             "regrid": ("tile_regrid3_kernel<%s, %s, %d%s>" % (areal, real, 2 if table == 's19' else 0, ", split" if acc == 3 else "")) if args.algo == 1 else "regrid_kernel",
              "paint": ("%s<PAINT, double, %s>" % (k1, real)) if args.algo == 1 else "halo_scatter_kernel<PAINT>"}
     ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
     traffic = valu = src = None
-    if not args.acc_f64 and args.algo == 1:
-        traffic, valu, src = committed_traffic({"halos_per_gpu": nh, "nside": args.nside, "pairs_per_gpu": n_pairs, "table": table}, dom,
-                                               metric_has="PaintProfilesShell" if paint else "BaryonifyShell")
+    if args.algo == 1:
+        match = {"halos_per_gpu": nh, "nside": args.nside, "pairs_per_gpu": n_pairs, "table": table}
+        if not paint:
+            match["precision"] = PRECISION_NAMES[acc]
+        traffic, valu, src = committed_traffic(match, dom, metric_has="PaintProfilesShell" if paint else "BaryonifyShell")
     r = {"kernel": names[dom], "algo": args.algo, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg[dom],
          "launch_ms": kernels[dom]}

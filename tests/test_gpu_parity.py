@@ -49,6 +49,20 @@ def test_hip_vs_reference_golden_f32_accumulators(gpu, name, algo):
         assert np.abs(out - exp).max() <= 1e-5 * np.abs(exp).max()
 
 
+@pytest.mark.parametrize('name', [n for n in GOLDEN_CASES if n.endswith('baryonify')])
+def test_hip_vs_reference_golden_parity_grade_and_default(gpu, name):
+    """BFGX_ACC_PARITY (fp64 pair math with 1e-11 elementary functions, split fp32 pix_offsets, fp64 regrid geometry; on these small shells
+    the barrier-per-tile form of the fast kernel and the lean regrid) and the DEFAULT (BFGX_ACC_AUTO: the plan picks from the table) against
+    the reference's own output: SURVEY 8(d)'s 1e-6 mean(map) for the default whatever the table, 1e-8 for the parity-grade mode"""
+    g = load_golden(name)
+    exp = g['expected']
+    out = run(g, 'parity', 1)
+    assert out.dtype == np.float64 and np.abs(out - exp).max() <= 1e-8 * exp.mean()
+    assert np.isclose(out.sum(), g['map_in'].sum(), rtol=1e-12)
+    out = run(g, None, 1)
+    assert np.abs(out - exp).max() <= 1e-6 * exp.mean() and np.isclose(out.sum(), g['map_in'].sum())
+
+
 @pytest.mark.parametrize('name,algo', CASES)
 def test_hip_vs_oracle(gpu, name, algo):
     g = load_golden(name)
@@ -58,8 +72,9 @@ def test_hip_vs_oracle(gpu, name, algo):
 
 
 def test_default_accumulators(gpu):
-    """defaults: BaryonifyShell f32 pair math + f32 pix_offsets; PaintProfilesShell f32 pair math accumulated in f64 into the f64 map
-    (stated tolerance 5e-5 of the pixel's value); acc_f64 = True is fp64 throughout"""
+    """defaults: BaryonifyShell picks its precision from the table (fp32 pair math + fp32 pix_offsets while the table moves a pixel by less than
+    0.4 pixel sides, the parity-grade mode beyond: 1e-6 mean(map) either way); PaintProfilesShell f32 pair math accumulated in f64 into the f64
+    map (stated tolerance 5e-5 of the pixel's value); acc_f64 = True is fp64 throughout"""
     g = load_golden('lowz_baryonify')
     r = product_runner(g)
     out = r.process()
@@ -71,6 +86,37 @@ def test_default_accumulators(gpu):
     assert np.abs(out - exp).max() > 1e-10 * np.abs(exp).max()                       # (it IS the mixed mode)
     out = product_runner(g, acc_f64=True).process()
     assert np.abs(out - exp).max() <= 1e-10 * np.abs(exp).max()
+
+
+def test_plan_picks_its_precision_from_the_table(gpu):
+    """BFGX_ACC_AUTO: fp32 pair math while the table cannot move a pixel by more than 0.4 pixel sides of the plan's NSIDE, the parity-grade mode
+    beyond; a table the fast kernel cannot take (a property axis) resolves the parity-grade mode to fp64 throughout; explicit requests stay"""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    cat = syn.make_catalog(1000)
+    z, M, r = syn.table_grid(cat, pad=1e-3)
+    axes = [np.log(1 + z), np.log(M), np.log(r)]
+    d = syn.displacement_table(z, M, r)
+    st = torch.cuda.current_stream().cuda_stream
+    got = {}
+    for nside, scale in ((1024, 1.0), (1024, 40.0), (64, 40.0), (4096, 8.0)):
+        model, keep = engine.model_from_tables(axes, scale * d, syn.COSMO, 10.0, 10.0)
+        plan = engine.ShellPlan(model, keep, nside, 1000, 0, st)
+        got[(nside, scale)] = plan.precision(_lib.ACC_AUTO)
+        assert plan.precision(_lib.ACC_F32)[0] == _lib.ACC_F32 and plan.precision(_lib.ACC_F64)[0] == _lib.ACC_F64
+        assert plan.precision(_lib.ACC_PARITY)[0] == _lib.ACC_PARITY
+        plan.close()
+    assert got[(1024, 1.0)][0] == _lib.ACC_F32 and 0.01 < got[(1024, 1.0)][1] < 0.4, got
+    assert got[(1024, 40.0)][0] == _lib.ACC_PARITY and np.isclose(got[(1024, 40.0)][1], 40 * got[(1024, 1.0)][1], rtol=1e-9), got
+    assert got[(64, 40.0)][0] == _lib.ACC_F32 and np.isclose(got[(64, 40.0)][1] * 16, got[(1024, 40.0)][1], rtol=1e-9), got      # coarse pixels
+    assert got[(4096, 8.0)][0] == _lib.ACC_PARITY and got[(4096, 8.0)][1] < got[(1024, 40.0)][1], got                           # fine pixels
+    # a 4-axis table (model.p_keys): the generic tile kernel -- the parity-grade request runs as fp64 throughout there
+    p = np.linspace(0.5, 1.5, 3)
+    d4 = 40.0 * d[..., None] * p[None, None, None, :]
+    model, keep = engine.model_from_tables(axes + [p], d4, syn.COSMO, 10.0, 10.0)
+    plan = engine.ShellPlan(model, keep, 1024, 1000, 0, st)
+    assert plan.precision(_lib.ACC_AUTO)[0] == _lib.ACC_F64 and plan.precision(_lib.ACC_PARITY)[0] == _lib.ACC_F64
+    plan.close()
 
 
 def test_empty_catalog(gpu):

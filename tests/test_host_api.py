@@ -280,10 +280,18 @@ def test_host_entry_in_band_ranges_equals_one_pass(gpu, case, monkeypatch):
         used = {k: np.array(Catalog.cat[k]) for k in ('M', 'z', 'ra', 'dec')}
         ora = O.baryonify_shell(nside, hmap, used, O.Table([np.log(1 + z), np.log(M), np.log(r)], d, False, 10.0), 10.0, O.Background.from_dict(syn.COSMO))
         assert np.abs(piped - ora).max() <= 1e-10 * hmap.max()
-    # fp32 accumulators (the default) through the same route
+    # fp32 pair math through the same route
     runner.acc_f64 = False
     p32 = runner.process()
     assert np.abs(p32 - piped).max() <= 1e-5 * max(1.0, scale) * hmap.mean() and np.isclose(p32.sum(), hmap.sum(), rtol=1e-9)
+    # the parity-grade mode (split fp32 pix_offsets: the band-range route hands the regrid both halves) and the default, where the plan
+    # picks from the table: both within SURVEY 8(d)'s 1e-6 mean(map) of fp64 throughout whatever the displacement
+    runner.acc_f64 = 'parity'
+    ppar = runner.process()
+    assert np.abs(ppar - piped).max() <= 1e-8 * hmap.mean() and np.isclose(ppar.sum(), hmap.sum(), rtol=1e-12)
+    runner.acc_f64 = None
+    pdef = runner.process()
+    assert np.abs(pdef - piped).max() <= 1e-6 * hmap.mean() and np.isclose(pdef.sum(), hmap.sum(), rtol=1e-9)
 
 
 @pytest.mark.gpu
