@@ -26,6 +26,7 @@
 // every device allocation the library makes is counted (bfgx_debug_alloc_count): a warm one-shot call must make none
 #include <atomic>
 static std::atomic<long long> g_bfgx_allocs{0};
+static std::atomic<long long> g_host_pinned_in_place{0}, g_host_staged{0}, g_host_pin_min_bytes{-1};      // HostSpan (bfgx_debug_host_spans)
 template <typename T> static inline hipError_t bfgx_counted_malloc(T **p, size_t bytes) { ++g_bfgx_allocs; return hipMalloc((void **)p, bytes); }
 #define hipMalloc(ptr, bytes) bfgx_counted_malloc(ptr, bytes)
 #include "bfgx_cosmo.hpp"
@@ -1553,13 +1554,20 @@ struct HostSpan {
         if (hipPointerGetAttributes(&at, q) == hipSuccess && at.type == hipMemoryTypeHost) { use = user; return true; }
         (void)hipGetLastError();
         if (nb >= kPinInPlaceMin) {
-            if (hipHostRegister(user, nb, hipHostRegisterDefault) == hipSuccess) { registered = true; use = user; return true; }
+            if (hipHostRegister(user, nb, hipHostRegisterDefault) == hipSuccess) {
+                registered = true; use = user;
+                ++g_host_pinned_in_place;
+                long long m = g_host_pin_min_bytes.load();
+                while ((m < 0 || (long long)nb < m) && !g_host_pin_min_bytes.compare_exchange_weak(m, (long long)nb)) {}
+                return true;
+            }
             (void)hipGetLastError();
             return false;
         }
         if (!stage) return false;
         if (hipHostMalloc(&use, nb ? nb : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); use = nullptr; return false; }
         staged = true;
+        ++g_host_staged;
         if (!out) std::memcpy(use, q, nb);
         return true;
     }
@@ -1797,6 +1805,13 @@ int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d,
 }  // namespace
 
 long long bfgx_debug_catalog_uploads(void) { return g_catalog_uploads.load(); }
+
+void bfgx_debug_host_spans(long long *pinned_in_place, long long *staged, long long *smallest_pinned_bytes)
+{
+    if (pinned_in_place) *pinned_in_place = g_host_pinned_in_place.load();
+    if (staged) *staged = g_host_staged.load();
+    if (smallest_pinned_bytes) *smallest_pinned_bytes = g_host_pin_min_bytes.load();
+}
 
 void bfgx_cache_clear(void)
 {

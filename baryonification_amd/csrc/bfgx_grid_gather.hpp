@@ -80,8 +80,10 @@ template <int DIM, int NC>
 __global__ void __launch_bounds__(256, 6)
 grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restrict__ recs, const int32_t *__restrict__ blk_start,
                           const int32_t *__restrict__ blk_list, const int32_t *__restrict__ blk_nz, const double *__restrict__ map_in,
-                          double *__restrict__ map_out, double *__restrict__ block_sums)
+                          double *__restrict__ map_out, double *__restrict__ block_sums, float axis0_limit, int32_t *__restrict__ axis0_flag)
 {
+    // (axis0_flag: set when a cell moves further than axis0_limit cells along the FIRST array axis -- the streamed host entry gathers the map in
+    // ranges of planes and must know when a deposit could leave the planes it has in hand; nullptr: not wanted)
     // Two phases per batch of kGatherBatch halos.  (1) every thread tests its cells against the halos' bounding boxes and a
     // conservative r^2 bound (integer + a few fp64 operations per (halo, cell)) and queues the survivors in LDS -- a ball fills a
     // few per cent of the blocks it touches, so running the table readout under that test would leave most lanes idle.  (2) the
@@ -229,6 +231,7 @@ grid_gather_regrid_kernel(PairTable pt, GridGeom g, const GridHaloRec *__restric
 #pragma unroll
         for (int q = 0; q < DIM; ++q) if (!isfinite(o[c][q])) o[c][q] = 0.0;       // :580 / :591
         if (o[c][0] == 0.0 && o[c][1] == 0.0 && o[c][2] == 0.0) continue;
+        if (axis0_flag != nullptr && fabs(o[c][1]) > (double)axis0_limit) atomicOr(axis0_flag, 1);      // (pos[1] moves along the first array axis; rare)
         const int64_t p = (DIM == 3) ? ((int64_t)pc[c][0] * N + pc[c][1]) * N + pc[c][2] : (int64_t)pc[c][0] * N + pc[c][1];
         const double v = map_in[p];
         if (v == 0.0) continue;                          // an empty cell adds exactly nothing

@@ -186,6 +186,10 @@ void      bfgx_cache_clear(void);
 long long bfgx_debug_alloc_count(void);
 /* catalog copies host -> device made by the one-shot entries so far (tests: a call that repeats bfgx_opts.catalog_token makes none) */
 long long bfgx_debug_catalog_uploads(void);
+/* how the one-shot host entries have treated the caller's arrays so far (tests): arrays page-locked IN PLACE for a call (hipHostRegister; only
+ * arrays of >= 32 MiB, which own their pages -- DESIGN.md section 9 "the two GPU memory faults of round 4"), arrays staged through a page-locked
+ * buffer of the library's, and the smallest array ever page-locked in place (-1: none).  Any pointer may be NULL. */
+void bfgx_debug_host_spans(long long *pinned_in_place, long long *staged, long long *smallest_pinned_bytes);
 int       bfgx_host_alloc(size_t bytes, void **out);
 void      bfgx_host_free(void *p);
 

@@ -42,13 +42,24 @@ def test_default_mode_line_small(gpu):
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0
     assert 'value_acc_f64' in d and 'end_to_end' in d and d['end_to_end']['mass_conserved'] is True
     assert set(d['kernel_ms']) >= {'prep', 'offsets', 'regrid'}
-    assert d['backend'] is None and d['world_size_seen'] == 1 and '20000-halo' in d['metric'] and d['config']['table'] == 'closed-form'
-    # SURVEY 8(d) table (ii) rides along: the same step on the Schneider19 table the GPU builders make
-    s19 = d['value_s19']
-    assert s19['value'] > 0 and s19['mass_conserved'] is True and s19['acc_f64']['value'] > 0 and s19['table_abs_max_mpc'] > 1.0
-    assert s19['regrid']['far_overflowed'] is False and s19['regrid']['max_reach_rings'] >= 1
-    for r in (s19['roofline'], s19['roofline_regrid']):
+    # the headline runs SURVEY 8(d) table (ii), the Schneider19 benchmark table, in the default precision (the plan picks from the table and says so)
+    assert d['backend'] is None and d['world_size_seen'] == 1 and '20000-halo' in d['metric'] and d['config']['table'] == 's19'
+    assert d['config']['precision'] in ('f32', 'parity') and d['config']['precision_requested'] == 'auto' and d['config']['table_disp_pixels'] > 0
+    assert d['roofline']['kernel'].startswith('tile_') and d['roofline']['launch_ms'] > 0          # (at this size K2 may be the dominant one)
+    # fp64 throughout (the reference's own arithmetic) rides along WITH its kernel times and roofline
+    f64 = d['value_acc_f64']
+    assert f64['precision'] == 'f64' and f64['value'] > 0 and set(f64['kernel_ms']) >= {'prep', 'offsets', 'regrid'} and f64['mass_conserved'] is True
+    assert 'double, double' in f64['roofline']['kernel'] and 'tile_regrid3_kernel<double, double' in f64['roofline_regrid']['kernel']
+    # table (i), the closed-form plumbing table (rounds 1-4 quoted it as `value`), in the default precision
+    cf = d['value_closed_form']
+    assert cf['value'] > 0 and cf['mass_conserved'] is True and cf['acc_f64']['value'] > 0 and cf['precision'] in ('f32', 'parity')
+    assert cf['regrid']['far_overflowed'] is False and cf['regrid']['max_reach_rings'] >= 1
+    for r in (cf['roofline'], cf['roofline_regrid'], f64['roofline'], f64['roofline_regrid']):
         assert r['bound'] == 'hbm' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    # the other table as the headline, one precision forced
+    d = _run('--halos', '20000', '--nside', '128', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--table', 'closed-form', '--precision', 'parity')
+    _check_common(d)
+    assert d['config']['table'] == 'closed-form' and d['config']['precision'] == 'parity' and 'value_s19' in d and 'value_f32' in d and d['mass_conserved'] is True
 
 
 def test_paint_and_grid_lines_small(gpu):

@@ -398,3 +398,57 @@ def test_catalog_fingerprint_without_xxhash(monkeypatch):
     cat['M'][777] *= 1.0000001
     assert HR._catalog_fingerprint(cat, names) != f0
     assert HR._catalog_fingerprint(cat[:0], names)[3] == 0
+
+
+@pytest.mark.gpu
+def test_round4_fault_sequence_small_arrays_are_never_page_locked_in_place(gpu, monkeypatch):
+    """The call sequence in front of the two GPU memory faults of round 4 (gpurun_out/r04_t20.log, r04_t27.log), replayed in
+    one process: (1) the streamed route of bfgx_baryonify_shell forced onto a small map (BFGX_PIPE_CHUNKS), which then page-locked the caller's
+    map_in / map_out IN PLACE; (2) ParticleSnapshot.make_map on a 5-particle snapshot, whose records entry page-locked a 160-byte array;
+    (3) the ordinary one-shot calls that faulted (bfgx_baryonify_shell on a 393 KB map, bfgx_baryonify_grid on a 2 MB map): plain pageable
+    copies from heap arrays that share pages with what (1) / (2) had registered and unregistered.  Small arrays sit in the process heap
+    beside other live objects; hipHostRegister works on whole pages, so two such registrations (or one and the runtime's own pinning of a
+    pageable copy) overlap on the shared boundary pages and unregistering one takes the other's mapping with it.  The invariant that
+    removes it: the one-shot entries page-lock a caller's array in place only when it owns its pages (>= 32 MiB: a mapping of its own)."""
+    import ctypes as C
+    import baryonification_amd as bfg
+    from baryonification_amd import _lib, synthetic as syn
+    import helpers as H
+    lib = _lib.load()
+
+    def spans():
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        lib.bfgx_debug_host_spans(C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+    pinned0, staged0, _ = spans()
+    # (1) the streamed shell route on a small map
+    nside, N = 128, 4000
+    cat = syn.make_catalog(N, seed=3, logM_lo=13.0, logM_hi=14.5)
+    z, M, r = syn.table_grid(cat, pad=1e-3)
+    model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO), epsilon_max=10.0)
+    model.set_table(z, M, r, syn.displacement_table(z, M, r))
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    hmap = syn.make_map(nside)
+    runner = bfg.Runners.BaryonifyShell(Catalog, bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO), 10.0, model, verbose=False)
+    runner.acc_f64 = True
+    monkeypatch.setenv('BFGX_PIPE_CHUNKS', '4')
+    piped = runner.process()
+    monkeypatch.delenv('BFGX_PIPE_CHUNKS')
+    pinned1, staged1, smallest1 = spans()
+    assert pinned1 == pinned0, "a 1.5 MB map was page-locked in place"
+    assert staged1 >= staged0 + 1                                  # (it went through a page-locked staging buffer of the library's)
+    # (2) the records entry on a 5-particle snapshot
+    cos = syn.COSMO
+    Snap = bfg.utils.ParticleSnapshot(x=np.array([1.0, 2.0, 3.0, 4.0, 5.0]), y=np.array([1.0, 2.0, 3.0, 4.0, 5.0]), z=np.array([1.0, 2.0, 3.0, 4.0, 5.0]),
+                                      M=np.ones(5), L=10.0, redshift=0.0, cosmo=cos)
+    m5 = Snap.make_map(8)
+    assert m5.sum() == 5.0
+    # (3) the two ordinary calls that faulted: results must be right, and nothing small may have been page-locked in place on the way
+    whole = runner.process()
+    assert np.abs(whole - piped).max() <= 1e-12 * hmap.max() and np.isclose(whole.sum(), hmap.sum(), rtol=1e-12)
+    c = H.load_grid_golden('grid3d_baryonify')
+    out = H.grid_product_runner(c).process()
+    assert np.abs(out - c['expected']).max() <= 1e-10 * np.abs(c['expected']).max()
+    pinned2, _, smallest2 = spans()
+    assert pinned2 == pinned0
+    assert smallest2 < 0 or smallest2 >= (32 << 20)                # whatever this process page-locked in place before owned its pages
