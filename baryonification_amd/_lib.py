@@ -106,6 +106,7 @@ SYMBOLS = {
     'bfgx_cache_clear': (None, []),
     'bfgx_debug_alloc_count': (C.c_longlong, []),
     'bfgx_debug_catalog_uploads': (C.c_longlong, []),
+    'bfgx_debug_grid_pipe_fallbacks': (C.c_longlong, []),
     'bfgx_debug_host_spans': (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'bfgx_host_alloc': (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     'bfgx_host_free': (None, [C.c_void_p]),

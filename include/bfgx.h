@@ -190,6 +190,9 @@ long long bfgx_debug_catalog_uploads(void);
  * arrays of >= 32 MiB, which own their pages -- DESIGN.md section 9 "the two GPU memory faults of round 4"), arrays staged through a page-locked
  * buffer of the library's, and the smallest array ever page-locked in place (-1: none).  Any pointer may be NULL. */
 void bfgx_debug_host_spans(long long *pinned_in_place, long long *staged, long long *smallest_pinned_bytes);
+/* streamed bfgx_baryonify_grid calls so far that found a cell moving further along the first array axis than their plane ranges allow (2^S - 1 cells:
+ * 7 in 3-D, 15 in 2-D) and repeated the regrid in one pass on the uploaded map (tests) */
+long long bfgx_debug_grid_pipe_fallbacks(void);
 int       bfgx_host_alloc(size_t bytes, void **out);
 void      bfgx_host_free(void *p);
 

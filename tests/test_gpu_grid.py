@@ -778,6 +778,43 @@ def test_grid_host_entry_in_plane_ranges_equals_one_pass(gpu, monkeypatch, ndim,
     assert np.abs(piped - ora).max() <= 1e-10 * np.abs(ora).max()
 
 
+@pytest.mark.parametrize('ndim,N,nh,chunks,scale', [(3, 96, 300, 6, 3000.0), (2, 512, 200, 8, 6000.0)])
+def test_grid_host_entry_in_plane_ranges_with_large_moves_along_the_first_axis(gpu, monkeypatch, ndim, N, nh, chunks, scale):
+    """The streamed route gathers the map in ranges of planes of the first array axis, and a deposit may only travel 2^S - 1 cells (7 in 3-D, 15
+    in 2-D) along that axis before it could land in planes that have not arrived yet or have already left (the mass check would not notice:
+    its sums are arithmetic).  A table scaled until cells move by tens of cells: the gather kernel flags it and the call repeats the regrid in
+    one pass on the uploaded map -- the result equals the one-pass route; a table with small moves does not take the fallback"""
+    import baryonification_amd as bfg
+    from baryonification_amd import _lib
+    lib = _lib.load()
+    c = _big_case(ndim, N, nh, 77)
+    cat = c['cat']
+    for sc, expect_fallback in ((scale, True), (1.0, False)):
+        model = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(c['cosmo']), epsilon_max=8.0)
+        model.set_table(c['z'], c['Mt'], c['r'], sc * c['d'])
+        kw = dict(x=cat['x'], y=cat['y'], M=cat['M'], redshift=c['redshift'], cosmo=c['cosmo'])
+        if ndim == 3:
+            kw['z'] = cat['z']
+        HCat = bfg.utils.HaloNDCatalog(**kw)
+        GMap = bfg.utils.GriddedMap(map=c['map'], redshift=c['redshift'], bins=c['bins'], cosmo=c['cosmo'])
+        runner = bfg.Runners.BaryonifyGrid(HCat, GMap, 6.0, model, verbose=False)
+        monkeypatch.setenv('BFGX_NO_PIPELINE', '1')
+        one = runner.process().copy()
+        monkeypatch.delenv('BFGX_NO_PIPELINE')
+        monkeypatch.setenv('BFGX_PIPE_CHUNKS', str(chunks))
+        n0 = lib.bfgx_debug_grid_pipe_fallbacks()
+        piped = runner.process().copy()
+        n1 = lib.bfgx_debug_grid_pipe_fallbacks()
+        monkeypatch.delenv('BFGX_PIPE_CHUNKS')
+        assert (n1 - n0 == 1) == expect_fallback, (sc, n0, n1)
+        assert np.isclose(piped.sum(), c['map'].sum()) and not np.array_equal(one, c['map'])
+        assert np.abs(piped - one).max() <= 1e-12 * np.abs(one).max()
+        if expect_fallback:
+            # the moves really are large: mass has travelled more than a block row from where it was
+            moved = np.abs(one - c['map'])
+            assert moved.max() > 0.5 * np.abs(c['map']).max()
+
+
 def test_make_map_records_entry_equals_columns(gpu):
     """ParticleSnapshot.make_map hands the structured array to the library as it is (bfgx_deposit_particles_records: fields read at their
     stride on the device) == the column entry a catalog with an unaligned layout falls back to"""
