@@ -70,7 +70,7 @@ class SchneiderProfiles(object):
     model_param_names = model_params
 
     def __init__(self, mass_def=None, use_fftlog_projection=False, padding_lo_proj=0.1, padding_hi_proj=10,
-                 n_per_decade_proj=10, xi_mm=None, bias=None, **kwargs):
+                 n_per_decade_proj=10, xi_mm=None, bias=None, c_of_M=None, **kwargs):
         if use_fftlog_projection:
             raise NotImplementedError("FFTLog projection is not part of this build; the real-space projection is")
         for m in self.model_param_names:              # defaults as Schneider19.py:84-92
@@ -85,6 +85,9 @@ class SchneiderProfiles(object):
         self.padding_lo_proj, self.padding_hi_proj, self.n_per_decade_proj = padding_lo_proj, padding_hi_proj, n_per_decade_proj
         self.mass_def = mass_def if mass_def is not None else MassDef(200, 'critical')
         self.xi_mm, self.bias = xi_mm, bias
+        # c_of_M(cosmo, M, a) -> concentration: stands in for ccl's ConcentrationDiemer15 when cdelta is None (Schneider19.py:390-397: the reference's
+        # default_config has cdelta = None).  A pyccl user passes  lambda cosmo, M, a: ccl.halos.ConcentrationDiemer15(mass_def=md)(cosmo, M, a)
+        self.c_of_M = c_of_M
         self.cutoff = kwargs.get('cutoff', 1e3)
         self.proj_cutoff = kwargs.get('proj_cutoff', self.cutoff)
         self._projected = self._projected_realspace
@@ -134,7 +137,7 @@ class SchneiderProfiles(object):
     def _combine(self, other, op, reflect=False):
         assert isinstance(other, (int, float, SchneiderProfiles)), \
             f"Object must be int/float/SchneiderProfile but is type '{type(other).__name__}'."
-        out = self.__class__(**self.model_params, xi_mm=self.xi_mm, bias=self.bias, padding_lo_proj=self.padding_lo_proj,
+        out = self.__class__(**self.model_params, xi_mm=self.xi_mm, bias=self.bias, c_of_M=self.c_of_M, padding_lo_proj=self.padding_lo_proj,
                              padding_hi_proj=self.padding_hi_proj, n_per_decade_proj=self.n_per_decade_proj)
         me = self
 
@@ -171,7 +174,11 @@ class SchneiderProfiles(object):
     # -- shared pieces --------------------------------------------------------------------------------
     def _concentration(self, cosmo, M, a):
         if self.cdelta is None:
-            raise NotImplementedError("cdelta=None needs the Diemer15 c(M) relation (CCL sigma(M)); pass cdelta")
+            if self.c_of_M is None:
+                raise NotImplementedError("cdelta=None needs the Diemer15 c(M) relation (CCL sigma(M)): pass cdelta, or c_of_M=callable(cosmo, M, a) "
+                                          "(with pyccl: ccl.halos.ConcentrationDiemer15)")
+            c = np.asarray(self.c_of_M(cosmo, np.atleast_1d(M), a), dtype=np.float64)
+            return c * np.ones_like(M, dtype=np.float64)
         return self.cdelta * np.ones_like(M, dtype=np.float64)
 
     def _star_fraction(self, M, tau, eta):
@@ -190,9 +197,9 @@ class SchneiderProfiles(object):
         return [v[:, None] for v in (beta, scaled('theta_ej'), scaled('theta_co'), scaled('delta'), scaled('gamma'))]
 
 
-def _dm_total_mass(par, cosmo, M, a):
+def _dm_total_mass(par, cosmo, M, a, c_of_M=None):
     """trapz(4 pi r^2 rho_DM) on the 500-point grid with the DM cutoff lifted (e.g. :609-613)"""
-    DM = DarkMatter(**par)
+    DM = DarkMatter(**par, c_of_M=c_of_M)
     DM.cutoff = 1e3
     rho = DM.real(cosmo, _R500, M, a)
     return np.atleast_1d(np.trapz(4 * np.pi * _R500 ** 2 * rho, _R500, axis=-1))[:, None]
@@ -228,7 +235,7 @@ class Stars(SchneiderProfiles):
         R = self._R(cosmo, M_use, a)
         f_cga = self._star_fraction(M_use, self.tau + self.tau_delta, self.eta + self.eta_delta)[:, None]
         R_h = (self.epsilon_h * R)[:, None]
-        M_tot = _dm_total_mass(self.model_params, cosmo, M_use, a)
+        M_tot = _dm_total_mass(self.model_params, cosmo, M_use, a, self.c_of_M)
         prof = f_cga * M_tot / (4 * np.pi ** (3 / 2) * R_h) * 1 / r_use ** 2 * np.exp(-(r_use / 2 / R_h) ** 2)
         return _squeeze(prof * _kfac(r_use, self.cutoff), r, M)
 
@@ -246,7 +253,7 @@ class Gas(SchneiderProfiles):
         beta, theta_ej, theta_co, delta, gamma = self._gas_params(M_use, 1 / a - 1)
         R_co, R_ej = theta_co * R[:, None], theta_ej * R[:, None]
         norm = np.trapz(4 * np.pi * _R500 ** 2 * self._shape(_R500, R_co, R_ej, beta, delta, gamma), _R500, axis=-1)[:, None]
-        M_tot = _dm_total_mass(self.model_params, cosmo, M_use, a)
+        M_tot = _dm_total_mass(self.model_params, cosmo, M_use, a, self.c_of_M)
         prof = self._shape(r_use, R_co, R_ej, beta, delta, gamma) * _kfac(r_use, self.cutoff)
         return _squeeze(prof * (f_gas * M_tot / norm), r, M)
 

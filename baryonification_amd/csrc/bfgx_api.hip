@@ -135,6 +135,8 @@ struct bfgx_plan {
     double table_disp_pixels = 0.0;  // largest |d| a / D_A of the table within its model-side cut, in pixel sides of this plan's NSIDE
     float *offsets_lo = nullptr;     // set while a BFGX_ACC_PARITY call is in flight: the low halves of the split pix_offsets
     int k1_tile_lo = 0, k1_tile_n = -1;   // tiles K1 / K3 process (-1: the whole sphere); set by the *_bands_device entries
+    int k1_spread_tiles = -1;             // tiles the binned catalog is spread over when that is NOT the tile range of the launch (the one-shot paint entry bins
+                                          // the whole catalog once and launches K3 range by range: the density that picks the kernel's form is per sphere); -1: the launch's tiles
     int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
     int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
     int route_margin = 0;            // rings by which bfgx_disc_rings_device widens every halo's range (bfgx_plan_set_route_margin)
@@ -434,11 +436,12 @@ static int launch_tile_scatter2(bfgx_plan *p, ACC *out, ACC *out_lo = nullptr)
         // per sphere the fluid form is taken outright; below, K0's per-workgroup sums of the halos' estimated pixels decide ON THE DEVICE
         // (k1_form_kernel) and both forms are launched -- the one not chosen returns at once (~5 us).
         const bool eligible = p->k1_fluid && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave && ntodo >= 2 * p->num_cus;
-        const bool dense = (double)p->k1_nhalos * (double)p->tiling.ntiles >= 6.0e5 * (double)ntodo;
+        const int nspread = p->k1_spread_tiles > 0 ? p->k1_spread_tiles : ntodo;      // (the tiles the binned halos cover)
+        const bool dense = (double)p->k1_nhalos * (double)p->tiling.ntiles >= 6.0e5 * (double)nspread;
         const bool forced = p->k1_fluid == 2 && ldsf <= (size_t)160 * 1024 && p->tiling.BR <= kWave;
         if (eligible && !dense && !forced && p->k0_work_est && p->k1_nhalos > 0) {
             const int nblk = (int)((p->k1_nhalos + 255) / 256);
-            hipLaunchKernelGGL(k1_form_kernel, dim3(1), dim3(1024), 0, p->stream, nblk, (const float *)p->k0_work_est, 4800.0f * (float)ntodo, p->k1_form);
+            hipLaunchKernelGGL(k1_form_kernel, dim3(1), dim3(1024), 0, p->stream, nblk, (const float *)p->k0_work_est, 4800.0f * (float)nspread, p->k1_form);
             form = p->k1_form;
         }
         if (forced || (eligible && (dense || form))) {
@@ -681,7 +684,9 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
 {
     if (!model || !out) return fail(BFGX_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (nside < 1 || nside > (int64_t(1) << 24)) return fail(BFGX_ERR_INVALID, "nside out of range");
+    // (NSIDE 16384 has 3.2e9 pixels: the tile kernels keep first-pixel-of-ring offsets and per-tile counters in 32 bits -- RowScan.start, the
+    // walking regrid; 8192, 8.05e8 pixels / 6.4 GB of fp64 map, is the largest shell that is tested)
+    if (nside < 1 || nside > 8192) return fail(BFGX_ERR_INVALID, "nside must be 1 .. 8192 (the tile kernels index pixels with 32 bits inside a ring table)");
     if (max_halos < 0) return fail(BFGX_ERR_INVALID, "max_halos < 0");
     if (int rc = validate_model(model)) return rc;
     if (bfgx_device_count() <= 0)
@@ -821,7 +826,13 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
             // displacements add up to 15 pixels on average and 58 % of the pixels move beyond the 15-ring reach: 1.4e8 listed deposits,
             // 2.8 per pixel.  A list for half the pixels overflowed into the repair pass: K2 35 ms; with room for four deposits of EVERY
             // pixel, 4.3 GB at most, 10 ms.)
-            p->far.cap = std::min<int64_t>(std::max<int64_t>((int64_t)1 << 20, 4 * p->hpx.npix), (int64_t)1 << 28);
+            // Sized from the table (ADVICE, round 4): a listed deposit needs a pixel that moves beyond 9.7 pixel sides in total.  Tables that move a
+            // pixel by less than a quarter of a pixel per halo list the pole caps only (a few dozen entries): room for 1 / 16 of the pixels
+            // (16 B each: 13 MB at NSIDE 1024 instead of 0.8 GB); up to two pixels per halo: half the pixels; beyond: four deposits of every pixel.
+            // A list that overflows all the same (many overlapping discs) is repaired in-stream by the regrid's last pass.
+            const int64_t npx = p->hpx.npix;
+            const int64_t want = p->table_disp_pixels < 0.25 ? npx / 16 : (p->table_disp_pixels < 2.0 ? npx / 2 : 4 * npx);
+            p->far.cap = std::min<int64_t>(std::max<int64_t>((int64_t)1 << 20, want), (int64_t)1 << 28);
             if (const char *e = std::getenv("BFGX_FAR_CAP")) p->far.cap = std::max<int64_t>(1024, std::atoll(e));          // tests: force the overflow
             // control words in one allocation: [0..7] entries listed, [8..11] overflow (full-map regrid), [12..15] tiles left to
             // the walking kernel (followed by their numbers), ... ; the banded regrid's overflow flag lives after the tile list
@@ -2093,7 +2104,8 @@ int bfgx_paint_shell(const bfgx_catalog *cat, const bfgx_model *model, int64_t n
         if (int rc = launch_prep_and_bin(p, &dcat, 0, !mixed)) return rc;
         if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, &dcat)) return rc;
         p->paint_pair_f32 = mixed;
-        struct Reset { bfgx_plan *p; ~Reset() { p->paint_pair_f32 = false; p->k1_tile_lo = 0; p->k1_tile_n = -1; } } reset{p};
+        struct Reset { bfgx_plan *p; ~Reset() { p->paint_pair_f32 = false; p->k1_tile_lo = 0; p->k1_tile_n = -1; p->k1_spread_tiles = -1; } } reset{p};
+        p->k1_spread_tiles = p->tiling.ntiles;           // K0 has binned the WHOLE catalog; every range launch sees the same density (ADVICE, round 4)
         for (int c = 0; c < kChunks; ++c) {
             p->k1_tile_lo = p->band_tile0_host[cb[c]];
             p->k1_tile_n = p->band_tile0_host[cb[c + 1]] - p->k1_tile_lo;

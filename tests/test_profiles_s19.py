@@ -70,6 +70,27 @@ def test_profile_protocol(T):
         bfg.Profiles.TwoHalo(**par).real(cosmo, r, 1e14, 0.8)
     with pytest.raises(NotImplementedError):
         bfg.Profiles.DarkMatter(**dict(par, cdelta=None)).real(cosmo, r, 1e14, 0.8)
+    # cdelta = None (the reference's default_config: Diemer15, Schneider19.py:390-397) with a user's c(M): a constant c_of_M == cdelta, and a
+    # mass-dependent one reaches the sub-profiles and the arithmetic of profiles too
+    calls = []
+
+    def c7(cosmo_, M_, a_):
+        calls.append((np.shape(M_), a_))
+        return par['cdelta'] * np.ones_like(M_)
+    dmc = bfg.Profiles.DarkMatter(**dict(par, cdelta=None), c_of_M=c7)
+    assert np.allclose(dmc.real(cosmo, r, np.array([1e13, 1e14]), 0.8), dm.real(cosmo, r, np.array([1e13, 1e14]), 0.8), rtol=1e-14) and calls
+    cm = lambda cosmo_, M_, a_: 5.0 * (np.asarray(M_) / 1e14) ** -0.1
+    dmm = bfg.Profiles.DarkMatter(**dict(par, cdelta=None), c_of_M=cm)
+    ref5 = bfg.Profiles.DarkMatter(**dict(par, cdelta=5.0)).real(cosmo, r, 1e14, 0.8)
+    assert np.allclose(dmm.real(cosmo, r, 1e14, 0.8), ref5, rtol=1e-13)
+    assert not np.allclose(dmm.real(cosmo, r, 1e13, 0.8), bfg.Profiles.DarkMatter(**dict(par, cdelta=5.0)).real(cosmo, r, 1e13, 0.8), rtol=1e-3)
+    assert np.allclose((dmm + dmm).real(cosmo, r, 1e14, 0.8), 2 * ref5, rtol=1e-13)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        full = bfg.Profiles.DarkMatterBaryon(**dict(par, cdelta=None), c_of_M=cm).real(cosmo, r, 1e14, 0.8)
+        want = bfg.Profiles.DarkMatterBaryon(**dict(par, cdelta=5.0)).real(cosmo, r, 1e14, 0.8)
+    # (cdelta = None also sets c = 1 in the gas parameters' zeta powers, Schneider19.py:175: equal here because the zetas default to 0)
+    assert np.allclose(full, want, rtol=1e-12)
 
 
 # ------------------------------------------------------------------------------------------------- GPU
