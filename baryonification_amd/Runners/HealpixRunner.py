@@ -150,7 +150,7 @@ class BaryonifyShell(DefaultRunner):
         nside = int(self.LightconeShell.NSIDE)
         new_map = _lib.pinned_empty(orig_map.size)          # page-locked: the D2H copy of the result runs at PCIe rate
         # acc_f64: None (default) / 'auto' = the engine picks the precision from the model's table -- fp32 pair math while the table moves a pixel
-        # by less than 0.4 pixel sides, the parity-grade mode (fp64 pair math, split fp32 pix_offsets, fp64 regrid geometry) beyond: either way
+        # by less than 0.1 pixel sides, the parity-grade mode (fp64 pair math, split fp32 pix_offsets, fp64 regrid geometry) beyond: either way
         # within SURVEY 8(d)'s 1e-6 mean(map) of the fp64 reference; True = fp64 throughout (1e-10), False = fp32 pair math whatever the table,
         # 'parity' = the parity-grade mode whatever the table (include/bfgx.h BFGX_ACC_*)
         opts = _lib.bfgx_opts(int(self.device), _lib.acc_mode(self.acc_f64), 1, 1, int(self.algo), 0)

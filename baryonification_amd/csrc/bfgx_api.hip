@@ -563,9 +563,10 @@ static void build_tiling(int64_t nside, bool paint, int &BR, int &W, std::vector
 // How far can this table move a pixel?  The largest |d(r)| a / D_A(z) over the table's (z, M) nodes within the model-side cut r < eps_model R
 // and the runner's disc, in pixel sides of the plan's NSIDE.  fp32 pair math carries ~4e-7 of every contribution, and the bilinear deposit turns
 // an error of e pixel sides in a source pixel's position into ~e of its value: 1e-6 mean(map) -- SURVEY 8(d)'s tolerance -- holds while a
-// halo moves a pixel by well under a pixel (measured: 2.4e-7 mean(map) at 0.2 pixels, 2.1e-5 at 20).  Beyond kAutoDispPixels the plan picks the
+// halo moves a pixel by a small fraction of a pixel (measured at config 2, closed-form table scaled: 2.6e-7 / 3.9e-7 / 1.3e-6 / 8.0e-6 mean(map) at 0.03 /
+// 0.09 / 0.31 / 0.93 pixel sides per halo; 2.1e-5 on the S19 table, which moves 8.6).  Beyond kAutoDispPixels the plan picks the
 // parity-grade mode.
-constexpr double kAutoDispPixels = 0.4;
+constexpr double kAutoDispPixels = 0.1;
 static void plan_pick_precision(bfgx_plan *p, const bfgx_model *model)
 {
     const bfgx_table &t = model->table;

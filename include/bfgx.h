@@ -37,13 +37,13 @@ extern "C" {
 /* Precision of the displacement path (the `acc_f64` argument of the *_device entries, bfgx_opts.acc_offsets_f64).  The reference computes in
  * float64 throughout (HealpixRunner.py:289-341); SURVEY 8(d) states the tolerance a faster mode must hold: |d| <= 1e-6 mean(map) per pixel.
  *   BFGX_ACC_F32    fp32 pair math and fp32 pix_offsets [npix][3] (fp64 ring-row geometry and accumulation).  Holds 1e-6 mean(map) while a halo moves
- *                   a pixel by less than ~0.4 pixel sides; its error grows with displacement / pixel (2e-5 at 20 pixels).
+ *                   a pixel by less than ~0.1 pixel sides (measured: 2.6e-7 / 3.9e-7 / 1.3e-6 / 8e-6 mean(map) at 0.03 / 0.09 / 0.3 / 0.9 pixels per halo, 2e-5 on a table that moves 9).
  *   BFGX_ACC_F64    fp64 throughout, pix_offsets double [npix][3]: the reference's own arithmetic, 1e-10 of the map scale.
  *   BFGX_ACC_PARITY the parity-grade mode: fp64 pair math whose elementary functions carry 1e-11 (fp32 hardware seeds + one Newton step), pix_offsets
  *                   as TWO fp32 arrays -- hi [npix][3], then lo [npix][3] = (float)(o - hi) behind it (24 bytes per pixel, as fp64) --, the regrid scans
  *                   the high halves and evaluates survivors in fp64 on hi + lo.  Within 1e-9 mean(map) of BFGX_ACC_F64 at any displacement.  Needs the fast
  *                   tile kernel (3-axis table, uniform ln r axis); elsewhere, and in the band-restricted entries, it runs as BFGX_ACC_F64.
- *   BFGX_ACC_AUTO   the plan chooses from its table at creation: BFGX_ACC_F32 while the table cannot move a pixel by more than 0.4 pixel sides of the
+ *   BFGX_ACC_AUTO   the plan chooses from its table at creation: BFGX_ACC_F32 while the table cannot move a pixel by more than 0.1 pixel sides of the
  *                   plan's NSIDE (largest |d| a / D_A over the table's (z, M) nodes inside the model-side cut), BFGX_ACC_PARITY beyond.  The default of
  *                   the one-shot host entries and of the Python runners.  Scratch for pix_offsets must then hold 24 bytes per pixel.
  * bfgx_plan_precision tells what a request resolves to and how far the table moves a pixel. */

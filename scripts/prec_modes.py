@@ -24,6 +24,7 @@ ap.add_argument('--steps', type=int, default=100)
 ap.add_argument('--save', default='')
 ap.add_argument('--cmp', default='')
 ap.add_argument('--tag', default='')
+ap.add_argument('--scale', type=float, default=1.0, help='the table times this')
 args = ap.parse_args()
 
 nside, npix = args.nside, 12 * args.nside ** 2
@@ -39,6 +40,7 @@ if args.table == 's19':
         np.save(tpath, table)
 else:
     table = syn.displacement_table(z, M, r)
+table = args.scale * table
 axes = [np.log(1 + z), np.log(M), np.log(r)]
 model, keep = engine.model_from_tables(axes, table, syn.COSMO, 10.0, 10.0)
 t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}

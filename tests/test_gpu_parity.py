@@ -73,7 +73,7 @@ def test_hip_vs_oracle(gpu, name, algo):
 
 def test_default_accumulators(gpu):
     """defaults: BaryonifyShell picks its precision from the table (fp32 pair math + fp32 pix_offsets while the table moves a pixel by less than
-    0.4 pixel sides, the parity-grade mode beyond: 1e-6 mean(map) either way); PaintProfilesShell f32 pair math accumulated in f64 into the f64
+    0.1 pixel sides, the parity-grade mode beyond: 1e-6 mean(map) either way); PaintProfilesShell f32 pair math accumulated in f64 into the f64
     map (stated tolerance 5e-5 of the pixel's value); acc_f64 = True is fp64 throughout"""
     g = load_golden('lowz_baryonify')
     r = product_runner(g)
@@ -89,7 +89,7 @@ def test_default_accumulators(gpu):
 
 
 def test_plan_picks_its_precision_from_the_table(gpu):
-    """BFGX_ACC_AUTO: fp32 pair math while the table cannot move a pixel by more than 0.4 pixel sides of the plan's NSIDE, the parity-grade mode
+    """BFGX_ACC_AUTO: fp32 pair math while the table cannot move a pixel by more than 0.1 pixel sides of the plan's NSIDE, the parity-grade mode
     beyond; a table the fast kernel cannot take (a property axis) resolves the parity-grade mode to fp64 throughout; explicit requests stay"""
     import torch
     from baryonification_amd import _lib, engine, synthetic as syn
