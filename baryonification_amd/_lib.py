@@ -138,6 +138,11 @@ SYMBOLS = {
     'bfgx_paint_device': (C.c_int, [C.c_void_p, _P(bfgx_catalog), C.c_void_p, C.c_int]),
     'bfgx_plan_set_algo': (C.c_int, [C.c_void_p, C.c_int]),
     'bfgx_plan_status': (C.c_int, [C.c_void_p]),
+    'bfgx_route_step_device': (C.c_int, [C.c_void_p, C.POINTER(bfgx_catalog), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bfgx_plan_set_catalog_blocks': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    'bfgx_offsets_regrid_bands_device': (C.c_int, [C.c_void_p, C.POINTER(bfgx_catalog), C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_int32, C.c_int32,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bfgx_plan_precision': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     'bfgx_plan_regrid_stats': (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     'bfgx_plan_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),

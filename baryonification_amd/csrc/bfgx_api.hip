@@ -140,6 +140,7 @@ struct bfgx_plan {
     int32_t *tile_apron = nullptr;   // [ntiles][2] rings / columns of apron (tile_apron_kernel)
     int band_reach = 1;              // banded regrid: rings of apron every rank uses (bfgx_plan_set_band_reach)
     int route_margin = 0;            // rings by which bfgx_disc_rings_device widens every halo's range (bfgx_plan_set_route_margin)
+    int64_t cat_blk_rows = 0, cat_blk_stride = 0;      // K0 reads a blocked catalog (bfgx_plan_set_catalog_blocks)
     int32_t *wide_tiles = nullptr;   // [1 + ntiles]: number of tiles with wide entries, then those tiles (tile_scan_kernel)
     // fast tiled scatter (bfgx_scatter2.hpp): slim per-halo records + interleaved copies of the table
     bool fast_ok = false;            // 3-axis table with a uniform ln r axis, small enough to interleave
@@ -321,6 +322,7 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
         o.entries_a = o.fast ? p->entries_a : nullptr; o.cap_a = p->entries_a_cap; o.slow_list = p->slow_list; o.slow_cnt = p->slow_cnt;
     }
     o.ncell_m = p->model.tab.n[1] - 1; o.nrm1 = p->model.tab.n[2] - 1;
+    o.blk_rows = p->cat_blk_rows; o.blk_stride = p->cat_blk_stride;
 #define BFGX_PREP(NCV, REAL)                                                                                        \
     hipLaunchKernelGGL((halo_prep_kernel<NCV, REAL>), dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
                        c->ra, c->dec, c->extra[0], c->extra[1], c->ln1pz, c->lnM, fallback4, p->tiling, o)
@@ -1017,7 +1019,7 @@ int bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings)
 // otherwise acc_f64 says whether the one array is fp32 or fp64 (BFGX_ACC_PARITY / AUTO: as bfgx_offsets_bands_device resolves them)
 static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev, const void *offsets_dev,
                              int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev, bool reset_far,
-                             const float *offsets_lo_dev = nullptr)
+                             const float *offsets_lo_dev = nullptr, bool sums_later = false)
 {
     if (!p) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
@@ -1074,7 +1076,7 @@ static int regrid_bands_impl(bfgx_plan *p, int32_t band0, int32_t band1, const d
         }
         HIP_TRY(hipGetLastError());
     }
-    if (sums_dev) {
+    if (sums_dev && !sums_later) {             // (sums_later: the caller's next kernel adds the per-tile sums up)
         KernelTimer kt(p, BFGX_K_SUM);
         if (t1 - t0 > 16384) {
             HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
@@ -1227,6 +1229,32 @@ int bfgx_paint_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0
     return bands_scatter(p, cat, band0, band1, map_slice_dev, acc_f64, true);
 }
 
+// One rank's share of a resident multi-GPU BaryonifyShell step after the routing, as ONE enqueue-only call (Parallelize.py:250-318 has one call
+// drive all workers): K0 + binning + K1 for the bands [B0, B1) (the rank's own and, with a route margin, the band either side: the aprons of
+// its regrid) into offsets_dev (pixels from the first of band B0), the banded regrid of ITS bands [b0, b1) into out_slice_dev, the listed far
+// deposits that fall into its pixels added, the others counted into *foreign_dev, the two sums of the mass check.  One memset (the binning's)
+// zeroes every control word; eight launches.
+int bfgx_offsets_regrid_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t B0, int32_t B1, void *offsets_dev, int acc_f64,
+                                     int32_t b0, int32_t b1, const double *map_in_dev, double *out_slice_dev, double *sums_dev,
+                                     unsigned long long *foreign_dev)
+{
+    if (!p || !cat) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (B0 < 0 || B1 > p->tiling.nbands || B0 > b0 || b1 > B1 || b0 > b1) return fail(BFGX_ERR_INVALID, "band ranges must nest: [B0, B1) around [b0, b1)");
+    if (int rc = bands_scatter(p, cat, B0, B1, offsets_dev, acc_f64, false)) return rc;       // (its memset also zeroes the far list's counter)
+    if (b0 == b1) {
+        if (sums_dev) HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
+        return BFGX_OK;
+    }
+    const int64_t wlo = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * B0), whi = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * B1);
+    if (int rc = regrid_bands_impl(p, b0, b1, map_in_dev, offsets_dev, wlo, whi, acc_f64, out_slice_dev, sums_dev, false, nullptr, true)) return rc;
+    const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * b0), p1 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * b1);
+    const int t0 = p->band_tile0_host[b0], t1 = p->band_tile0_host[b1];
+    hipLaunchKernelGGL(regrid_far_local_kernel, dim3(64), dim3(256), 0, p->stream, p->far, out_slice_dev, p0, p1, foreign_dev, t1 - t0,
+                       sums_dev ? (const double *)(p->tile_sums + 2 * (size_t)t0) : (const double *)nullptr, sums_dev);
+    HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
 int bfgx_bands_max_offset2_device(bfgx_plan *p, int32_t band0, int32_t band1, float *out_dev)
 {
     if (!p || !out_dev) return fail(BFGX_ERR_INVALID, "NULL argument");
@@ -1336,6 +1364,48 @@ int bfgx_route_pack_device(bfgx_plan *p, int64_t n, const int32_t *rings_dev, in
                            cursor_dev, blocks_dev);
         HIP_TRY(hipGetLastError());
     }
+    return BFGX_OK;
+}
+
+// The routing of one resident multi-GPU step as ONE call and two launches (bfgx_disc_rings_device + bfgx_route_pack_device were four, with a
+// fill): route_prepare_kernel (NaN into column 0 of every block, the cursors zeroed) and route_step_kernel (ring range per halo, rows
+// packed by destination).  send_blocks_dev holds (world - 1) blocks [ncols][blockcap] in rank order WITHOUT this rank, recv_blocks_dev
+// world blocks: the other ranks' in rank order (what all_to_all_single delivers when the split towards oneself is empty), this rank's
+// own rows LAST -- they never enter the collective.  K0 reads the received blocks as they are (bfgx_plan_set_catalog_blocks).
+int bfgx_route_step_device(bfgx_plan *p, const bfgx_catalog *cat, int32_t world, int32_t rank, const int32_t *ring_bounds, int64_t blockcap,
+                           int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *send_blocks_dev, double *recv_blocks_dev,
+                           int32_t *overflow_dev)
+{
+    if (!p || !cat || !cursor_dev || !recv_blocks_dev || !overflow_dev || (world > 1 && !send_blocks_dev)) return fail(BFGX_ERR_INVALID, "NULL argument");
+    if (rank < 0 || rank >= world) return fail(BFGX_ERR_INVALID, "rank out of range");
+    if (blockcap < 1) return fail(BFGX_ERR_INVALID, "block capacity must be >= 1");
+    if (cat->n > 0 && (!cat->M || !cat->z || !cat->dec)) return fail(BFGX_ERR_INVALID, "catalog column pointer is NULL");
+    RouteStepArgs s;
+    std::memset(&s, 0, sizeof(s));
+    if (int rc = route_args(p, cat, world, ring_bounds, ncols, cols_dev, s.r)) return rc;
+    s.r.blockcap = blockcap; s.r.overflow = overflow_dev;
+    s.rank = rank; s.margin = p->route_margin;
+    s.M = cat->M; s.z = cat->z; s.dec = cat->dec;
+    s.send = send_blocks_dev; s.recv = recv_blocks_dev;
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t nblank = (int64_t)(2 * world - 1) * blockcap;
+    hipLaunchKernelGGL(route_prepare_kernel, dim3((unsigned)std::min<int64_t>((nblank + 255) / 256, 1024)), dim3(256), 0, p->stream, world, ncols, blockcap,
+                       send_blocks_dev, recv_blocks_dev, cursor_dev);
+    if (cat->n > 0)
+        // (2048 workgroups: eight waves per SIMD hide the latency of the strided column stores; each adds to the per-destination cursors once)
+        hipLaunchKernelGGL(route_step_kernel, dim3((unsigned)std::min<int64_t>((cat->n + 255) / 256, 4 * kRouteGrid)), dim3(256), 0, p->stream, s, p->model, p->hpx,
+                           cat->n, cursor_dev);
+    HIP_TRY(hipGetLastError());
+    return BFGX_OK;
+}
+
+// the catalogs of the following K0 launches are BLOCKED: rows halo j's columns at (j / rows) * stride + (j % rows) from the column pointers (what
+// an all_to_all of fixed-capacity blocks [block][column][rows] delivers: stride = ncols * rows); rows = 0: plain columns again
+int bfgx_plan_set_catalog_blocks(bfgx_plan *p, int64_t rows, int64_t stride)
+{
+    if (!p) return fail(BFGX_ERR_INVALID, "NULL plan");
+    if (rows < 0 || (rows > 0 && stride < rows)) return fail(BFGX_ERR_INVALID, "blocked catalog: rows >= 0, stride >= rows");
+    p->cat_blk_rows = rows; p->cat_blk_stride = rows > 0 ? stride : 0;
     return BFGX_OK;
 }
 

@@ -585,6 +585,9 @@ struct PrepOut {
                                   // takes the wide discs too (RowRec.fb bit 1): no halo is left to the generic kernel's wide pass
     int32_t rec_all;              // 1: HaloRec for every halo (halo-centric algo 0)
     int32_t ncell_m, nrm1;        // (nm - 1), (nr - 1) of the interleaved table
+    // a BLOCKED catalog (the rows an all_to_all has just delivered, [block][column][blk_rows]): halo j reads its columns at
+    // (j / blk_rows) * blk_stride + (j % blk_rows) from the column pointers of block 0 (blk_rows = 0: plain columns)
+    int64_t blk_rows, blk_stride;
 };
 
 // thread per halo.  NC = 4 * 2^K corner rows (K extra parameter axes): for NC > 4 the rows go to rowsx[j] instead of the
@@ -650,7 +653,8 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
                                               int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow, float *s_work)
 {
     HaloRec r;
-    const double M_j = M[j], z_j = z[j];
+    const int64_t jin = o.blk_rows > 0 ? (j / o.blk_rows) * o.blk_stride + (j % o.blk_rows) : j;      // where this halo's input columns are
+    const double M_j = M[jin], z_j = z[jin];
     const double a = 1.0 / (1.0 + z_j);                                   // HealpixRunner.py:295
     const double R = dev_radius(m.bg_runner, m.md_runner, M_j, a);        // :296 physical Mpc
     double D;                                                             // :297 CubicSpline D_a(z)
@@ -666,8 +670,8 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     // hp.ang2vec(ra, dec, lonlat=True) (:303) followed by query_disc's pointing(vec) (:306): the pointing of the unit
     // vector (sin t cos p, sin t sin p, cos t) is (t, p mod 2 pi) again, so the two atan2 of the round trip are skipped
     // (they return theta and phi to within an ulp)
-    const double theta = kHalfPi - dec[j] * kDeg2Rad;
-    const double phi = ra[j] * kDeg2Rad;
+    const double theta = kHalfPi - dec[jin] * kDeg2Rad;
+    const double phi = ra[jin] * kDeg2Rad;
     double st, ct, sp, cp;
     sincos_bounded(theta, st, ct);                                        // libm-free (bfgx_math.hpp): K0 is latency-bound
     sincos_bounded(phi, sp, cp);
@@ -798,11 +802,11 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     const double Rmod = (m.same_model ? R : dev_radius(m.bg_model, m.md_model, M_j, a)) / a;
     r.rcut = m.tab.eps_model * Rmod;
     r.inv_a = 1.0 / a;
-    const double x0 = lnz1 ? lnz1[j] : fast_log(1.0 / a), x1 = lnM ? lnM[j] : fast_log(M_j);
+    const double x0 = lnz1 ? lnz1[jin] : fast_log(1.0 / a), x1 = lnM ? lnM[jin] : fast_log(M_j);
     r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
     double wv[NC];
     int32_t ro[NC];
-    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, (NC >= 8) ? ex0[j] : 0.0, (NC >= 16) ? ex1[j] : 0.0, wv, ro);
+    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, (NC >= 8) ? ex0[jin] : 0.0, (NC >= 16) ? ex1[jin] : 0.0, wv, ro);
     r.oob = oob ? 1 : 0;
     if (NC == 4) {
         for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
@@ -987,6 +991,94 @@ route_blank_kernel(int32_t world, int32_t ncols, int64_t blockcap, double *__res
     const int64_t n = (int64_t)world * blockcap;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         rows[(i / blockcap) * ncols * blockcap + (i % blockcap)] = __builtin_nan("");
+}
+
+// ONE routing pass of a resident multi-GPU step (bfgx_route_step_device): per halo the ring range its disc can touch (the arithmetic of
+// disc_rings_kernel, + margin rings) and its rows packed into fixed-capacity blocks [position][column][blockcap], one per destination.  The rows
+// bound for this rank ITSELF never enter the collective: they are written straight into the last block of the receive buffer; the blocks of
+// the other destinations are packed in rank order without a gap (position q(d) = d below this rank, d - 1 above), which is the layout
+// all_to_all_single gives the receiver too when the split towards oneself is empty.  Column 0 (M) of every block was set to NaN by
+// route_prepare_kernel: rows nobody fills are dropped by K0 as invalid halos.
+struct RouteStepArgs {
+    RouteArgs r;
+    int32_t rank, margin;
+    const double *M, *z, *dec;                   // the local halos' columns the ring range needs (also among r.col)
+    double *send, *recv;                         // [world - 1] blocks to send, [world] blocks received (self last)
+};
+__global__ void __launch_bounds__(256)
+route_prepare_kernel(int32_t world, int32_t ncols, int64_t blockcap, double *__restrict__ send, double *__restrict__ recv, int32_t *__restrict__ cursor)
+{
+    if (blockIdx.x == 0 && (int)threadIdx.x < world) cursor[threadIdx.x] = 0;
+    const int64_t nb = (int64_t)(world - 1) * blockcap, nr = (int64_t)world * blockcap;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb + nr; i += (int64_t)gridDim.x * 256) {
+        double *base = i < nb ? send : recv;
+        const int64_t k = i < nb ? i : i - nb;
+        base[(k / blockcap) * ncols * blockcap + (k % blockcap)] = __builtin_nan("");
+    }
+}
+__global__ void __launch_bounds__(256)
+route_step_kernel(RouteStepArgs s, DevModel m, Hpx h, int64_t n, int32_t *__restrict__ cursor)
+{
+    const RouteArgs &a = s.r;
+    __shared__ int hist[kRouteMaxRanks], base[kRouteMaxRanks], taken[kRouteMaxRanks];
+    const int tid = threadIdx.x;
+    if (tid < kRouteMaxRanks) { hist[tid] = 0; taken[tid] = 0; }
+    __syncthreads();
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t j0 = (int64_t)blockIdx.x * per, j1 = min(n, j0 + per);
+    const int nl4 = (int)(4 * h.nside);
+    auto ring_range = [&](int64_t j, int &first, int &last) {           // disc_rings_kernel's arithmetic
+        const double M_j = s.M[j], z_j = s.z[j];
+        const double aa = 1.0 / (1.0 + z_j);
+        const double R = dev_radius(m.bg_runner, m.md_runner, M_j, aa);
+        double D;
+        {
+            int i = (int)floor(z_j / m.da_step);
+            i = max(0, min(i, kDaKnots - 2));
+            const double t = z_j - (double)i * m.da_step;
+            const double *c = m.da_coef + 4 * i;
+            D = ((c[0] * t + c[1]) * t + c[2]) * t + c[3];
+        }
+        const double radius = R * m.eps_runner / D;
+        const double theta = kHalfPi - s.dec[j] * kDeg2Rad;
+        first = 1; last = 0;
+        const bool bad = !(radius > 0.0) || !isfinite(radius) || !(theta >= 0.0) || !(theta <= kPi) || !(M_j > 0.0) || !isfinite(M_j) || !(z_j > -1.0);
+        if (bad) return;
+        if (radius >= kPi) { first = 1; last = nl4 - 1; }
+        else {
+            const double lo = fmax(theta - radius, 0.0), hi = fmin(theta + radius, kPi);
+            first = (int)ring_above(h, cos(lo)) - 1;
+            last = (int)ring_above(h, cos(hi)) + 2;
+            first = max(1, first - 1); last = min(nl4 - 1, last + 1);
+        }
+        first = max(1, first - s.margin); last = min(nl4 - 1, last + s.margin);
+    };
+    // (pass 1: how many rows this workgroup has for every destination; the ring ranges of the workgroup's run of halos wait in LDS for pass 2)
+    constexpr int kStash = 4096;
+    __shared__ int2 stash[kStash];
+    for (int64_t j = j0 + tid; j < j1; j += 256) {
+        int first, last, jlo, jhi;
+        ring_range(j, first, last);
+        if (j - j0 < kStash) stash[j - j0] = make_int2(first, last);
+        route_range(a, first, last, jlo, jhi);
+        for (int d = jlo; d <= jhi; ++d) atomicAdd(&hist[d], 1);
+    }
+    __syncthreads();
+    if (tid < a.world) base[tid] = hist[tid] ? atomicAdd(cursor + tid, hist[tid]) : 0;       // one range per (workgroup, destination)
+    __syncthreads();
+    for (int64_t j = j0 + tid; j < j1; j += 256) {
+        int first, last, jlo, jhi;
+        if (j - j0 < kStash) { const int2 q = stash[j - j0]; first = q.x; last = q.y; } else ring_range(j, first, last);
+        route_range(a, first, last, jlo, jhi);
+        for (int d = jlo; d <= jhi; ++d) {
+            const int64_t slot = base[d] + atomicAdd(&taken[d], 1);
+            if (slot >= a.blockcap) { *a.overflow = 1; continue; }
+            double *blk = (d == s.rank) ? s.recv + (int64_t)(a.world - 1) * a.ncols * a.blockcap
+                                        : s.send + (int64_t)(d < s.rank ? d : d - 1) * a.ncols * a.blockcap;
+            blk += slot;
+            for (int c = 0; c < a.ncols; ++c) blk[c * a.blockcap] = a.col[c][j];
+        }
+    }
 }
 
 // The fast kernel's form when the halo count does not decide it: form[0] = 1 (fluid) if the catalog's estimated pairs per tile reach

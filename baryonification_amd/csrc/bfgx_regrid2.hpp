@@ -934,9 +934,26 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
 }
 
 // banded regrid: adds the listed deposits whose pixel lies in [p0, p1) to the slice that starts at pixel p0, counts the others
+// (tile_sums != NULL: the last workgroup also adds up the per-tile sums of the banded regrid into sums[2] -- one launch less per step)
 __global__ void __launch_bounds__(256)
-regrid_far_local_kernel(FarList far, double *__restrict__ out_slice, int64_t p0, int64_t p1, unsigned long long *__restrict__ foreign)
+regrid_far_local_kernel(FarList far, double *__restrict__ out_slice, int64_t p0, int64_t p1, unsigned long long *__restrict__ foreign,
+                        int ntiles = 0, const double *__restrict__ tile_sums = nullptr, double *__restrict__ sums = nullptr)
 {
+    if (tile_sums != nullptr && blockIdx.x == gridDim.x - 1) {
+        __shared__ double sa[256 / kWave], sb[256 / kWave];
+        double xa = 0.0, xb = 0.0;
+        for (int t = threadIdx.x; t < ntiles; t += 256) { xa += tile_sums[2 * t]; xb += tile_sums[2 * t + 1]; }
+#pragma unroll
+        for (int sft = kWave >> 1; sft > 0; sft >>= 1) { xa += __shfl_down(xa, sft, kWave); xb += __shfl_down(xb, sft, kWave); }
+        const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+        if (lane == 0) { sa[wid] = xa; sb[wid] = xb; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ta = 0.0, tb = 0.0;
+            for (int w = 0; w < 256 / kWave; ++w) { ta += sa[w]; tb += sb[w]; }
+            sums[0] = ta; sums[1] = tb;
+        }
+    }
     unsigned long long n = *far.count;
     if ((int64_t)n > far.cap) n = (unsigned long long)far.cap;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {

@@ -74,6 +74,25 @@ class ShellPlan(object):
                                                      int(blockcap), len(col_ptrs), cols, C.c_void_p(int(cursor_ptr)), C.c_void_p(int(blocks_ptr)),
                                                      C.c_void_p(int(overflow_ptr))))
 
+    def route_step(self, cat_dev, rank, ring_bounds, blockcap, col_ptrs, cursor_ptr, send_ptr, recv_ptr, overflow_ptr):
+        """the routing of one resident multi-GPU step in one call (ring ranges + packing; two launches): send = (world - 1) blocks
+        [len(col_ptrs)][blockcap] in rank order without this rank, recv = world blocks with this rank's own rows written into the LAST one"""
+        rb = np.ascontiguousarray(ring_bounds, dtype=np.int32)
+        cols = (C.c_void_p * len(col_ptrs))(*[int(c) for c in col_ptrs])
+        _lib.check(_lib.load().bfgx_route_step_device(self._h, C.byref(cat_dev), int(rb.size - 1), int(rank), rb.ctypes.data, int(blockcap), len(col_ptrs), cols,
+                                                     C.c_void_p(int(cursor_ptr)), C.c_void_p(int(send_ptr) or None), C.c_void_p(int(recv_ptr)),
+                                                     C.c_void_p(int(overflow_ptr))))
+
+    def set_catalog_blocks(self, rows, stride):
+        """the catalogs of the following K0 launches are blocks [block][column][rows] (stride = columns x rows); rows = 0: plain columns"""
+        _lib.check(_lib.load().bfgx_plan_set_catalog_blocks(self._h, int(rows), int(stride)))
+
+    def offsets_regrid_bands(self, cat_dev, B0, B1, offsets_ptr, band0, band1, map_in_ptr, out_slice_ptr, sums_ptr=0, foreign_ptr=0, acc_f64=False):
+        """K0 + K1 for the bands [B0, B1), the banded regrid of [band0, band1) into the slice, far deposits applied, sums: one enqueue-only call"""
+        _lib.check(_lib.load().bfgx_offsets_regrid_bands_device(self._h, C.byref(cat_dev), int(B0), int(B1), C.c_void_p(int(offsets_ptr)), int(acc_f64),
+                                                               int(band0), int(band1), C.c_void_p(int(map_in_ptr)), C.c_void_p(int(out_slice_ptr)),
+                                                               C.c_void_p(int(sums_ptr) or None), C.c_void_p(int(foreign_ptr) or None)))
+
     def bands_max_offset2(self, band0, band1, out_ptr):
         """largest |offset|^2 (float32, device) of the slice offsets_bands() has just written for the bands [band0, band1): reduced
         from the per-tile maxima K1 leaves, no pass over the slice"""

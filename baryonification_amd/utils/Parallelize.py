@@ -51,7 +51,7 @@ import os
 import numpy as np
 
 __all__ = ['SplitJoinParallel', 'SimpleParallel', 'shard_slices', 'distributed_process', 'band_partition', 'sliced_reduce',
-           'halo_exchange', 'gather_slices', 'route_halos', 'route_halos_fixed', 'band_ring_bounds']
+           'halo_exchange', 'gather_slices', 'route_halos', 'route_halos_fixed', 'route_step_fixed', 'band_ring_bounds']
 
 
 def shard_slices(n, world):
@@ -182,6 +182,33 @@ def route_halos_fixed(cols, rings, ring_bounds, blockcap, plan=None, work=None):
     _a2a(recv.view(-1), send.view(-1), None, None)
     out.view(k, world, blockcap).copy_(recv.permute(1, 0, 2))         # [source][column][row] -> contiguous columns
     return out, work['overflow']
+
+
+def route_step_fixed(cat_dev, cols, ring_bounds, blockcap, plan, work):
+    """The routing of a resident step as route_halos_fixed does it, in ONE library call and one collective, nothing read back, no transpose:
+    plan.route_step finds every local halo's ring range and packs its rows by destination into fixed-capacity blocks [columns][blockcap]; the
+    rows bound for this rank itself are written straight into the LAST block of the receive buffer and never enter the collective, the other
+    world - 1 blocks travel in ONE all_to_all_single whose split towards oneself is empty (so the received blocks sit in rank order in front
+    of it).  Returns (recv [world][k][blockcap] -- K0 reads it as a blocked catalog: plan.set_catalog_blocks(blockcap, k * blockcap) --,
+    overflow int32 tensor).  `cat_dev`: bfgx_catalog of the local halos (M, z, dec are what the ring range needs)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    k = len(cols)
+    dev = cols[0].device
+    key = ('step', world, k, int(blockcap), str(dev))
+    if work.get('key') != key:
+        work.clear()
+        work.update(key=key, send=torch.empty((max(world - 1, 1), k, blockcap), dtype=torch.float64, device=dev),
+                    recv=torch.empty((world, k, blockcap), dtype=torch.float64, device=dev),
+                    cursor=torch.empty(world, dtype=torch.int32, device=dev), overflow=torch.zeros(1, dtype=torch.int32, device=dev))
+    send, recv = work['send'], work['recv']
+    plan.route_step(cat_dev, rank, ring_bounds, blockcap, [c.data_ptr() for c in cols], work['cursor'].data_ptr(),
+                    send.data_ptr() if world > 1 else 0, recv.data_ptr(), work['overflow'].data_ptr())
+    blk = k * blockcap
+    splits = [blk if d != rank else 0 for d in range(world)]
+    _a2a(recv.view(-1)[:(world - 1) * blk], send.view(-1)[:(world - 1) * blk], splits, splits)
+    return recv, work['overflow']
 
 
 def band_ring_bounds(cuts, rings_per_band, nside):
@@ -326,10 +353,11 @@ def halo_exchange(mine, pb, needs, width, full=None):
     return full
 
 
-def gather_slices(mine, pb, npix, result='root', recv=None, out=None):
+def gather_slices(mine, pb, npix, result='root', recv=None, out=None, root_in_place=False):
     """The ranks' disjoint slices (pixels [pb[j], pb[j+1])) -> the full map on rank 0 (`result='root'`: one all_to_all with
     empty splits except towards rank 0, 7 separate links) or on every rank (`result='all'`: one all_gather of slices
-    padded to the longest).  Returns the map or None."""
+    padded to the longest).  Returns the map or None.  root_in_place: rank 0 has written its own slice into `out` already (it
+    regridded straight into the final map): only the other ranks' slices travel."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -349,6 +377,12 @@ def gather_slices(mine, pb, npix, result='root', recv=None, out=None):
             full[int(pb[j]):int(pb[j + 1])] = buf[j * L:j * L + lens[j]]
         return full
     assert result == 'root', "result must be 'root' or 'all'"
+    if root_in_place:
+        ins = [0] * world if rank == 0 else [lens[rank]] + [0] * (world - 1)
+        outs = [0] + lens[1:] if rank == 0 else [0] * world
+        tail = out[int(pb[1]):] if rank == 0 else mine.new_empty(0)
+        _a2a(tail, mine.new_empty(0) if rank == 0 else mine, outs, ins)
+        return out if rank == 0 else None
     ins = [lens[rank]] + [0] * (world - 1)
     outs = lens if rank == 0 else [0] * world
     if rank == 0 and out is not None and recv is None:

@@ -600,7 +600,7 @@ def shell_line(args, ctx, scaling, brief):
     spatial = (world > 1 or force_x) and args.exchange == 'spatial' and args.algo == 1
     if slices or spatial:
         from baryonification_amd.utils.Parallelize import (_hip_reach, band_partition, band_ring_bounds, gather_slices, halo_exchange,
-                                                           route_halos, route_halos_fixed, sliced_reduce)
+                                                           route_halos, route_halos_fixed, route_step_fixed, sliced_reduce)
         first = plan.bands()
         cuts = band_partition(first, world)
         pb = first[cuts]
@@ -678,15 +678,21 @@ def shell_line(args, ctx, scaling, brief):
                         d_out.copy_(h_out)
 
         def step_spatial():
-            plan_sp.disc_rings(cat_dev, d_rings.data_ptr())
-            mark('disc_rings')
             if sp_state['fixed']:
-                got, _ = route_halos_fixed(cols_local, d_rings, rb, blockcap, plan=plan_sp, work=route_work)   # [6][world * blockcap], NaN-padded
+                # ring ranges + packing in ONE call (two launches); the rows bound for this rank itself skip the collective; K0 reads the
+                # received blocks as they are (no transpose)
+                recv, _ = route_step_fixed(cat_dev, cols_local, rb, blockcap, plan_sp, route_work)          # [world][6][blockcap], NaN-padded
+                mark('route')
                 if sp_state['cd'] is None:                     # (the receive buffers are reused: the descriptor is built once)
-                    sp_state['cd'] = _lib.make_catalog_dev(int(got.shape[1]), got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), got[3].data_ptr(),
-                                                           ln1pz_ptr=got[4].data_ptr(), lnM_ptr=got[5].data_ptr())
+                    B8 = blockcap * 8
+                    bp = recv.data_ptr()
+                    sp_state['cd'] = _lib.make_catalog_dev(world * blockcap, bp, bp + B8, bp + 2 * B8, bp + 3 * B8, ln1pz_ptr=bp + 4 * B8, lnM_ptr=bp + 5 * B8)
+                    plan_sp.set_catalog_blocks(blockcap, 6 * blockcap)
                 cd = sp_state['cd']
             else:
+                plan_sp.set_catalog_blocks(0, 0)
+                plan_sp.disc_rings(cat_dev, d_rings.data_ptr())
+                mark('disc_rings')
                 got = route_halos(cols_local, d_rings, rb, plan=plan_sp)       # [6][n]: the halos whose discs can touch my ring bands
                 n = int(got.shape[1])
                 assert n <= cap, "rank %d received %d halos, more than the plan holds (%d): a strongly clustered sky" % (rank, n, cap)
@@ -706,20 +712,27 @@ def shell_line(args, ctx, scaling, brief):
                 B0, B1, wlo, whi = sp_state['wide']
                 if sp_state.get('full') is None or sp_state['full'].dtype != acc_dtype or sp_state['full'].numel() != (whi - wlo) * 3:
                     sp_state['full'] = torch.empty((whi - wlo) * 3, dtype=acc_dtype, device=dev)
+                if not route_far[0]:
+                    # rank 0's pixels are regridded straight into the final map (they never enter the gather), K0 .. K2 + far deposits + sums in
+                    # ONE enqueue-only call (bfgx_offsets_regrid_bands_device)
+                    out_ptr = d_fin[p0:p1].data_ptr() if rank == 0 else d_slice.data_ptr()
+                    plan_sp.offsets_regrid_bands(cd, B0, B1, sp_state['full'].data_ptr(), b0, b1, d_map.data_ptr(), out_ptr, d_sums.data_ptr(),
+                                                 d_foreign.data_ptr(), acc_f64=acc_f64)
+                    mark('K0+K1+K2')
+                    gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None, root_in_place=True)
+                    mark('gather')
+                    return
                 plan_sp.offsets_bands(cd, B0, B1, sp_state['full'].data_ptr(), acc_f64=acc_f64)
                 mark('K0+K1')
                 plan_sp.regrid_bands(b0, b1, d_map.data_ptr(), sp_state['full'].data_ptr(), wlo, whi, d_slice.data_ptr(), d_sums.data_ptr(), acc_f64=acc_f64)
                 mark('K2')
-                if route_far[0]:
-                    fp, fv = plan_sp.far_fetch()
-                    lists = [None] * world
-                    dist.all_gather_object(lists, (fp, fv))
-                    for qp, qv in lists:
-                        m = (qp >= p0) & (qp < p1)
-                        if m.any():
-                            d_slice.index_add_(0, torch.from_numpy(qp[m] - p0).to(dev), torch.from_numpy(qv[m]).to(dev))
-                else:
-                    plan_sp.far_apply(d_slice.data_ptr(), p0, p1, d_foreign.data_ptr())
+                fp, fv = plan_sp.far_fetch()
+                lists = [None] * world
+                dist.all_gather_object(lists, (fp, fv))
+                for qp, qv in lists:
+                    m = (qp >= p0) & (qp < p1)
+                    if m.any():
+                        d_slice.index_add_(0, torch.from_numpy(qp[m] - p0).to(dev), torch.from_numpy(qv[m]).to(dev))
                 mark('far')
                 gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None)
                 mark('gather')
@@ -1070,6 +1083,15 @@ def shell_line(args, ctx, scaling, brief):
         }
         if spatial:
             out["routing_rows"] = routing_rows
+            if sp_state['fixed'] and sp_state.get('local_apron') and not route_far[0] and not paint:
+                # what one timed step enqueues on a rank (two library calls + two collectives; nothing is read back by the host)
+                out["step_launches"] = ["route_prepare_kernel (NaN into column 0 of the routing blocks, cursors zeroed)",
+                                        "route_step_kernel (ring range per halo + rows packed by destination; this rank's own rows straight into the receive buffer)",
+                                        "all_to_all_single (halo rows; the split towards oneself is empty)",
+                                        "memset (every control word of the binning and the regrid)", "halo_prep_kernel (blocked catalog: no transpose)",
+                                        "tile_scan_kernel", "tile_place_kernel", "tile_scatter2f_kernel", "tile_apron_kernel", "tile_regrid3_kernel",
+                                        "regrid_far_local_kernel (far deposits + the two sums)",
+                                        "all_to_all_single (map slices -> rank 0; rank 0 regrids its own slice in place)"]
         if kt is not None:
             kernels = {k: (ms / n if n else None) for k, (ms, n) in kt.items() if n}
             out["ms_per_step_with_kernel_events"] = elapsed_ev / args.steps * 1e3

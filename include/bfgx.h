@@ -251,6 +251,25 @@ int  bfgx_plan_set_band_reach(bfgx_plan *p, int32_t rings);
 int  bfgx_plan_band_apron(bfgx_plan *p, int32_t band0, int32_t band1, int64_t *olo, int64_t *ohi);
 int  bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const double *map_in_dev,
                               const void *offsets_dev, int64_t olo, int64_t ohi, int acc_f64, double *out_slice_dev, double *sums_dev);
+/* A rank's share of one resident multi-GPU step in TWO calls (Parallelize.py:250-318: one call drives all workers).
+ * bfgx_route_step_device: the routing -- per local halo the ring range its disc can touch (+ the plan's route margin) and its rows packed by
+ * destination into fixed-capacity blocks [ncols][blockcap] (column 0 = M; rows nobody fills keep M = NaN, which K0 drops).  send_blocks_dev:
+ * (world - 1) blocks in rank order WITHOUT this rank -- the input of ONE all_to_all_single whose split towards oneself is empty;
+ * recv_blocks_dev: world blocks, the other ranks' in rank order first (where that all_to_all puts them), this rank's own rows LAST: they are
+ * written there directly and never enter the collective.  *overflow_dev is set when a block was too small.  Two launches, nothing read back.
+ * bfgx_plan_set_catalog_blocks(rows, stride): the catalogs of the following K0 launches are such blocks -- halo j's columns at
+ * (j / rows) * stride + (j % rows) from the column pointers of block 0 (stride = ncols * blockcap); rows = 0: plain columns again.
+ * bfgx_offsets_regrid_bands_device: K0 + binning + K1 for the bands [B0, B1) (the rank's own [b0, b1) and, with a route margin of one band, the
+ * band either side: the aprons of its regrid, computed locally) into offsets_dev (pixels from the first pixel of band B0; f32 or f64 as
+ * bfgx_offsets_bands_device resolves acc_f64), the banded regrid of [b0, b1) into out_slice_dev, the listed far deposits that fall into those
+ * pixels added (the others counted into *foreign_dev, which the caller zeroes once), the two sums of the mass check.  One memset, eight launches. */
+int  bfgx_route_step_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t world, int32_t rank, const int32_t *ring_bounds, int64_t blockcap,
+                            int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *send_blocks_dev, double *recv_blocks_dev,
+                            int32_t *overflow_dev);
+int  bfgx_plan_set_catalog_blocks(bfgx_plan *p, int64_t rows, int64_t stride);
+int  bfgx_offsets_regrid_bands_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t B0, int32_t B1, void *offsets_dev, int acc_f64,
+                                      int32_t b0, int32_t b1, const double *map_in_dev, double *out_slice_dev, double *sums_dev,
+                                      unsigned long long *foreign_dev);
 int  bfgx_plan_far_fetch(bfgx_plan *p, int64_t cap, int64_t *pix_host, double *val_host, int64_t *n_host);
 /* What the LAST full-map regrid (bfgx_regrid_device / bfgx_baryonify_device) did, read back from its control words (blocking;
  * diagnostics for tests and bench lines -- regrid_pixels_hpix, HealpixRunner.py:13-67, has no counterpart): deposits listed for the
