@@ -10,12 +10,12 @@ import os
 
 import numpy as np
 
-BFGX_MAX_EXTRA = 2
+BFGX_MAX_EXTRA = 4
 BFGX_MAX_DIM = 3 + BFGX_MAX_EXTRA
 KERNEL_KINDS = ('prep', 'offsets', 'regrid', 'paint', 'sum', 'count', 'bin', 'wide')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3        # include/bfgx.h BFGX_ABI_VERSION: 3 since bfgx_opts carries catalog_token (32 bytes)
+ABI_VERSION = 4        # include/bfgx.h BFGX_ABI_VERSION: 4 since BFGX_MAX_EXTRA = 4 (bfgx_table / bfgx_catalog hold 7 axes / 4 property columns)
 LIB_PATH = os.environ.get('BFGX_LIB', os.path.join(_HERE, 'csrc', 'libbfgx.so'))   # BFGX_LIB: ablation builds only
 
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_MASS, ERR_ASSERT = 0, -1, -2, -3, -4, -5, -6

@@ -227,11 +227,15 @@ static int upload_model(std::vector<void *> &owned, hipStream_t stream, const bf
         std::vector<double> tr;
         const double *src = t.values;
         if (t.ndim > 3) {
-            const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2], np0 = t.n[3], np1 = t.ndim > 4 ? t.n[4] : 1;
+            // host order [z][M][r][p...] (np C order, the extra axes last) -> device order [z][M][p...][r]
+            const size_t nz = t.n[0], nm = t.n[1], nr = t.n[2];
+            size_t nx = 1;
+            for (int d = 3; d < t.ndim; ++d) nx *= (size_t)t.n[d];
             tr.resize(nvals);
-            for (size_t iz = 0; iz < nz; ++iz) for (size_t im = 0; im < nm; ++im) for (size_t ir = 0; ir < nr; ++ir)
-                for (size_t a0 = 0; a0 < np0; ++a0) for (size_t a1 = 0; a1 < np1; ++a1)
-                    tr[((((iz * nm + im) * np0 + a0) * np1 + a1) * nr) + ir] = t.values[((((iz * nm + im) * nr + ir) * np0 + a0) * np1) + a1];
+            for (size_t zm = 0; zm < nz * nm; ++zm)
+                for (size_t ir = 0; ir < nr; ++ir)
+                    for (size_t q = 0; q < nx; ++q)
+                        tr[(zm * nx + q) * nr + ir] = t.values[(zm * nr + ir) * nx + q];
             src = tr.data();
         }
         const void *dv = nullptr;
@@ -323,12 +327,16 @@ static int launch_prep(bfgx_plan *p, const bfgx_catalog *c, int fallback4, bool 
     }
     o.ncell_m = p->model.tab.n[1] - 1; o.nrm1 = p->model.tab.n[2] - 1;
     o.blk_rows = p->cat_blk_rows; o.blk_stride = p->cat_blk_stride;
+    ExtraCols ex;
+    for (int k = 0; k < BFGX_MAX_EXTRA; ++k) ex.p[k] = c->extra[k];
 #define BFGX_PREP(NCV, REAL)                                                                                        \
     hipLaunchKernelGGL((halo_prep_kernel<NCV, REAL>), dim3(grid), dim3(256), 0, p->stream, p->model, p->hpx, c->n, c->M, c->z, \
-                       c->ra, c->dec, c->extra[0], c->extra[1], c->ln1pz, c->lnM, fallback4, p->tiling, o)
+                       c->ra, c->dec, ex, c->ln1pz, c->lnM, fallback4, p->tiling, o)
     if (p->NC == 4) { if (f64) BFGX_PREP(4, double); else BFGX_PREP(4, float); }
     else if (p->NC == 8) BFGX_PREP(8, float);
-    else BFGX_PREP(16, float);
+    else if (p->NC == 16) BFGX_PREP(16, float);
+    else if (p->NC == 32) BFGX_PREP(32, float);
+    else BFGX_PREP(64, float);
 #undef BFGX_PREP
     HIP_TRY(hipGetLastError());
     return BFGX_OK;
@@ -494,7 +502,9 @@ static int launch_tile_scatter(bfgx_plan *p, ACC *out)
     if (p->NC == 4) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, false);
     if (MODE == MODE_COUNT) return launch_tile_scatter_nc<MODE, ACC, 4>(p, out, false);      // census never reads the rows
     if (p->NC == 8) return launch_tile_scatter_nc<MODE, ACC, 8>(p, out, false);
-    return launch_tile_scatter_nc<MODE, ACC, 16>(p, out, false);
+    if (p->NC == 16) return launch_tile_scatter_nc<MODE, ACC, 16>(p, out, false);
+    if (p->NC == 32) return launch_tile_scatter_nc<MODE, ACC, 32>(p, out, false);       // three / four property axes (Tabulate.py:524-561)
+    return launch_tile_scatter_nc<MODE, ACC, 64>(p, out, false);
 }
 
 // blocking: if the entry list overflowed, grow it to the exact size and redo the fill pass
@@ -1692,7 +1702,10 @@ int upload_catalog(bfgx_plan *p, const bfgx_catalog *h, DevBuf cols[kCatCols], b
         if (!lnz) lnz = hostlog.data();
         if (!lnm) lnm = hostlog.data() + h->n;
     }
-    const double *src[kCatCols] = {h->M, h->z, h->ra, h->dec, nex > 0 ? h->extra[0] : nullptr, nex > 1 ? h->extra[1] : nullptr, lnz, lnm};
+    const double *src[kCatCols];
+    src[0] = h->M; src[1] = h->z; src[2] = h->ra; src[3] = h->dec;
+    for (int k = 0; k < BFGX_MAX_EXTRA; ++k) src[4 + k] = k < nex ? h->extra[k] : nullptr;
+    src[4 + BFGX_MAX_EXTRA] = lnz; src[5 + BFGX_MAX_EXTRA] = lnm;
     for (int i = 0; i < kCatCols; ++i) {
         const bool wanted = i < 4 + nex || i >= 4 + BFGX_MAX_EXTRA;
         if (!wanted) continue;
@@ -1864,7 +1877,10 @@ int upload_catalog_pooled(CacheEntry *e, const bfgx_catalog *h, bfgx_catalog *d,
         if (!lnz) lnz = hostlog.data();
         if (!lnm) lnm = hostlog.data() + h->n;
     }
-    const double *src[kCatCols] = {h->M, h->z, h->ra, h->dec, nex > 0 ? h->extra[0] : nullptr, nex > 1 ? h->extra[1] : nullptr, lnz, lnm};
+    const double *src[kCatCols];
+    src[0] = h->M; src[1] = h->z; src[2] = h->ra; src[3] = h->dec;
+    for (int k = 0; k < BFGX_MAX_EXTRA; ++k) src[4 + k] = k < nex ? h->extra[k] : nullptr;
+    src[4 + BFGX_MAX_EXTRA] = lnz; src[5 + BFGX_MAX_EXTRA] = lnm;
     const double *dp[kCatCols] = {};
     for (int i = 0; i < kCatCols; ++i) {
         const bool wanted = i < 4 + nex || i >= 4 + BFGX_MAX_EXTRA;

@@ -138,7 +138,8 @@ grid_prep_kernel(DevModel m, GridGeom g, GridCatalog c, int mode, GridHaloRec *_
         const double x1 = c.lnM ? c.lnM[j] : (double)logf((float)M_j);    // float32 log of the float32 catalog mass
         double wv[NC];
         int32_t ro[NC];
-        const bool oob = table_corners<NC>(m.tab, m.tab.axis[0], m.tab.axis[1], x0, x1, (NC >= 8) ? c.extra[0][j] : 0.0, (NC >= 16) ? c.extra[1][j] : 0.0, wv, ro);
+        const double xe[2] = {(NC >= 8) ? c.extra[0][j] : 0.0, (NC >= 16) ? c.extra[1][j] : 0.0};
+        const bool oob = table_corners<NC>(m.tab, m.tab.axis[0], m.tab.axis[1], x0, x1, xe, wv, ro);
         r.oob = oob ? 1 : 0;
         for (int q = 0; q < NC; ++q) { r.w[q] = wv[q]; r.rowoff[q] = ro[q]; }
         if (c.rmat) { r.ell = 1; for (int q = 0; q < 4; ++q) r.rmat[q] = c.rmat[4 * j + q]; }

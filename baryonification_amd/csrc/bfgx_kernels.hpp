@@ -316,12 +316,16 @@ struct DevModel {
     double da_step;
 };
 
-// corner rows of a table with extra parameter axes (p_keys): 4 * 2^K rows per halo, K = 1 or 2
+// corner rows of a table with extra parameter axes (p_keys): 4 * 2^K rows per halo.  The shell path takes K <= BFGX_MAX_EXTRA = 4 (64 rows: the
+// reference's RegularGridInterpolator takes any number, Tabulate.py:524-561); the regular-grid and snapshot records keep K <= 2 (kNCmax)
 constexpr int kNCmax = 16;
+constexpr int kNCmaxShell = 4 << BFGX_MAX_EXTRA;
 struct RowSetX {
-    double w[kNCmax];
-    int32_t rowoff[kNCmax];
+    double w[kNCmaxShell];
+    int32_t rowoff[kNCmaxShell];
 };
+// the per-halo values of the table's extra axes (the catalog's property columns, HealpixRunner.py:298)
+struct ExtraCols { const double *p[BFGX_MAX_EXTRA]; };
 
 // per-halo record written by K0, read (wave-uniformly) by K1/K3
 struct alignas(16) HaloRec {
@@ -372,39 +376,43 @@ __device__ inline int axis_find(const double *g, int n, double x)
 // of the corners' radial rows in the device layout [z][M][p0][p1][r] (r innermost).  Returns true when a coordinate is
 // outside its axis (RegularGridInterpolator fill_value = nan).
 template <int NC>
-__device__ inline bool table_corners(const DevTable &tab, const double *gz, const double *gm, double x0, double x1, double xe0, double xe1,
+__device__ inline bool table_corners(const DevTable &tab, const double *gz, const double *gm, double x0, double x1, const double *xe,
                                      double *wv, int32_t *ro)
 {
-    // gz / gm: the ln(1 + z) and ln M axes (K0 stages them in LDS: the binary searches are chains of dependent loads)
+    // gz / gm: the ln(1 + z) and ln M axes (K0 stages them in LDS: the binary searches are chains of dependent loads); xe[K]: the halo's
+    // values on the K extra axes
     const int iz = axis_find(gz, tab.n[0], x0);
     const int im = axis_find(gm, tab.n[1], x1);
-    constexpr int K = (NC == 4) ? 0 : (NC == 8 ? 1 : 2);
-    int ip[2] = {0, 0};
-    double tp[2] = {0.0, 0.0};
+    constexpr int K = (NC == 4) ? 0 : (NC == 8 ? 1 : (NC == 16 ? 2 : (NC == 32 ? 3 : 4)));
+    static_assert(NC == (4 << K), "NC = 4 * 2^K");
+    int ip[K > 0 ? K : 1];
+    double tp[K > 0 ? K : 1];
     bool oob = (iz < 0 || im < 0);
-    if (K >= 1) {
-        ip[0] = axis_find(tab.axis[3], tab.n[3], xe0);
-        oob = oob || ip[0] < 0;
-        if (ip[0] >= 0) tp[0] = (xe0 - tab.axis[3][ip[0]]) / (tab.axis[3][ip[0] + 1] - tab.axis[3][ip[0]]);
-    }
-    if (K >= 2) {
-        ip[1] = axis_find(tab.axis[4], tab.n[4], xe1);
-        oob = oob || ip[1] < 0;
-        if (ip[1] >= 0) tp[1] = (xe1 - tab.axis[4][ip[1]]) / (tab.axis[4][ip[1] + 1] - tab.axis[4][ip[1]]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double *g = tab.axis[3 + k];
+        ip[k] = axis_find(g, tab.n[3 + k], xe[k]);
+        tp[k] = 0.0;
+        oob = oob || ip[k] < 0;
+        if (ip[k] >= 0) tp[k] = (xe[k] - g[ip[k]]) / (g[ip[k] + 1] - g[ip[k]]);
     }
     if (!oob) {
         const double tz = (x0 - gz[iz]) / (gz[iz + 1] - gz[iz]);
         const double tm = (x1 - gm[im]) / (gm[im + 1] - gm[im]);
         const int nr = tab.n[2];
-        const int np0 = (K >= 1) ? tab.n[3] : 1, np1 = (K >= 2) ? tab.n[4] : 1;
         for (int c = 0; c < NC; ++c) {
+            // corner c in scipy's itertools.product order over (z, M, p0, .., p_{K-1}): bit K + 1 = z, bit K = M, bit K - 1 - k = axis k
             const int bz = (c >> (K + 1)) & 1, bm = (c >> K) & 1;
-            const int b0 = (K >= 1) ? ((c >> (K >= 1 ? K - 1 : 0)) & 1) : 0, b1 = (K >= 2) ? (c & 1) : 0;
             double w = (1.0 * (bz ? tz : 1.0 - tz)) * (bm ? tm : 1.0 - tm);
-            if (K >= 1) w *= (b0 ? tp[0] : 1.0 - tp[0]);
-            if (K >= 2) w *= (b1 ? tp[1] : 1.0 - tp[1]);
+            int idx = (iz + bz) * tab.n[1] + im + bm;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int b = (c >> (K - 1 - k)) & 1;
+                w *= (b ? tp[k] : 1.0 - tp[k]);
+                idx = idx * tab.n[3 + k] + ip[k] + b;
+            }
             wv[c] = w;
-            ro[c] = ((((iz + bz) * tab.n[1] + im + bm) * np0 + ip[0] + b0) * np1 + ip[1] + b1) * nr;
+            ro[c] = idx * nr;
         }
     } else {
         for (int c = 0; c < NC; ++c) { wv[c] = 0.0; ro[c] = 0; }
@@ -597,7 +605,7 @@ template <int NC, typename real>
 __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, bool live, const double *gz, const double *gm,
                                               const double *__restrict__ M, const double *__restrict__ z,
                                               const double *__restrict__ ra, const double *__restrict__ dec,
-                                              const double *__restrict__ ex0, const double *__restrict__ ex1,
+                                              ExtraCols ex,
                                               const double *__restrict__ lnz1, const double *__restrict__ lnM,
                                               int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow, float *s_work);
 
@@ -606,7 +614,7 @@ __global__ void __launch_bounds__(256, 4)
 halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
                  const double *__restrict__ M, const double *__restrict__ z,
                  const double *__restrict__ ra, const double *__restrict__ dec,
-                 const double *__restrict__ ex0, const double *__restrict__ ex1,
+                 ExtraCols ex,
                  const double *__restrict__ lnz1, const double *__restrict__ lnM,
                  int fallback4, Tiling T, PrepOut o)
 {
@@ -636,7 +644,7 @@ halo_prep_kernel(DevModel m, Hpx h, int64_t nhalo,
     __syncthreads();                                       // (s_nslow)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // (every lane runs it -- the binning shuffles across the wave --, the lanes beyond the catalog on its last halo and without any store)
-    halo_prep_one<NC, real>(m, h, j < nhalo ? j : nhalo - 1, j < nhalo, gz, gm, M, z, ra, dec, ex0, ex1, lnz1, lnM, fallback4, T, o, &s_nslow, &s_work);
+    halo_prep_one<NC, real>(m, h, j < nhalo ? j : nhalo - 1, j < nhalo, gz, gm, M, z, ra, dec, ex, lnz1, lnM, fallback4, T, o, &s_nslow, &s_work);
     if (o.slow_cnt) {
         __syncthreads();
         if (threadIdx.x == 0) o.slow_cnt[blockIdx.x] = s_nslow;
@@ -648,7 +656,7 @@ template <int NC, typename real>
 __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, int64_t j, bool live, const double *gz, const double *gm,
                                               const double *__restrict__ M, const double *__restrict__ z,
                                               const double *__restrict__ ra, const double *__restrict__ dec,
-                                              const double *__restrict__ ex0, const double *__restrict__ ex1,
+                                              ExtraCols ex,
                                               const double *__restrict__ lnz1, const double *__restrict__ lnM,
                                               int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow, float *s_work)
 {
@@ -806,14 +814,17 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     r.lnoff = m.tab.rdelta ? (x0 - fast_log(Rmod)) : x0;
     double wv[NC];
     int32_t ro[NC];
-    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, (NC >= 8) ? ex0[jin] : 0.0, (NC >= 16) ? ex1[jin] : 0.0, wv, ro);
+    double xe[BFGX_MAX_EXTRA];
+#pragma unroll
+    for (int k = 0; k < BFGX_MAX_EXTRA; ++k) xe[k] = ((4 << k) < NC) ? ex.p[k][jin] : 0.0;          // (axis k exists iff NC >= 8 << k)
+    const bool oob = table_corners<NC>(m.tab, gz, gm, x0, x1, xe, wv, ro);
     r.oob = oob ? 1 : 0;
     if (NC == 4) {
         for (int c = 0; c < 4; ++c) { r.w[c] = wv[c]; r.rowoff[c] = ro[c]; }
     } else {
         for (int c = 0; c < 4; ++c) { r.w[c] = 0.0; r.rowoff[c] = 0; }
         RowSetX rx;
-        for (int c = 0; c < kNCmax; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
+        for (int c = 0; c < kNCmaxShell; ++c) { rx.w[c] = c < NC ? wv[c] : 0.0; rx.rowoff[c] = c < NC ? ro[c] : 0; }
         if (live) o.rowsx[j] = rx;
     }
 

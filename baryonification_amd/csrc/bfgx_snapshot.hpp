@@ -105,7 +105,7 @@ snap_halo_prep_kernel(DevModel m, SnapGeom g, int64_t nh, const double *__restri
         const double x1 = lnM ? lnM[j] : (double)logf((float)M_j);                      // float32 log, see bfgx_grid.hpp
         double wv[kNC];
         int32_t ro[kNC];
-        r.oob = table_corners<kNC>(m.tab, m.tab.axis[0], m.tab.axis[1], log(1.0 / a), x1, 0.0, 0.0, wv, ro) ? 1 : 0;
+        r.oob = table_corners<kNC>(m.tab, m.tab.axis[0], m.tab.axis[1], log(1.0 / a), x1, (const double *)nullptr, wv, ro) ? 1 : 0;
         for (int q = 0; q < kNC; ++q) { r.w[q] = wv[q]; r.rowoff[q] = ro[q]; }
         if (!(R_q > 0.0) || !isfinite(R_q)) r.valid = 0;
         for (int ax = 0; ax < g.ndim && r.valid; ++ax) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BFGX_ABI_VERSION 3
+#define BFGX_ABI_VERSION 4
 
 /* Precision of the displacement path (the `acc_f64` argument of the *_device entries, bfgx_opts.acc_offsets_f64).  The reference computes in
  * float64 throughout (HealpixRunner.py:289-341); SURVEY 8(d) states the tolerance a faster mode must hold: |d| <= 1e-6 mean(map) per pixel.
@@ -51,7 +51,8 @@ extern "C" {
 #define BFGX_ACC_F32    0
 #define BFGX_ACC_F64    1
 #define BFGX_ACC_PARITY 3
-#define BFGX_MAX_EXTRA 2          /* extra (per-halo parameter) table axes, model.p_keys */
+#define BFGX_MAX_EXTRA 4          /* extra (per-halo parameter) table axes, model.p_keys (Tabulate.py:524-561 takes any number; four = 64 corner rows
+                                     per halo is what the generic tile kernel is instantiated for; the regular-grid runners take two) */
 #define BFGX_MAX_DIM (3 + BFGX_MAX_EXTRA)
 
 typedef enum bfgx_status {

@@ -223,6 +223,17 @@ def main_params():
     run_param_paint('param1_paint', 64, cat, 8.0, z, M, r, {'cdelta': c_ax}, P4)
     P5 = P4[..., None] * (f_ax / 0.1)[None, None, None, None, :] ** 1.5
     run_param_paint('param2_paint', 64, cat, 8.0, z, M, r, {'cdelta': c_ax, 'fgas': f_ax}, P5)
+    # three and four property axes (Tabulate.py:524-561 takes any number): 32 / 64 corner rows per halo
+    cat['theta'] = rng.uniform(2.0, 6.0, 250)
+    cat['theta'][5] = 6.5                                    # outside the third axis
+    cat['mu'] = rng.uniform(-0.2, 0.4, 250)
+    cat['mu'][7:9] = [-0.2, 0.4]                             # on both ends of the fourth
+    t_ax = np.array([2.0, 3.5, 6.0])
+    m_ax = np.array([-0.2, 0.1, 0.4])
+    P6 = P5[..., None] * (1 + 0.05 * (t_ax - 4.0))[None, None, None, None, None, :]
+    run_param_paint('param3_paint', 64, cat, 8.0, z, M, r, {'cdelta': c_ax, 'fgas': f_ax, 'theta': t_ax}, P6)
+    P7 = P6[..., None] * np.exp(0.3 * m_ax)[None, None, None, None, None, None, :]
+    run_param_paint('param4_paint', 64, cat, 8.0, z, M, r, {'cdelta': c_ax, 'fgas': f_ax, 'theta': t_ax, 'mu': m_ax}, P7)
 
 
 if __name__ == '__main__':

@@ -6,7 +6,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, 'golden')
 GOLDEN_CASES = ['c1_baryonify', 'lowz_baryonify', 'rdelta_baryonify', 'massdef_baryonify', 'lowz_paint', 'c1_paint', 'massdef_paint',
-                'param1_paint', 'param2_paint']
+                'param1_paint', 'param2_paint', 'param3_paint', 'param4_paint']
 COSMO_KEYS = ('Omega_m', 'Omega_b', 'h', 'sigma8', 'n_s', 'w0')
 
 

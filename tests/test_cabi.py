@@ -28,7 +28,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_device_count_callable_without_gpu():
     L = _lib.load()
-    assert L.bfgx_abi_version() == 3 == _lib.ABI_VERSION
+    assert L.bfgx_abi_version() == 4 == _lib.ABI_VERSION
     assert L.bfgx_device_count() >= 0
 
 
@@ -36,8 +36,8 @@ def test_struct_sizes_match_header_layout():
     import ctypes as C
     assert C.sizeof(_lib.bfgx_cosmo) == 64
     assert C.sizeof(_lib.bfgx_massdef) == 16
-    assert C.sizeof(_lib.bfgx_table) == 4 + 4 * 5 + 8 * 5 + 8 + 4 + 4 + 8
-    assert C.sizeof(_lib.bfgx_catalog) == 8 + 4 * 8 + 2 * 8 + 2 * 8       # n, M z ra dec, extra[2], ln1pz lnM
+    assert C.sizeof(_lib.bfgx_table) == 4 + 4 * 7 + 8 * 7 + 8 + 4 + 4 + 8       # ndim, n[7], axis[7], values, rdelta, log, eps_model
+    assert C.sizeof(_lib.bfgx_catalog) == 8 + 4 * 8 + 4 * 8 + 2 * 8       # n, M z ra dec, extra[4], ln1pz lnM
     assert C.sizeof(_lib.bfgx_opts) == 24 + 8                           # 6 x int32, catalog_token
 
 

@@ -358,28 +358,29 @@ def test_paint_host_entry_in_band_ranges_equals_one_pass(gpu, mode, monkeypatch)
     assert np.abs(piped - ora).max() <= (1e-10 if mode is True else 5e-5) * np.abs(ora).max()
 
 
-def test_more_than_two_property_axes_are_refused_loudly():
-    """Tabulate.py:524-561 / BaryonCorrection.py:205-221 accept any number of `other_params`; libbfgx reads out at most two property
-    axes (BFGX_MAX_EXTRA).  A third must raise, naming the limit -- never a silent truncation"""
+def test_more_than_four_property_axes_are_refused_loudly():
+    """Tabulate.py:524-561 / BaryonCorrection.py:205-221 accept any number of `other_params`; libbfgx reads out up to four property
+    axes (BFGX_MAX_EXTRA: 64 corner rows per halo; goldens param3_paint / param4_paint).  A fifth must raise, naming the limit -- never a
+    silent truncation"""
     import pytest
     from baryonification_amd import _lib
     from baryonification_amd.Runners import _model as RM
-    ax = [np.linspace(0.1, 0.2, 2), np.linspace(28, 34, 3), np.linspace(-3, 3, 4), np.linspace(0, 1, 2), np.linspace(0, 1, 2), np.linspace(0, 1, 2)]
-    with pytest.raises(NotImplementedError, match="BFGX_MAX_EXTRA = 2"):
+    ax = [np.linspace(0.1, 0.2, 2), np.linspace(28, 34, 3), np.linspace(-3, 3, 4)] + [np.linspace(0, 1, 2) for _ in range(5)]
+    with pytest.raises(NotImplementedError, match="BFGX_MAX_EXTRA = 4"):
         _lib.make_table(ax, np.zeros([a.size for a in ax]))
-    _lib.make_table(ax[:5], np.zeros([a.size for a in ax[:5]]))          # two property axes are fine
+    _lib.make_table(ax[:7], np.zeros([a.size for a in ax[:7]]))          # four property axes are fine
 
-    class ThreeParams(object):                                           # a duck-typed ParamTabulatedProfile with three property axes
-        p_keys = ['alpha', 'beta', 'gamma']
+    class FiveParams(object):                                            # a duck-typed ParamTabulatedProfile with five property axes
+        p_keys = ['p0', 'p1', 'p2', 'p3', 'p4']
         epsilon_max, cosmo, mass_def = 10.0, None, None
         raw_input_z_range, raw_input_M_range, raw_input_r_range = ax[0], ax[1], ax[2]
-        raw_input_alpha_range, raw_input_beta_range, raw_input_gamma_range = ax[3], ax[4], ax[5]
+        raw_input_p0_range, raw_input_p1_range, raw_input_p2_range, raw_input_p3_range, raw_input_p4_range = ax[3:8]
         raw_input_d = np.zeros([a.size for a in ax])
 
     class R(object):
-        model = ThreeParams()
-    R.model.__dict__['p_keys'] = ThreeParams.p_keys
-    with pytest.raises(NotImplementedError, match="3 property axes"):
+        model = FiveParams()
+    R.model.__dict__['p_keys'] = FiveParams.p_keys
+    with pytest.raises(NotImplementedError, match="5 property axes"):
         RM.build_model(R(), 'displacement')
 
 
