@@ -125,6 +125,7 @@ struct bfgx_plan {
     FarList far;                     // deposits of the gathering regrid that need the generic route (bfgx_regrid2.hpp)
     int32_t *far_overflow_full = nullptr;   // full-map regrid: overflow of the list is repaired in-stream (pass 1), not an error
     int32_t *regrid_todo = nullptr;  // [0] = count, then the tiles the lean gather kernel leaves to the one with the ring walk
+    int32_t *regrid_lean = nullptr;  // [0] = count (zeroed by the regrid's last launch), then the tiles of the lean kernel (reach <= 1 ring)
     float *tile_omax = nullptr;      // largest |offset|^2 of every tile (K1's flush or tile_reach_kernel): the reach of the gathering regrid
     bool omax_from_k1 = false;       // set while a fused offsets + regrid call is in flight
     bool paint_pair_f32 = false;     // set while a paint call with acc_f64 = 2 is in flight: f32 pair math into the f64 map
@@ -856,6 +857,12 @@ int bfgx_plan_create(int device, void *hip_stream, int64_t nside, int64_t max_ha
                 dalloc(sizeof(int32_t) * 2 * (size_t)(T.ntiles + 1), &f3))
                 return bail(fail(BFGX_ERR_HIP, "hipMalloc(far list) failed"));
             p->tile_apron = (int32_t *)f3;
+            {
+                void *fl = nullptr;
+                if (dalloc(sizeof(int32_t) * (size_t)(T.ntiles + 4), &fl)) return bail(fail(BFGX_ERR_HIP, "hipMalloc(lean tile list) failed"));
+                p->regrid_lean = (int32_t *)fl;
+                if (hipMemsetAsync(fl, 0, sizeof(int32_t) * 4, p->stream) != hipSuccess) return bail(fail(BFGX_ERR_HIP, "hipMemset failed"));
+            }
             int32_t *ctrl = (int32_t *)f0;
             p->far.count = (unsigned long long *)ctrl; p->far.pix = (int64_t *)f1; p->far.val = (double *)f2;
             p->far_overflow_full = ctrl + 2;
@@ -1481,16 +1488,17 @@ static void launch_regrid_gather(bfgx_plan *p, const double *map_in_dev, const A
     if (!from_k1)
         hipLaunchKernelGGL(tile_reach_kernel<ACC>, dim3(nt), dim3(256), 0, p->stream, p->hpx, p->tiling, o, p->tile_omax);
     hipLaunchKernelGGL(tile_apron_kernel, dim3((nt + 255) / 256), dim3(256), 0, p->stream, p->hpx, p->tiling, (const float *)p->tile_omax, 0,
-                       reach.cap, 0, nt, p->tile_apron, p->regrid_todo);
-    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0, SPLIT>), dim3(nt), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
-                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
+                       reach.cap, 0, nt, p->tile_apron, p->regrid_todo, p->regrid_lean);
+    // (the lean kernel: a persistent grid over the tiles whose reach is one ring -- all of them on a table of sub-pixel moves, none on the S19 table)
+    hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 0, SPLIT>), dim3(std::min(nt, 8 * p->num_cus)), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_lean, (double *)nullptr);
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 2, SPLIT>), dim3(nwalk), dim3(256), lds_walk, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
                        map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, (double *)nullptr);
     // the two sums of the mass check: added up by the last launch, or -- above 16384 tiles, where that single workgroup's loop
     // takes 0.2 - 0.6 ms -- by 64 workgroups afterwards
     const bool many = nt > 16384 && sums_dev != nullptr && ts != nullptr;
     hipLaunchKernelGGL((tile_regrid3_kernel<ACC, real, 1, SPLIT>), dim3(nfix), dim3(256), lds, p->stream, p->hpx, p->tiling, map_in_dev, o, o_lo,
-                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, many ? (double *)nullptr : sums_dev);
+                       map_out_dev, far, reach, ts, -1, nt, p->regrid_todo, many ? (double *)nullptr : sums_dev, p->regrid_lean);
     if (many) {
         (void)hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream);
         hipLaunchKernelGGL(sum_tiles_multi_kernel, dim3(64), dim3(256), 0, p->stream, nt, (const double *)ts, sums_dev);

@@ -292,10 +292,14 @@ tile_reach_kernel(Hpx h, Tiling T, const ACC *__restrict__ offsets, float *__res
 // reach exceeds one ring are listed in todo ([0] = count) for the kernel with the ring walk.  One thread per tile.
 __global__ void __launch_bounds__(256)
 tile_apron_kernel(Hpx h, Tiling T, const float *__restrict__ tile_omax, int rings, double cap, int tile0, int ntiles,
-                  int32_t *__restrict__ apron, int32_t *__restrict__ todo)
+                  int32_t *__restrict__ apron, int32_t *__restrict__ todo, int32_t *__restrict__ lean = nullptr)
 {
+    // (lean != nullptr: the tiles whose reach is at most one ring are listed too -- [0] = count, zeroed by the regrid's last launch --, so that
+    // the lean kernel is a small persistent grid over THAT list and costs nothing where every tile walks: 6208 workgroups of 40 KB that
+    // return at once were 16 us per step on the S19 table)
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ntiles) return;
+    bool is_lean = false;
+    if (i < ntiles) {
     const int tile = tile0 + i;
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
@@ -346,6 +350,19 @@ tile_apron_kernel(Hpx h, Tiling T, const float *__restrict__ tile_omax, int ring
     apron[2 * tile] = R;
     apron[2 * tile + 1] = (nphi == 1) ? 0 : (kk < (float)kReachColsMax ? (int)kk + 1 : kReachColsMax);
     if (todo != nullptr && R > 1) todo[1 + atomicAdd(todo, 1)] = tile;
+    is_lean = R <= 1;
+    }
+    if (lean != nullptr) {                               // one atomic per wave
+        const unsigned long long m = __ballot(is_lean);
+        if (m) {
+            const int lane = threadIdx.x & (kWave - 1), leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(lean, __popcll(m));
+            base = __shfl(base, leader, kWave);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (is_lean && pos < ntiles) lean[1 + pos] = tile0 + i;           // (pos < ntiles always; the bound keeps a stale count inside the list)
+        }
+    }
 }
 
 // largest |o|^2 of n pixels as the bits of a float (non-negative floats order like unsigned integers); *out zeroed by the caller
@@ -527,7 +544,7 @@ template <typename ACC, typename real, int PASS, bool SPLIT = false>
 __global__ void __launch_bounds__(256, BFGX_K2_OCC)
 tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const ACC *__restrict__ offsets, const ACC *__restrict__ offsets_lo,
                     double *__restrict__ map_out, FarList far, ReachArgs reach, double *__restrict__ tile_sums, int tile_off, int ntiles,
-                    int *__restrict__ todo, double *__restrict__ sums_out)
+                    int *__restrict__ todo, double *__restrict__ sums_out, int *__restrict__ lean_reset = nullptr)
 {
     // map_in, offsets and map_out are indexed by GLOBAL pixel number.  tile_off < 0: all tiles, heavy ones first; tile_off >= 0
     // (a rank that owns a range of bands): tiles tile_off + blockIdx.x, and the caller passes offsets / map_out pointers
@@ -540,6 +557,9 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
     RegRowC<real> *rowc = reinterpret_cast<RegRowC<real> *>(rows + NTmax);
     const int tid = threadIdx.x;
     const int nl4 = (int)(4 * h.nside);
+    // (PASS 1 is the regrid's last launch: the lean kernel's list is free again -- its count starts the next regrid at zero; FIRST, before the
+    // early return below: a count that is never reset grows past the list)
+    if (PASS == 1 && lean_reset != nullptr && blockIdx.x == 0 && tid == 0) *lean_reset = 0;
     if (PASS == 1 && sums_out != nullptr && blockIdx.x == 0) {
         // the two sums of the mass check from the per-tile totals the gather kernels left (the last launch of the regrid: all
         // tiles are done); sums_out[0] = sum of the source values, [1] = sum of the deposits
@@ -563,9 +583,11 @@ tile_regrid3_kernel(Hpx h, Tiling T, const double *__restrict__ map_in, const AC
             atomicAdd(map_out + far.pix[i], far.val[i]);
         return;
     }
-    const bool listed = (PASS == 2) && todo != nullptr;
-    if (listed) ntiles = todo[0];
-    for (int blk = blockIdx.x; blk < ntiles; blk += (PASS == 0 ? ntiles : (int)gridDim.x)) {      // (PASS 0: one tile per workgroup)
+    // PASS 2 walks the tiles tile_apron_kernel listed in `todo`; PASS 0 (full-map regrid) the tiles of ITS list, a small persistent grid -- or,
+    // without a list (banded regrid), one tile per workgroup
+    const bool listed = (PASS == 2 || PASS == 0) && todo != nullptr;
+    if (listed) ntiles = min(todo[0], ntiles);
+    for (int blk = blockIdx.x; blk < ntiles; blk += ((PASS == 0 && !listed) ? ntiles : (int)gridDim.x)) {
     const int tile = listed ? todo[1 + blk] : ((tile_off < 0) ? T.tile_order[blk] : tile_off + blk);
     const int band = T.tile_band[tile];
     const int nphi = T.band_nphi[band];
