@@ -72,6 +72,15 @@ def _paint_mode(runner):
     return 2 if (a is None or a in (2, 'mixed')) else (1 if a else 2)
 
 
+def _wide_offsets(runner, plan):
+    """Do the multi-GPU paths of this runner need more than fp32 pair math?  runner.acc_f64 as BaryonifyShell.process() reads it (None: the plan
+    picks from the table, include/bfgx.h BFGX_ACC_AUTO).  The rank-to-rank exchanges move ONE array of pix_offsets, so the parity-grade mode runs
+    as fp64 throughout here (the band-restricted entries resolve it the same way): a table that moves pixels holds SURVEY 8(d)'s 1e-6 mean(map)
+    on N GPUs as on one."""
+    from .. import _lib
+    return plan.precision(_lib.acc_mode(getattr(runner, 'acc_f64', None)))[0] != _lib.ACC_F32
+
+
 def _hip_compute(runner, kind, cat_cols, device):
     """Per-rank partial accumulator on `device` (torch tensor): pix_offsets (f32 [npix*3]) or painted map."""
     import torch
@@ -89,8 +98,9 @@ def _hip_compute(runner, kind, cat_cols, device):
     cd = _lib.make_catalog_dev(n, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr(),
                                [t[k].data_ptr() for k in p_keys], ln1pz_ptr=t['_lnz'].data_ptr(), lnM_ptr=t['_lnM'].data_ptr())
     if kind == 'baryonify':
-        acc = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
-        plan.offsets(cd, acc.data_ptr(), acc_f64=False)
+        wide = _wide_offsets(runner, plan)
+        acc = torch.zeros(npix * 3, dtype=torch.float64 if wide else torch.float32, device=dev)
+        plan.offsets(cd, acc.data_ptr(), acc_f64=int(wide))
     else:
         acc = torch.zeros(npix, dtype=torch.float64, device=dev)
         plan.paint(cd, acc.data_ptr(), acc_f64=_paint_mode(runner))
@@ -248,8 +258,9 @@ def _hip_compute_spatial(runner, kind, cat_cols, device, world, rank):
                                [t[4 + i].data_ptr() for i in range(len(p_keys))], ln1pz_ptr=t[-2].data_ptr(), lnM_ptr=t[-1].data_ptr())
     p0, p1 = int(first[cuts[rank]]), int(first[cuts[rank + 1]])
     if kind == 'baryonify':
-        sl = torch.zeros((p1 - p0) * 3, dtype=torch.float32, device=dev)
-        plan.offsets_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=False)
+        wide = _wide_offsets(runner, plan)
+        sl = torch.zeros((p1 - p0) * 3, dtype=torch.float64 if wide else torch.float32, device=dev)
+        plan.offsets_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=int(wide))
     else:
         sl = torch.zeros(p1 - p0, dtype=torch.float64, device=dev)
         plan.paint_bands(cd, int(cuts[rank]), int(cuts[rank + 1]), sl.data_ptr(), acc_f64=_paint_mode(runner))
@@ -264,7 +275,7 @@ def _hip_regrid(runner, plan, acc, device):
     hmap = torch.from_numpy(np.ascontiguousarray(runner.LightconeShell.map, dtype=np.float64)).to(dev)
     out = torch.zeros_like(hmap)
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
-    plan.regrid(hmap.data_ptr(), acc.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    plan.regrid(hmap.data_ptr(), acc.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=int(acc.dtype == torch.float64))
     torch.cuda.synchronize(dev)
     s = sums.cpu().numpy()
     assert np.isclose(s[1], s[0]), "ERROR in pixel regridding, sum(new_map) [%0.14e] != sum(oldmap) [%0.14e]" % (s[1], s[0])
@@ -431,7 +442,7 @@ def _hip_regrid_slice(runner, plan, off_apron, olo, ohi, b0, b1, p0, p1, device)
     hmap = torch.from_numpy(np.ascontiguousarray(runner.LightconeShell.map, dtype=np.float64)).to(dev)
     out = torch.empty(int(p1 - p0), dtype=torch.float64, device=dev)
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
-    plan.regrid_bands(b0, b1, hmap.data_ptr(), off_apron.data_ptr(), olo, ohi, out.data_ptr(), sums.data_ptr(), acc_f64=False)
+    plan.regrid_bands(b0, b1, hmap.data_ptr(), off_apron.data_ptr(), olo, ohi, out.data_ptr(), sums.data_ptr(), acc_f64=int(off_apron.dtype == torch.float64))
     pix, val = plan.far_fetch()
     return out, pix, val, sums.cpu().numpy()
 
@@ -665,7 +676,7 @@ class SplitJoinParallel(object):
         stats = _lib.bfgx_stats()
         acc64 = getattr(runner, 'acc_f64', None)
         if self.kind == 'baryonify':
-            opts = _lib.bfgx_opts(0, int(bool(acc64)), 1, 1, 1, 0)
+            opts = _lib.bfgx_opts(0, _lib.acc_mode(acc64), 1, 1, 1, 0)
             orig_map = _lib.f8(runner.LightconeShell.map)
             rc = _lib.load().bfgx_baryonify_shell_multi(C.byref(c), C.byref(model), nside, orig_map.ctypes.data, new_map.ctypes.data,
                                                         self.njobs, devs, C.byref(opts), C.byref(stats))

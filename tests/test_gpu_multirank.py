@@ -30,7 +30,7 @@ def test_distributed_process_hip_two_ranks(gpu):
     out = _launch('rehearse_multi_gpu.py', 2)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith('rehearsal')]
-    assert len(lines) == 4 and all(l.rstrip().endswith('OK') for l in lines), out.stdout[-2000:]       # 2 runners x 2 exchanges
+    assert len(lines) == 6 and all(l.rstrip().endswith('OK') for l in lines), out.stdout[-2000:]       # 3 cases x 2 exchanges
 
 
 def test_grid_slabs_hip_two_ranks(gpu):
