@@ -48,7 +48,7 @@ class DefaultRunnerSnapshot(object):
 class BaryonifySnapshot(DefaultRunnerSnapshot):
     """Moves every particle within epsilon_max * R200c of a halo radially by the model's displacement."""
 
-    def process(self):
+    def _setup(self):
         snap = self.ParticleSnapshot
         hcat = self.HaloNDCatalog.cat
         is2D = snap.is2D
@@ -60,6 +60,45 @@ class BaryonifySnapshot(DefaultRunnerSnapshot):
         with np.errstate(invalid='ignore', divide='ignore'):
             lnM = np.log(np.asarray(hcat['M'], dtype=np.float32)).astype(np.float64)     # float32 log, as BaryonifyGrid
         cat, cols = _lib.make_grid_catalog_host(hcat['M'], hcat['x'], hcat['y'], None if is2D else hcat['z'], lnM)
+        return snap, is2D, model, keep, cat, cols
+
+    def process_make_map(self, N_grid):
+        """`ParticleSnapshot(cat=self.process(), ...).make_map(N_grid)` (SnapshotRunner.py:173-262 followed by io.py:622-670) as ONE call for
+        the common case that only the map of the baryonified particles is wanted (the reference's notebook 10): the records go to the device
+        once, the displaced coordinates exist only as the deposit's sort keys, the map comes back.  Not in the reference's API; the result
+        equals the two calls (cell for cell with unit masses, to the order of the sums inside a cell otherwise).  Snapshots whose `cat` is
+        not one C-contiguous structured array of float64 fields take the two calls."""
+        snap, is2D, model, keep, cat, cols = self._setup()
+        rec = snap.cat
+        fields = rec.dtype.fields or {}
+        need = ('x', 'y', 'M') if is2D else ('x', 'y', 'z', 'M')
+        ndim = 2 if is2D else 3
+        ok = (isinstance(rec, np.ndarray) and rec.ndim == 1 and rec.flags.c_contiguous and rec.dtype.itemsize % 8 == 0 and rec.dtype.itemsize >= 16 and
+              all(k in fields and fields[k][0] == np.float64 and fields[k][1] % 8 == 0 for k in need))
+        if ok:
+            edges = np.linspace(0, snap.L, N_grid + 1)                # io.py:640
+            out = _lib.pinned_empty(N_grid ** ndim).reshape((N_grid,) * ndim)
+            opts = _lib.bfgx_opts(int(self.device), 1, 1, 0, 1, 0)
+            stats = _lib.bfgx_stats()
+            rc = _lib.load().bfgx_baryonify_snapshot_records_map(
+                C.byref(cat), C.byref(model), ndim, float(snap.L), float(self.HaloNDCatalog.redshift), rec.size,
+                rec.ctypes.data if rec.size else None, rec.dtype.itemsize, fields['x'][1], fields['y'][1], 0 if is2D else fields['z'][1],
+                fields['M'][1], int(N_grid), edges.ctypes.data, out.ctypes.data, C.byref(opts), C.byref(stats))
+            if rc == _lib.ERR_UNSUPPORTED:
+                ok = False                                            # (a grid the tile-owned deposit does not take)
+            else:
+                _lib.check(rc)
+                self.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+                del keep, cols
+                return out
+        from ..utils.io import ParticleSnapshot
+        new = ParticleSnapshot.__new__(ParticleSnapshot)
+        new.__dict__.update(snap.__dict__)
+        new.cat = self.process()
+        return new.make_map(N_grid)
+
+    def process(self):
+        snap, is2D, model, keep, cat, cols = self._setup()
         opts = _lib.bfgx_opts(int(self.device), 1, 1, 0, 1, 0)
         stats = _lib.bfgx_stats()
         rec = snap.cat

@@ -180,6 +180,11 @@ SYMBOLS = {
     'bfgx_snapshot_plan_destroy': (None, [C.c_void_p]),
     'bfgx_snapshot_displace_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, _P(C.c_int64)]),
+    'bfgx_baryonify_snapshot_records_map': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_void_p,
+                                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                                      _P(bfgx_opts), _P(bfgx_stats)]),
+    'bfgx_snapshot_displace_deposit_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_int32, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     'bfgx_grid_plan_create': (C.c_int, [C.c_int, C.c_void_p, _P(bfgx_grid), C.c_int64, _P(bfgx_model), _P(C.c_void_p)]),
     'bfgx_grid_plan_destroy': (None, [C.c_void_p]),
     'bfgx_grid_offsets_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_void_p, _P(C.c_int64)]),

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -39,8 +40,8 @@ template <typename T> static inline hipError_t bfgx_counted_malloc(T **p, size_t
 #include "bfgx_tables.hpp"
 #include "bfgx_grid.hpp"
 #include "bfgx_fft.hpp"
-#include "bfgx_snapshot.hpp"
 #include "bfgx_deposit.hpp"
+#include "bfgx_snapshot.hpp"
 #include "bfgx_grid_gather.hpp"
 #include "bfgx_fftlog.hpp"
 

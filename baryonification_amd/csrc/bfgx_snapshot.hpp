@@ -11,10 +11,14 @@
 //   scan_* kernels           exclusive scan of the per-cell counts
 //   snap_halo_fill_kernel    halo index into each touched cell's list
 //   snap_displace_kernel     per particle: min-image separation (:67-92), displacement read-out, offset (:225-252),
-//                            periodic re-wrap (:254-262)
+//                            periodic re-wrap (:254-262).  KEYS = true (BaryonifySnapshot.process() followed by
+//                            ParticleSnapshot.make_map(N), io.py:622-670, when only the map is wanted): the displaced
+//                            position goes straight into its deposit key (bfgx_deposit.hpp) instead of three columns --
+//                            24 B per particle are neither written nor read again, and deposit_keys_kernel does not run
 #pragma once
 #include "bfgx_kernels.hpp"
 #include "bfgx_tables.hpp"
+#include "bfgx_deposit.hpp"
 
 namespace bfgx {
 
@@ -290,13 +294,29 @@ constexpr int kSnapQueue = 768 * kSnapPPT;           // queued hits per round (3
 #ifndef BFGX_SNAP_OCC
 #define BFGX_SNAP_OCC 4             // workgroups of 256 threads per SIMD group the kernel is compiled for (register budget 512 / (4 x this))
 #endif
-template <int DIM>
+// KEYS: where the deposit keys of the displaced particles go.  The workgroup then owns CHUNKS of kDepChunk consecutive particles -- the unit
+// deposit_split_kernel<1> works on -- and leaves each chunk's histogram of level-1 buckets in wg_hist[bucket][chunk], as deposit_keys_kernel does.
+struct SnapDepArgs {
+    DepGeom dg;
+    const double *edges;              // [dg.nb + 1]
+    uint32_t *keys;                   // [np]
+    int32_t *wg_hist;                 // [dg.B1][nchunks]
+    int32_t nchunks, _pad;
+};
+
+template <int DIM, bool KEYS>
 __global__ void __launch_bounds__(256, BFGX_SNAP_OCC)
 snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, const double *py,
                      const double *pz, const SnapHaloRec *__restrict__ recs, const uint32_t *__restrict__ bitmap,
                      const int32_t *__restrict__ cell_start, const SnapEntry *__restrict__ entries, double *ox, double *oy, double *oz,
-                     int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total, int64_t sin, int64_t sout)
+                     int32_t *__restrict__ flags, unsigned long long *__restrict__ pair_total, int64_t sin, int64_t sout, SnapDepArgs da)
 {
+    static_assert(!KEYS || kDepChunk % kSnapBlock == 0, "a chunk of the deposit's sort is a whole number of rounds");
+    __shared__ int dhist[KEYS ? 1024 : 1];
+    __shared__ double sedge[KEYS ? kDepEdgesLds : 1];
+    const bool lds_edges = KEYS && da.dg.nb + 1 <= kDepEdgesLds;
+    if (KEYS && lds_edges) for (int i = threadIdx.x; i <= da.dg.nb; i += 256) sedge[i] = da.edges[i];      // (the first barrier of the loop publishes them)
+    const double dscale = KEYS ? (double)da.dg.nb / (da.edges[da.dg.nb] - da.edges[0]) : 0.0;
     // sin / sout: distance in doubles between consecutive particles of the input / output columns (1: plain columns; the records entry
     // passes the record size / 8 and column pointers into the record buffer -- possibly the SAME buffer: a particle's own coordinates are
     // read before they are written, and no other thread reads them)
@@ -354,9 +374,15 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, con
         else hit(slot, en.idx);                                                  // queue full (a cluster core): done here
     };
 
-    // grid-stride over blocks of 256 particles: a bounded number of workgroups, so that the pair census ends in a few thousand
-    // atomics on one address instead of one per wave (10^6 same-address atomics cost ~10 ms)
-    for (int64_t base = (int64_t)blockIdx.x * kSnapBlock; base < np; base += (int64_t)gridDim.x * kSnapBlock) {
+    // grid-stride over blocks of 256 particles (KEYS: over chunks of kDepChunk, a chunk in rounds of 256): a bounded number of workgroups,
+    // so that the pair census ends in a few thousand atomics on one address instead of one per wave (10^6 same-address atomics cost ~10 ms)
+    constexpr int kRounds = KEYS ? kDepChunk / kSnapBlock : 1;
+    const int64_t nunits = KEYS ? (int64_t)da.nchunks : (np + kSnapBlock - 1) / kSnapBlock;
+    for (int64_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    if (KEYS) for (int i = tid; i < da.dg.B1; i += 256) dhist[i] = 0;          // (used in phase 3, two barriers from here)
+    for (int rnd = 0; rnd < kRounds; ++rnd) {
+        const int64_t base = (unit * kRounds + rnd) * kSnapBlock;
+        if (base >= np) break;                                  // (the whole workgroup)
         // particle k of this thread: slot = k * 256 + tid (consecutive lanes = consecutive particles: coalesced)
         bool on[kSnapPPT];
         double x[kSnapPPT], y[kSnapPPT], z[kSnapPPT];
@@ -431,21 +457,42 @@ snap_displace_kernel(PairTable pt, SnapGeom g, int64_t np, const double *px, con
         for (int k = 0; k < kSnapPPT; ++k) {
             const int64_t p = base + k * 256 + tid;
             const int sl = k * 256 + tid;
+            double nx = 0.0, ny = 0.0, nz = 0.0;
             if (on[k] || outside[k]) {
-                double nx = x[k] + sacc[0][sl], ny = y[k] + sacc[1][sl], nz = z[k] + sacc[2][sl];  // :254-257
+                nx = x[k] + sacc[0][sl]; ny = y[k] + sacc[1][sl]; nz = z[k] + sacc[2][sl];         // :254-257
                 if (nx > g.L) nx -= g.L;                                                     // :259-262
                 if (nx < 0.0) nx += g.L;
                 if (ny > g.L) ny -= g.L;
                 if (ny < 0.0) ny += g.L;
-                ox[p * sout] = nx; oy[p * sout] = ny;
                 if (DIM == 3) {
                     if (nz > g.L) nz -= g.L;
                     if (nz < 0.0) nz += g.L;
-                    oz[p * sout] = nz;
                 }
+                if (!KEYS) {
+                    ox[p * sout] = nx; oy[p * sout] = ny;
+                    if (DIM == 3) oz[p * sout] = nz;
+                }
+            }
+            if constexpr (KEYS) {
+                // ParticleSnapshot.make_map's histogram bin of the displaced position (io.py:640-668; deposit_keys_kernel), every lane
+                // of the wave (lds_hist_rank shuffles).  The search runs on `e` once per address space (see deposit_keys_kernel).
+                const bool have = p < np;
+                auto bins = [&](const auto *e) {
+                    const int bx = histogram_bin(e, da.dg.nb, nx, dscale), by = histogram_bin(e, da.dg.nb, ny, dscale);
+                    const int bz = (DIM == 3) ? histogram_bin(e, da.dg.nb, nz, dscale) : 0;
+                    return (have && bx >= 0 && by >= 0 && bz >= 0) ? dep_key(da.dg, bx, by, bz) : kDepNoKey;
+                };
+                const uint32_t key = lds_edges ? bins(sedge) : bins(da.edges);
+                lds_hist_rank(dhist, (int)((key >> kDepLocalBits) >> da.dg.lB2), key != kDepNoKey);
+                if (have) da.keys[p] = key;
             }
         }
         __syncthreads();                                   // the LDS buffers are reused by the next block of particles
+    }
+    if (KEYS) {
+        for (int i = tid; i < da.dg.B1; i += 256) da.wg_hist[(int64_t)i * da.nchunks + unit] = dhist[i];
+        __syncthreads();                                   // (before the next chunk's zeroing)
+    }
     }
     if (pair_total) {
         __shared__ unsigned long long wsum[256 / kWave];

@@ -435,3 +435,14 @@ class SnapshotPlan(object):
                                                             C.c_void_p(int(part_ptrs[1])), z_in, C.c_void_p(int(out_ptrs[0])),
                                                             C.c_void_p(int(out_ptrs[1])), z_out, C.byref(n)))
         return int(n.value)
+
+    def displace_deposit(self, halos_dev, n_part, part_ptrs, mass_ptr, n_grid, edges_ptr, map_out_ptr):
+        """BaryonifySnapshot.process() followed by ParticleSnapshot.make_map(n_grid) of the result (SnapshotRunner.py:173-262, io.py:622-670)
+        when only the map is wanted: map_out [n_grid^ndim] float64 on the device; the displaced coordinates are never stored.  mass_ptr 0 =
+        unit masses.  Returns the number of displaced pairs."""
+        n = C.c_int64(0)
+        z_in = C.c_void_p(int(part_ptrs[2])) if self.ndim == 3 else None
+        _lib.check(_lib.load().bfgx_snapshot_displace_deposit_device(self._h, C.byref(halos_dev), int(n_part), C.c_void_p(int(part_ptrs[0])),
+                                                                    C.c_void_p(int(part_ptrs[1])), z_in, C.c_void_p(int(mass_ptr) or None),
+                                                                    int(n_grid), C.c_void_p(int(edges_ptr)), C.c_void_p(int(map_out_ptr)), C.byref(n)))
+        return int(n.value)

@@ -82,7 +82,9 @@ def parse():
     ap.add_argument('--grid-halos', type=int, default=100_000, help='grid3d: halos per GPU')
     ap.add_argument('--separate-deposit', action='store_true',
                     help='grid3d, one GPU: deposit and BaryonifyGrid as two calls (the deposit then does not leave map_out / the sum behind and '
-                         'BaryonifyGrid copies and sums the map itself); default: the fused bfgx_grid_deposit_baryonify_device')
+                         'BaryonifyGrid copies and sums the map itself); default: the fused bfgx_grid_deposit_baryonify_device.  snapshot: '
+                         'displacement and deposit as two calls (the moved coordinates are stored and read again); default: the fused '
+                         'bfgx_snapshot_displace_deposit_device')
     ap.add_argument('--sorted-particles', action='store_true',
                     help='grid3d / snapshot: order the synthetic particles by coarse cell (as snapshot files stored along a space-filling '
                          'curve are) instead of uniformly random order')
@@ -286,7 +288,9 @@ def main_grid(args):
         part_out = torch.empty_like(part)
         splan = engine.SnapshotPlan(model, keep, 3, L, zr, nh, device=local_rank, stream=stream)
     fused = world == 1 and not snapshot and not args.separate_deposit
-    ev = {k: [] for k in (('displace', 'deposit', 'pk') if snapshot else (('deposit+baryonify', 'pk') if fused else ('deposit', 'pk')))}
+    snap_fused = snapshot and not args.separate_deposit
+    ev = {k: [] for k in ((('displace+deposit', 'pk') if snap_fused else ('displace', 'deposit', 'pk')) if snapshot else
+                          (('deposit+baryonify', 'pk') if fused else ('deposit', 'pk')))}
     pairs = [0]
 
     def timed(kind, fn):
@@ -295,6 +299,16 @@ def main_grid(args):
         ev[kind].append((a, b))
 
     def step_snapshot():
+        if snap_fused:
+            # process() + make_map(N) in one call: the displacement kernel writes the deposit's sort keys, the moved coordinates are never stored
+            def both():
+                pairs[0] = splan.displace_deposit(cat_dev, npart, (part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr()), 0, N,
+                                                  d_edges.data_ptr(), d_out.data_ptr())
+            timed('displace+deposit', both)
+            timed('pk', lambda: engine.power_spectrum_device(d_out.data_ptr(), N, L, Nk, d_work.data_ptr(), d_pk.data_ptr(),
+                                                             d_ks.data_ptr(), d_cnt.data_ptr(), local_rank, stream))
+            return
+
         def displace():
             pairs[0] = splan.displace(cat_dev, npart, (part[0].data_ptr(), part[1].data_ptr(), part[2].data_ptr()),
                                       (part_out[0].data_ptr(), part_out[1].data_ptr(), part_out[2].data_ptr()))
@@ -392,7 +406,8 @@ def main_grid(args):
         spec = N * N * engine.fft_pitch(N) * 16
         alg = {'regrid': (0 if fused else N ** 3 * 16) if world == 1 else N ** 3 * (3 * 8 + 8 + 8 * 8 + 8),
                'offsets': (pairs[0] * (8 + 9 * 16) + nh * 8 * (4 + 344)) if world == 1 else pairs[0] * 3 * 8 + nh * 32,
-               'deposit': npart * (3 * 8 + 8) + N ** 3 * (16 if fused else 8), 'pk': N ** 3 * 8 + 4 * spec, 'displace': npart * 48 + nh * 32}
+               'deposit': npart * (3 * 8 + 8) + N ** 3 * (16 if fused else 8), 'pk': N ** 3 * 8 + 4 * spec, 'displace': npart * 48 + nh * 32,
+               'displace+deposit': npart * 24 + nh * 32 + N ** 3 * 8}
         dom = max(alg, key=lambda k: kernels.get(k) or 0.0)
         ach = alg[dom] / (kernels[dom] * 1e-3) / 1e9
         g_traffic, _, g_src = committed_traffic({"ngrid": N, "particles": npart, "particle_order": "coarse-cell raster" if args.sorted_particles else "random",
@@ -411,7 +426,7 @@ def main_grid(args):
                           "particle_order": "coarse-cell raster" if args.sorted_particles else "random", "ngrid": N, "particles": npart, "halos_per_gpu": nh, "contributing_pairs_per_gpu": pairs[0],
                           "parallelism": "halo shards x%d + RCCL reduce(pix_offsets) -> rank 0 regrid + P(k)" % world if world > 1 else "single GPU"},
                "halos_per_s": nh * world / elapsed * args.steps, "kernel_ms": kernels,
-               "fused_deposit": bool(fused),
+               "fused_deposit": bool(fused or snap_fused),
                "kernel_ms_note": ("single GPU, fused call (bfgx_grid_deposit_baryonify_device): the deposit's last kernel stores map_in, the start value of "
                                   "map_out and the map's sum together (no grid_copy_sum_kernel); 'deposit' = the fused call minus the plan-timed kernels, "
                                   "'offsets' = grid_gather_regrid_kernel (halo loop AND the regrid of the moved cells in one cell-owned pass), "
@@ -423,7 +438,8 @@ def main_grid(args):
                "roofline": {"kernel": {"regrid": "grid_copy_sum_kernel" if world == 1 else "grid_regrid_kernel<3>",
                                        "offsets": "grid_gather_regrid_kernel<3> (halo loop + regrid, cell-owned)" if world == 1 else "grid_scatter_kernel<3,OFFSETS>",
                                        "deposit": "deposit_keys + 2 x deposit_split + deposit_tiles (bfgx_deposit.hpp)",
-                                       "pk": "fft_r2c_lines + fft_c2c_strided + fft_c2c_strided<bins>", "displace": "snap_displace_kernel<3>"}[dom],
+                                       "pk": "fft_r2c_lines + fft_c2c_strided + fft_c2c_strided<bins>", "displace": "snap_displace_kernel<3>",
+                                       "displace+deposit": "snap_displace_kernel<3, keys> + 2 x deposit_split + deposit_tiles"}[dom],
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": g_traffic,
                             "traffic_source": g_src, "algorithmic_bytes_per_launch": alg[dom]}}
         if sorted_companion is not None:

@@ -518,6 +518,14 @@ int bfgx_baryonify_snapshot(const bfgx_grid_catalog *halos_host, const bfgx_mode
 int bfgx_baryonify_snapshot_records(const bfgx_grid_catalog *halos_host, const bfgx_model *model, int32_t ndim, double L, double redshift,
                                     int64_t n, const void *records_in, void *records_out, int32_t itemsize, int32_t off_x, int32_t off_y,
                                     int32_t off_z, const bfgx_opts *opts, bfgx_stats *stats);
+/* ParticleSnapshot(cat = BaryonifySnapshot(...).process()).make_map(n_grid) in one call (SnapshotRunner.py:173-262 then io.py:622-670), for a
+ * caller who wants the map of the displaced particles only: the records go up once, the displaced coordinates are never stored or sent back,
+ * map_out [n_grid^ndim] float64 (host) = np.histogramdd of the displaced positions on edges [n_grid + 1] (host) with the weights of the float64
+ * field at off_mass (off_mass < 0: unit masses; NaN masses -> BFGX_ERR_ASSERT, io.py:636).  Same record rules as above. */
+int bfgx_baryonify_snapshot_records_map(const bfgx_grid_catalog *halos_host, const bfgx_model *model, int32_t ndim, double L, double redshift,
+                                        int64_t n, const void *records_in, int32_t itemsize, int32_t off_x, int32_t off_y, int32_t off_z,
+                                        int32_t off_mass, int32_t n_grid, const double *edges, double *map_out, const bfgx_opts *opts,
+                                        bfgx_stats *stats);
 /* resident form: the model and the halo-cell workspace live in a plan (one per box / redshift / model); all columns and
  * outputs are device pointers (out may not alias in); blocking (two small read-backs) */
 typedef struct bfgx_snapshot_plan bfgx_snapshot_plan;
@@ -527,6 +535,14 @@ void bfgx_snapshot_plan_destroy(bfgx_snapshot_plan *p);
 int  bfgx_snapshot_displace_device(bfgx_snapshot_plan *p, const bfgx_grid_catalog *halos_dev, int64_t n_part, const double *x_dev,
                                    const double *y_dev, const double *z_dev, double *x_out_dev, double *y_out_dev, double *z_out_dev,
                                    int64_t *n_pairs_host);
+/* BaryonifySnapshot.process() (SnapshotRunner.py:173-262) followed by ParticleSnapshot.make_map(n_grid) (io.py:622-670) of the result,
+ * for a caller who wants the MAP of the displaced particles and not the particles: map_out_dev [n_grid^ndim] float64 = np.histogramdd of the
+ * displaced, re-wrapped positions on edges_dev [n_grid + 1] with weights mass_dev (NULL: unit masses).  The displaced coordinates are never
+ * stored: the displacement kernel writes the deposit's sort keys.  BFGX_ERR_UNSUPPORTED for grids the tile-owned deposit does not take
+ * (call bfgx_snapshot_displace_device + bfgx_deposit_particles_device then).  Blocking like bfgx_snapshot_displace_device. */
+int  bfgx_snapshot_displace_deposit_device(bfgx_snapshot_plan *p, const bfgx_grid_catalog *halos_dev, int64_t n_part, const double *x_dev,
+                                           const double *y_dev, const double *z_dev, const double *mass_dev, int32_t n_grid,
+                                           const double *edges_dev, double *map_out_dev, int64_t *n_pairs_host);
 /* one call = plan create + displace + destroy */
 int bfgx_baryonify_snapshot_device(int device, void *hip_stream, const bfgx_grid_catalog *halos_dev, const bfgx_model *model,
                                    const bfgx_snapshot *snap_dev, double *x_out_dev, double *y_out_dev, double *z_out_dev,

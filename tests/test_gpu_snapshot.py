@@ -175,3 +175,97 @@ def test_snapshot_records_entry_streamed_equals_columns(gpu, monkeypatch, ndim, 
     Snap.cat = odd
     out = runner.process()
     assert out.dtype == odd.dtype and same(out['x'], cols['x']) and np.array_equal(out['tag'], odd['tag'])
+
+
+@pytest.mark.parametrize('ndim,n_grid,masses', [(3, 64, False), (3, 50, True), (2, 256, False), (2, 333, True)])
+def test_snapshot_displace_deposit_fused_equals_process_then_make_map(gpu, ndim, n_grid, masses):
+    """bfgx_snapshot_displace_deposit_device (the displacement kernel writes the deposit's sort keys; the displaced coordinates are never
+    stored) == BaryonifySnapshot.process() followed by ParticleSnapshot.make_map(n_grid): cell for cell the map of the two-call route
+    (SnapshotRunner.py:173-262, io.py:622-670), and np.histogramdd of the CPU oracle's displaced particles up to the handful of particles
+    that sit within 1e-13 L of a cell edge"""
+    import torch
+    from baryonification_amd import _lib, engine
+    from baryonification_amd import synthetic as syn
+    from oracle import grid as G
+    from oracle import oracle as O
+    rng = np.random.default_rng(70 + ndim + n_grid)
+    L, nh, npart, zr = 300.0, 1500, 300_000, 0.2
+    M = (10 ** rng.uniform(12.8, 15.0, nh)).astype(np.float32).astype(np.float64)
+    hpos = rng.uniform(0, L, (nh, 3)).astype(np.float32).astype(np.float64)
+    if ndim == 2:
+        hpos[:, 2] = 0.0
+    part = rng.uniform(0, L, (npart, 3))
+    part[:50_000] = (hpos[rng.integers(0, nh, 50_000)] + rng.normal(scale=1.0, size=(50_000, 3))) % L
+    part[50_000:50_010, 0] = [0.0, L] * 5                         # on the box faces: the closed last edge of np.histogramdd
+    mass = rng.uniform(0.5, 2.0, npart) if masses else None
+    z, Mt, r = np.linspace(0.15, 0.25, 3), np.geomspace(10 ** 12.7, 10 ** 15.1, 8), np.geomspace(1e-3, 2e2, 200)
+    d = syn.displacement_table(z, Mt, r)
+    cos = dict(syn.COSMO)
+    dev = torch.device('cuda:0')
+    stream = torch.cuda.current_stream().cuda_stream
+    m, keep = engine.model_from_tables([np.log(1 + z), np.log(Mt), np.log(r)], d, dict(cos, w0=-1.0), 5.0, 8.0)
+    t = {'M': torch.tensor(M, device=dev), 'x': torch.tensor(hpos[:, 0].copy(), device=dev), 'y': torch.tensor(hpos[:, 1].copy(), device=dev),
+         'z': torch.tensor(hpos[:, 2].copy(), device=dev), 'lnM': torch.tensor(np.log(M.astype(np.float32)).astype(np.float64), device=dev)}
+    dcat = _lib.make_grid_catalog_dev(nh, t['M'].data_ptr(), t['x'].data_ptr(), t['y'].data_ptr(), t['z'].data_ptr() if ndim == 3 else 0, t['lnM'].data_ptr())
+    p = torch.tensor(np.ascontiguousarray(part[:, :ndim].T), device=dev)
+    o = torch.empty_like(p)
+    ptrs = [p[k].data_ptr() for k in range(ndim)] + [0] * (3 - ndim)
+    optrs = [o[k].data_ptr() for k in range(ndim)] + [0] * (3 - ndim)
+    d_mass = torch.tensor(mass, device=dev) if masses else None
+    edges = np.linspace(0, L, n_grid + 1)
+    d_edges = torch.tensor(edges, device=dev)
+    two, one = torch.empty(n_grid ** ndim, dtype=torch.float64, device=dev), torch.full((n_grid ** ndim,), -1.0, dtype=torch.float64, device=dev)
+    plan = engine.SnapshotPlan(m, keep, ndim, L, zr, nh, 0, stream)
+    pairs = plan.displace(dcat, npart, ptrs, optrs)
+    engine.deposit_particles_device(optrs[0], optrs[1], optrs[2], d_mass.data_ptr() if masses else 0, npart, n_grid, d_edges.data_ptr(), two.data_ptr(),
+                                    ndim, 0, stream)
+    for _ in range(2):                                            # (twice: the workspaces are reused)
+        one.fill_(-1.0)
+        assert plan.displace_deposit(dcat, npart, ptrs, d_mass.data_ptr() if masses else 0, n_grid, d_edges.data_ptr(), one.data_ptr()) == pairs
+        torch.cuda.synchronize()
+        if masses:           # (the sums inside a cell run in another order)
+            assert np.abs(one.cpu().numpy() - two.cpu().numpy()).max() <= 1e-12 * two.max().item()
+        else:
+            assert torch.equal(one, two)
+    plan.close()
+    cat = {'M': M, 'x': hpos[:, 0], 'y': hpos[:, 1], 'z': hpos[:, 2]}
+    tab = O.Table([np.log(1 + z), np.log(Mt), np.log(r)], d, False, 8.0)
+    ora = G.baryonify_snapshot([part[:, k] for k in range(ndim)], L, cat, zr, tab, 5.0, G.grid_background(cos))
+    ref = np.histogramdd(np.stack(ora, axis=1), bins=[edges] * ndim, weights=mass)[0].ravel()
+    got = one.cpu().numpy()
+    assert np.isclose(got.sum(), ref.sum(), rtol=1e-12) and np.abs(got - ref).sum() <= 8.0          # (at most four particles in a neighbouring cell)
+    if not masses:
+        assert np.count_nonzero(got != ref) <= 8
+    assert np.abs(got - np.histogramdd(part[:, :ndim], bins=[edges] * ndim, weights=mass)[0].ravel()).sum() > 100      # (particles did move)
+
+
+@pytest.mark.parametrize('name,n_grid', [('snap3d_baryonify', 32), ('snap3d_baryonify', 50), ('snap2d_baryonify', 128)])
+def test_process_make_map_equals_process_then_make_map(gpu, name, n_grid):
+    """BaryonifySnapshot.process_make_map(N) (bfgx_baryonify_snapshot_records_map: one upload, no displaced records) ==
+    ParticleSnapshot(cat=runner.process()).make_map(N) of the product == np.histogramdd of the REFERENCE's displaced particles
+    (tests/golden/snap*.npz) with the same weights (io.py:622-670)"""
+    import baryonification_amd as bfg
+    g = H.load_snapshot_golden(name)
+    rng = np.random.default_rng(5)
+    runner = H.snapshot_product_runner(g)
+    runner.ParticleSnapshot.cat['M'] = rng.uniform(0.5, 2.0, runner.ParticleSnapshot.cat.size)
+    mass = np.array(runner.ParticleSnapshot.cat['M'])
+    ndim = g['ndim']
+    fused = runner.process_make_map(n_grid)
+    assert fused.shape == (n_grid,) * ndim and fused.dtype == np.float64 and runner.last_stats['n_pairs'] >= g['moved_idx'].size
+    snap = runner.ParticleSnapshot
+    two = bfg.utils.ParticleSnapshot(x=np.zeros(1), y=np.zeros(1), z=None if ndim == 2 else np.zeros(1), M=np.ones(1), L=g['L'], redshift=g['redshift'],
+                                     cosmo=g['cosmo_runner'])
+    two.cat = runner.process()
+    two_map = two.make_map(n_grid)
+    assert np.abs(fused - two_map).max() <= 1e-12 * two_map.max()
+    edges = np.linspace(0, g['L'], n_grid + 1)
+    exp = g['expected']
+    ok = ~np.isnan(exp).any(axis=1)                                # (a particle exactly on a halo: NaN in the reference, dropped by histogramdd's edges)
+    ref = np.histogramdd(exp[ok], bins=[edges] * ndim, weights=mass[ok])[0]
+    assert np.abs(fused - ref).sum() <= 4 * 2.0 and np.isclose(fused.sum(), ref.sum(), rtol=1e-12)
+    assert snap.cat is runner.ParticleSnapshot.cat and np.array_equal(snap.cat['M'], mass)          # the input snapshot is untouched
+    # NaN masses: the reference's make_map asserts (io.py:636)
+    runner.ParticleSnapshot.cat['M'][3] = np.nan
+    with pytest.raises(AssertionError):
+        runner.process_make_map(n_grid)
