@@ -277,9 +277,9 @@ def _random_offsets(nside, scale_pix, seed):
     return d * mag[:, None]
 
 
-@pytest.mark.parametrize('nside,scale', [(128, 0.4), (128, 2.5), (128, 9.0), (128, 40.0), (64, 25.0), (512, 6.0), (512, 60.0)])
+@pytest.mark.parametrize('nside,scale', [(128, 0.4), (128, 2.5), (128, 9.0), (128, 40.0), (64, 25.0), (512, 6.0), (512, 60.0), (256, 200.0), (512, 200.0)])
 def test_regrid_any_displacement_vs_oracle(gpu, monkeypatch, nside, scale):
-    """K2 for displacements from a fraction of a pixel to tens of pixels (the gathering regrid sizes its aprons from the data;
+    """K2 for displacements from a fraction of a pixel to 200 pixels (the gathering regrid sizes its aprons from the data;
     what it does not gather goes through the far list, and through the in-stream repair pass when that list overflows:
     NSIDE 512 x 60 pixels lists ~8e6 deposits against a capacity forced down to 1e6 -- a plan's own list holds four deposits of every
     pixel): fp64 route against the oracle's get_interpol
@@ -296,8 +296,10 @@ def test_regrid_any_displacement_vs_oracle(gpu, monkeypatch, nside, scale):
     z, M, r = syn.table_grid(cat)
     model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r), syn.COSMO, 10.0, 10.0)
     dev = torch.device('cuda:0')
-    if scale >= 60:
+    if scale == 60:
         monkeypatch.setenv('BFGX_FAR_CAP', '1000000')
+    if scale > 60:                  # (a table that moves pixels this far gives its plan such a list; this plan's table moves nothing)
+        monkeypatch.setenv('BFGX_FAR_CAP', str(4 * npix))
     plan = engine.ShellPlan(model, keep, nside, 1000, device=0, stream=torch.cuda.current_stream().cuda_stream)
     d_map = torch.from_numpy(hmap).to(dev)
     for f64, tol in ((True, 1e-10), (False, 3e-5 * max(1.0, scale))):
@@ -312,8 +314,10 @@ def test_regrid_any_displacement_vs_oracle(gpu, monkeypatch, nside, scale):
         assert abs(sums[0].item() - hmap.sum()) <= 1e-9 * hmap.sum() and abs(sums[1].item() - sums[0].item()) <= 1e-9 * hmap.sum()
         assert abs(got.sum() - hmap.sum()) <= 1e-9 * hmap.sum()
         assert np.abs(got - ora).max() <= tol * np.abs(ora).max(), (f64, np.abs(got - ora).max() / np.abs(ora).max())
-        if scale >= 60:
+        if scale == 60:
             assert plan.regrid_stats()['far_overflowed']                          # (the repair pass was what ran)
+        if scale > 60:
+            assert not plan.regrid_stats()['far_overflowed']                      # (200 pixels: the plan's own list holds every deposit)
     plan.close()
 
 
