@@ -40,13 +40,16 @@ class DefaultRunner(object):
             raise NotImplementedError("You have set use_ellipticity = True, but this not yet implemented for HealpixRunner")
 
     def build_Rmat(self, A, ref):
-        A /= np.linalg.norm(A)
-        ref /= np.linalg.norm(ref)
-        ang = np.arccos(np.dot(A, ref))
-        return np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        """2 x 2 rotation by the angle between A and ref (HealpixRunner.py:170-197); both are normalised IN PLACE, as there."""
+        for v in (A, ref):
+            v /= np.linalg.norm(v)
+        angle = np.arccos(np.dot(A, ref))
+        c, s = np.cos(angle), np.sin(angle)
+        return np.array([[c, -s], [s, c]])
 
     def coord_array(self, *args):
-        return np.vstack([a.flatten() for a in args]).T
+        """(N, len(args)) array of the flattened arguments, one per column (HealpixRunner.py:200-218)"""
+        return np.stack([np.ravel(a) for a in args], axis=1)
 
     # -- shared plumbing -----------------------------------------------------------------------
     def _check_keys(self, keys):

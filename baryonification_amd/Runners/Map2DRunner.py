@@ -67,33 +67,34 @@ class DefaultRunnerGrid(object):
             assert 'A_ell' in names, "The 'A_ell' column is missing, but you set use_ellipticity = True"
 
     def build_Rmat(self, A, q):
-        """Shear matrix of a halo with orientation vector A and axis ratio q (Map2DRunner.py:283-337)."""
+        """Shear matrix of a halo with orientation vector A (normalised IN PLACE) and axis ratio q: the reduced shear g of galsim's
+        Shear(q, beta), |g| = tanh(eta / 2) with eta = -ln q, as [[1 + g1, g2], [g2, 1 - g1]] / sqrt(1 - |g|^2) (Map2DRunner.py:283-337).
+        The operations and their order are the reference's: the matrices enter the parity tests bit for bit."""
         A /= np.linalg.norm(A)
-        if len(A) == 1:
+        ndim = len(A)
+        if ndim == 1:
             raise ValueError("Can't rotate a 1-dimensional vector")
-        elif len(A) == 2:
-            ref = np.array([1., 0.])
-            beta = np.arccos(np.dot(A, ref))
-            eta = -np.log(q)
-            if eta > 1e-4:
-                eta2g = np.tanh(0.5 * eta) / eta
-            else:
-                etasq = eta * eta
-                eta2g = 0.5 + etasq * ((-1 / 24) + etasq * (1 / 240))
-            g = eta2g * eta * np.exp(2j * beta)
-            g1, g2 = g.real, g.imag
-            det = np.sqrt(1 - np.abs(g) ** 2)
-            return np.array([[1 + g1, g2], [g2, 1 - g1]]) / det
-        raise NotImplementedError("This method has not yet been verified. Use 2D ellipticity method instead")
+        if ndim != 2:
+            raise NotImplementedError("This method has not yet been verified. Use 2D ellipticity method instead")
+        beta = np.arccos(np.dot(A, np.array([1., 0.])))                 # position angle against the first axis
+        eta = -np.log(q)
+        if eta > 1e-4:
+            ratio = np.tanh(0.5 * eta) / eta                             # |g| / eta
+        else:                                                            # its series about eta = 0
+            e2 = eta * eta
+            ratio = 0.5 + e2 * ((-1 / 24) + e2 * (1 / 240))
+        g = ratio * eta * np.exp(2j * beta)
+        return np.array([[1 + g.real, g.imag], [g.imag, 1 - g.real]]) / np.sqrt(1 - np.abs(g) ** 2)
 
     def coord_array(self, *args):
-        return np.vstack([a.flatten() for a in args]).T
+        """(N, len(args)) array of the flattened arguments, one per column (Map2DRunner.py:340-358)"""
+        return np.stack([np.ravel(a) for a in args], axis=1)
 
     def pick_indices(self, center, width, Npix):
-        inds = np.arange(center - width, center + width)
-        inds = np.where((inds) < 0, inds + Npix, inds)
-        inds = np.where((inds) >= Npix, inds - Npix, inds)
-        return inds
+        """the 2 width indices around `center` on a periodic axis of Npix cells, wrapped once either way (Map2DRunner.py:361-391)"""
+        idx = np.arange(center - width, center + width)
+        idx = idx + Npix * (idx < 0)
+        return idx - Npix * (idx >= Npix)
 
     # -- shared plumbing -----------------------------------------------------------------------
     def _check_keys(self, keys):
