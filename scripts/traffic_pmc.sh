@@ -32,6 +32,9 @@ for f in glob.glob(out + '/*/**/*counter_collection.csv', recursive=True):
                 break
 fetch = {g: v / nsteps for g, v in tot['FETCH_SIZE'].items()}
 write = {g: v / nsteps for g, v in tot['WRITE_SIZE'].items()}
+if 'displace' in fetch and 'deposit' in fetch:          # the fused snapshot flow is timed (and keyed by bench.py) as one group
+    for d in (fetch, write, tot['SQ_INSTS_VALU']):
+        d['displace+deposit'] = d.get('displace', 0.0) + d.get('deposit', 0.0)
 bench = json.loads([l for l in open(out + '/FETCH_SIZE.json') if l.startswith('{')][0])
 print(json.dumps({
     "source": "rocprofv3 --pmc passes (one counter per pass) of `python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-events %s` "
