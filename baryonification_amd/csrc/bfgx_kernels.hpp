@@ -609,10 +609,11 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
                                               const double *__restrict__ lnz1, const double *__restrict__ lnM,
                                               int fallback4, const Tiling &T, const PrepOut &o, int *s_nslow, float *s_work);
 
+// workgroups of 256 per CU the kernel is compiled for (register budget 512 / this per lane).  Measured, config 2 on the S19 table (K0 in ms):
+// 3: 0.133, 4: 0.136, 5: 0.164, 6: 0.219, 8: 0.269 -- more waves only buy spills: the kernel is bound by the instructions it issues (2560 per
+// wave), not by the latency of its atomics
 #ifndef BFGX_K0_OCC
-#define BFGX_K0_OCC 4               // workgroups of 256 per CU the kernel is compiled for (register budget 512 / this per lane).  Measured, config 2 on the
-#endif                              // S19 table (K0 in ms): 3: 0.133, 4: 0.136, 5: 0.164, 6: 0.219, 8: 0.269 -- more waves only buy spills: the kernel is bound by the
-#if 0                               // instructions it issues (2560 per wave), not by the latency of its atomics
+#define BFGX_K0_OCC 4
 #endif
 template <int NC, typename real>
 __global__ void __launch_bounds__(256, BFGX_K0_OCC)
