@@ -24,7 +24,7 @@
 #define BFGX_ABLATE 0      // >0: timing-only ablation builds (scripts/ablate.sh); never shipped
 #endif
 #ifndef BFGX_ABL0
-#define BFGX_ABL0 0        // K0 ablations (timing only): 1 no record stores, 2 no tile binning, 3 neither, 4 geometry only
+#define BFGX_ABL0 0        // K0 ablations (timing only): 1 no record stores, 2 no tile binning, 3 neither, 16 no list stores, 32 no census of small discs
 #endif
 #include "bfgx_cosmo.hpp"
 #include "bfgx_math.hpp"
@@ -744,7 +744,7 @@ __device__ __forceinline__ void halo_prep_one(const DevModel &m, const Hpx &h, i
     // <4-pixel fallback (HealpixRunner.py:309-310): only discs of a few pixels can qualify -> exact census
     r.fb = 0; r._pad = 0;
     for (int q = 0; q < 4; ++q) { r.fb_ring[q] = 0; r.fb_k[q] = 0; }
-    if (fallback4 && !bad && (r.rlast - r.rfirst) < 8) {
+    if (fallback4 && !bad && (r.rlast - r.rfirst) < 8 && !(BFGX_ABL0 & 32)) {
         // (from the middle ring outwards -- mid, mid + 1, mid - 1, ... --: the longest rows come first, and a disc of 4 or more pixels is
         // recognised after two rows instead of three or four from the edge; the slowest lane of a wave sets the trip count)
         int total = 0;
