@@ -14,7 +14,7 @@ import numpy as np
 from .. import _lib
 from ..utils.cosmology import MassDef
 from ..utils.Tabulate import ParamTabulatedProfile
-from ._model import build_model
+from ._model import build_model, process_callable_exact, wants_exact
 
 __all__ = ['DefaultRunner', 'BaryonifyShell', 'PaintProfilesShell']
 
@@ -148,6 +148,8 @@ class BaryonifyShell(DefaultRunner):
     def process(self):
         keys = vars(self.model).get('p_keys', [])
         self._check_keys(keys)
+        if wants_exact(self, 'displacement'):        # a plain Python callable on a small catalog: called per halo, as the reference does (:321)
+            return process_callable_exact(self, 'displacement', self.LightconeShell.map)
         model, p_keys, keep = build_model(self, 'displacement')
         orig_map = _lib.f8(self.LightconeShell.map)
         nside = int(self.LightconeShell.NSIDE)
@@ -176,6 +178,8 @@ class PaintProfilesShell(DefaultRunner):
         keys = vars(self.model).get('p_keys', []) if self.model is not None else []
         self._check_keys(keys)
         assert self.model is not None, "You must provide a model"     # HealpixRunner.py:415
+        if wants_exact(self, 'projected'):           # (:441)
+            return process_callable_exact(self, 'projected')
         model, p_keys, keep = build_model(self, 'projected')
         nside = int(self.LightconeShell.NSIDE)
         new_map = _lib.pinned_empty(self.LightconeShell.map.size)

@@ -148,6 +148,80 @@ class _Proxy(object):
         return getattr(self._r, name)
 
 
+EXACT_MAX_HALOS = 50_000        # catalogs up to this size: a callable model is called per halo, as the reference does (model.bfgx_exact overrides)
+
+
+def plain_callable(model, kind):
+    """is `model` an object the reference would simply CALL -- a displacement(r, M, a) / projected(cosmo, r, M, a) method, no table of its
+    own (raw_input_*) and no way to build one (setup_interpolator)?"""
+    attr = 'raw_input_d' if kind == 'displacement' else ('raw_input_2D' if kind == 'projected' else 'raw_input_3D')
+    return (model is not None and not hasattr(model, attr) and not hasattr(model, 'setup_interpolator')
+            and callable(getattr(model, kind, None)))
+
+
+def wants_exact(runner, kind):
+    """the per-halo route for a plain callable: model.bfgx_exact = True / False, default by the size of the catalog (the route makes one
+    Python call per halo, as the reference's loop does: HealpixRunner.py:321, :441)"""
+    if not plain_callable(runner.model, kind):
+        return False
+    flag = getattr(runner.model, 'bfgx_exact', None)
+    return runner.HaloLightConeCatalog.cat.size <= EXACT_MAX_HALOS if flag is None else bool(flag)
+
+
+def process_callable_exact(runner, kind, orig_map=None):
+    """BaryonifyShell / PaintProfilesShell .process() for a model that is a plain Python callable, evaluated exactly as the reference does:
+    once per halo, on the separations r_sep / a_j of that halo's own pixels (HealpixRunner.py:314-331, :436-445).  The device finds the discs
+    and the separations (bfgx_shell_pairs_begin / _radii), this loop calls the model, the device turns the values into pixel offsets and
+    regrids / adds the painted values (bfgx_shell_pairs_apply).  No table, hence no interpolation error: the result equals the reference's to
+    the rounding of the geometry (1e-10)."""
+    import ctypes as C
+    from ..utils.cosmology import Cosmology
+    model = runner.model
+    cat = runner.HaloLightConeCatalog.cat
+    paint = kind != 'displacement'
+    # the runner's side of the geometry only (cosmology, mass definition, epsilon_max); the table is a placeholder nobody reads
+    table, keep = _lib.make_table([np.array([0.0, 1.0])] * 3, np.zeros((2, 2, 2)), False, False, 0.0)
+    m = _lib.bfgx_model()
+    m.table = table
+    m.cosmo_runner = m.cosmo_model = _lib.make_cosmo(cosmo_to_dict(runner.cosmo))
+    D, rho = massdef_to_tuple(runner.mass_def)
+    m.massdef_runner = m.massdef_model = _lib.make_massdef(D, rho)
+    m.eps_runner = float(runner.epsilon_max)
+    cols = [_lib.f8(cat[k]) for k in ('M', 'z', 'ra', 'dec')]
+    c, ckeep = _lib.make_catalog_host(cols[0], cols[1], cols[2], cols[3], [])
+    nside = int(runner.LightconeShell.NSIDE)
+    lib = _lib.load()
+    h = C.c_void_p()
+    counts = np.zeros(max(cat.size, 1), dtype=np.int64)
+    _lib.check(lib.bfgx_shell_pairs_begin(C.byref(c), C.byref(m), nside, int(paint), int(runner.device), C.byref(h), counts.ctypes.data))
+    try:
+        off = np.concatenate([[0], np.cumsum(counts[:cat.size])]).astype(np.int64)
+        r = np.empty(max(int(off[-1]), 1))
+        _lib.check(lib.bfgx_shell_pairs_radii(h, r.ctypes.data))
+        vals = np.zeros_like(r)
+        cosmo = getattr(model, 'cosmo', None) or runner.cosmo
+        cosmo_obj = cosmo if isinstance(cosmo, Cosmology) else Cosmology.from_dict(cosmo_to_dict(cosmo))
+        M, z = cols[0], cols[1]
+        with np.errstate(all='ignore'):
+            for j in range(cat.size):
+                sl = slice(int(off[j]), int(off[j + 1]))
+                a_j = 1.0 / (1.0 + z[j])                                                      # HealpixRunner.py:295
+                if paint:
+                    vals[sl] = np.asarray(model.projected(cosmo_obj, r[sl], M[j], a_j), dtype=np.float64).reshape(-1)     # :441
+                else:
+                    vals[sl] = np.asarray(model.displacement(r[sl], M[j], a_j), dtype=np.float64).reshape(-1)              # :321
+        npix = 12 * nside * nside
+        new_map = _lib.pinned_empty(npix)
+        stats = _lib.bfgx_stats()
+        src = None if paint else _lib.f8(orig_map)
+        _lib.check(lib.bfgx_shell_pairs_apply(h, vals.ctypes.data, None if paint else src.ctypes.data, new_map.ctypes.data, 1, C.byref(stats)))
+    finally:
+        lib.bfgx_shell_pairs_end(h)
+    runner.last_stats = {k: getattr(stats, k) for k, _ in stats._fields_}
+    del keep, ckeep
+    return new_map
+
+
 def build_model(runner, kind, runner_cosmo=None):
     """kind = 'displacement' (BaryonifyShell / BaryonifyGrid), 'projected' (PaintProfilesShell, PaintProfilesGrid on
     2D maps) or 'real' (PaintProfilesGrid on 3D maps).  `runner_cosmo` overrides the runner-side cosmology dict (the

@@ -180,6 +180,10 @@ SYMBOLS = {
     'bfgx_snapshot_plan_destroy': (None, [C.c_void_p]),
     'bfgx_snapshot_displace_device': (C.c_int, [C.c_void_p, _P(bfgx_grid_catalog), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, _P(C.c_int64)]),
+    'bfgx_shell_pairs_begin': (C.c_int, [_P(bfgx_catalog), _P(bfgx_model), C.c_int64, C.c_int32, C.c_int32, _P(C.c_void_p), C.c_void_p]),
+    'bfgx_shell_pairs_radii': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'bfgx_shell_pairs_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, _P(bfgx_stats)]),
+    'bfgx_shell_pairs_end': (None, [C.c_void_p]),
     'bfgx_baryonify_snapshot_records_map': (C.c_int, [_P(bfgx_grid_catalog), _P(bfgx_model), C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_void_p,
                                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                                       _P(bfgx_opts), _P(bfgx_stats)]),

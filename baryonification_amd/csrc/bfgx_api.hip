@@ -2393,3 +2393,6 @@ int bfgx_pressure_profile(int device, int64_t nrows, const double *r500, const d
 
 // ------------------------------------------------------------------------------ particle snapshots (8f-2)
 #include "bfgx_snapshot_api.inc"
+
+// ------------------------------------------------------------------------------ models that are Python callables
+#include "bfgx_callable_api.inc"

@@ -1552,6 +1552,89 @@ halo_scatter_kernel(PairTable pt, Hpx h, int64_t nhalo, const HaloRec *__restric
     if (counts && lane == 0) counts[j] = npairs;
 }
 
+// ---------------------------------------------------------------------------------- models that are Python callables
+// The reference calls model.displacement(r_sep / a, M, a) / model.projected(cosmo, r_sep / a, M, a) ONCE PER HALO on any object, with the
+// separations of that halo's own pixels (HealpixRunner.py:314-321, :436-441).  A model that carries no table can be served exactly that way:
+// WHAT 0 writes r_sep / a of every (halo, pixel) pair -- halo j's pairs at off[j] .., in the order of halo_scatter_kernel's enumeration --,
+// the host calls the model per halo on its slice, and WHAT 1 / 2 add what it returned:
+//   WHAT 1 (BaryonifyShell):      offset = value * a * diff / r_sep, non-finite components -> 0 (:321-323), new unit vector - old (:326-328)
+//   WHAT 2 (PaintProfilesShell):  Paint = value, non-finite -> 0 (:441-442)
+// No table, no model-side cut (the callable makes its own, BaryonCorrection.py:381-382).  Global fp64 atomics: the per-halo Python calls
+// around this kernel take seconds, the kernel microseconds.
+template <int WHAT>
+__global__ void __launch_bounds__(kWave * kWavesPerBlock)
+halo_pairs_kernel(Hpx h, int64_t nhalo, const HaloRec *__restrict__ recs, const int64_t *__restrict__ off, const double *__restrict__ vals,
+                  double *__restrict__ r_out, double *__restrict__ out)
+{
+    __shared__ RowLds lds[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int64_t j = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+    if (j >= nhalo) return;
+    RowLds &L = lds[wid];
+    const HaloRec &r = recs[j];
+    const int64_t base = off[j];
+    // one pair: pixel (start + k) of a ring with (z, sth); q = its index in the pair arrays
+    auto pair = [&](int64_t q, int64_t pix, double z, double sth, double phi_pix) {
+        double sd, cd;
+        sincos_dphi(phi_pix - r.phi0, sd, cd);
+        const double vx = sth * cd, vy = sth * sd, vz = z;                              // (frame rotated by -phi0: the halo at (s0, 0, z0))
+        const double dx = r.D * (vx - r.s0), dy = r.D * vy, dz = r.D * (vz - r.z0);   // :314-316
+        const double r_sep = sqrt(dx * dx + dy * dy + dz * dz);                         // :317
+        if (WHAT == 0) { r_out[q] = r_sep * r.inv_a; return; }                          // :321 r_sep / a_j
+        const double val = vals[q];
+        if (WHAT == 2) {
+            if (isfinite(val) && val != 0.0) atomic_accumulate(out + pix, val);         // :441-445
+            return;
+        }
+        const double d = val * r.a;                                                     // :321
+        double ox = d * (dx / r_sep), oy = d * (dy / r_sep), oz = d * (dz / r_sep);     // :322
+        ox = isfinite(ox) ? ox : 0.0; oy = isfinite(oy) ? oy : 0.0; oz = isfinite(oz) ? oz : 0.0;   // :323, element by element
+        if (ox == 0.0 && oy == 0.0 && oz == 0.0) return;
+        const double nx = __builtin_fma(r.D, vx, ox), ny = __builtin_fma(r.D, vy, oy), nz = __builtin_fma(r.D, vz, oz);   // :326
+        const double inv_n = 1.0 / sqrt(nx * nx + ny * ny + nz * nz);                   // :327
+        const double ex = __builtin_fma(nx, inv_n, -vx), ey = __builtin_fma(ny, inv_n, -vy), ez = __builtin_fma(nz, inv_n, -vz);   // :328
+        double *o = out + 3 * pix;
+        atomic_accumulate(o, ex * r.cph0 - ey * r.sph0);                                // rotate back by +phi0
+        atomic_accumulate(o + 1, ex * r.sph0 + ey * r.cph0);
+        atomic_accumulate(o + 2, ez);
+    };
+    if (r.fb) {                                                                         // HealpixRunner.py:309-310
+        if (lane < 4) {
+            int64_t st, nr; bool sh; double z, sth;
+            ring_info_small(h, r.fb_ring[lane], st, nr, sh);
+            ring_z_sth(h, r.fb_ring[lane], z, sth);
+            pair(base + lane, st + r.fb_k[lane], z, sth, ((double)r.fb_k[lane] + (sh ? 0.5 : 0.0)) * (kTwoPi / (double)nr));
+        }
+        return;
+    }
+    int64_t done = 0;
+    for (int rbase = r.rfirst; rbase <= r.rlast; rbase += kWave) {
+        const int ring = rbase + lane;
+        RowSpan s;
+        s.cnt = 0; s.lo = 0; s.start = 0; s.nr = 1; s.shifted = false; s.z = 0.0; s.sth = 0.0;
+        if (ring <= r.rlast) disc_row(h, ring, r.z0, r.xa, r.cosr, r.phi0, r.irmin, r.irmax, s);
+        const int incl = wave_scan_incl(s.cnt, lane);
+        const int total = __shfl(incl, kWave - 1, kWave);
+        L.prefix[lane] = incl - s.cnt;
+        L.nr[lane] = (int)s.nr; L.lo[lane] = s.lo; L.start[lane] = s.start;
+        L.z[lane] = s.z; L.sth[lane] = s.sth; L.shift[lane] = s.shifted ? 0.5 : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < total; t += kWave) {
+            int row = 0;
+#pragma unroll
+            for (int st = kWave >> 1; st > 0; st >>= 1)
+                if (L.prefix[row + st] <= t) row += st;
+            const int nrr = L.nr[row];
+            int k = L.lo[row] + (t - L.prefix[row]);
+            if (k >= nrr) k -= nrr;
+            pair(base + done + t, L.start[row] + k, L.z[row], L.sth[row], ((double)k + L.shift[row]) * (kTwoPi / (double)nrr));
+        }
+        done += total;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------- K1 / K3, tiled
 // (algo 1, default) one workgroup per tile: accumulators live in LDS, entries (halos touching the tile) are
 // taken 16 at a time by each wave: lanes = entries -> lanes = ring rows (clipped to the tile) -> lanes = pairs.

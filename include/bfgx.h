@@ -548,6 +548,24 @@ int bfgx_baryonify_snapshot_device(int device, void *hip_stream, const bfgx_grid
                                    const bfgx_snapshot *snap_dev, double *x_out_dev, double *y_out_dev, double *z_out_dev,
                                    int64_t *n_pairs_host);
 
+/* ---- models that are Python callables --------------------------------------------------------------
+ * The reference calls model.displacement(r_sep / a_j, M_j, a_j) (HealpixRunner.py:321) / model.projected(cosmo, r_sep / a_j, M_j, a_j)
+ * (:441) once per halo on ANY object.  For a model that carries no table the binding serves it exactly so:
+ *   begin   the halos' discs on the device (`model` carries the runner's cosmology / mass definition / epsilon_max; its 3-axis table must be
+ *           valid and is ignored); counts_host[n] = pixels of every halo's disc (4 for BaryonifyShell's < 4-pixel fallback, :309-310)
+ *   radii   r_host[sum counts] = r_sep / a_j of every (halo, pixel) pair, halo j's at the exclusive prefix sum of the counts
+ *   (the caller evaluates its model per halo on that halo's slice of r_host)
+ *   apply   vals_host[sum counts] = what the model returned.  paint = 0: offset = value a diff / r_sep, non-finite components -> 0, accumulated
+ *           in the pixels' unit vectors (:321-331), then the regrid of map_in into map_out (:333-341) and the mass check (:344-346: BFGX_ERR_MASS);
+ *           paint = 1: map_out[pixel] += value, non-finite -> 0 (:441-445; map_in ignored).  fp64 throughout.
+ *   end     frees the handle (also after an error). */
+typedef struct bfgx_pairs bfgx_pairs;
+int  bfgx_shell_pairs_begin(const bfgx_catalog *cat_host, const bfgx_model *model, int64_t nside, int32_t paint, int32_t device, bfgx_pairs **out,
+                            int64_t *counts_host);
+int  bfgx_shell_pairs_radii(bfgx_pairs *h, double *r_host);
+int  bfgx_shell_pairs_apply(bfgx_pairs *h, const double *vals_host, const double *map_in, double *map_out, int32_t check_mass, bfgx_stats *stats);
+void bfgx_shell_pairs_end(bfgx_pairs *h);
+
 #ifdef __cplusplus
 }
 #endif

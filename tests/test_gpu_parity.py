@@ -316,10 +316,12 @@ def test_multi_device_c_entry_large_displacements(gpu, scale):
     assert np.abs(one - g['map_in']).max() > 0 and pix > 0
 
 
-def test_callable_models_are_tabulated_on_first_use(gpu):
+def test_callable_models_per_halo_and_tabulated(gpu):
     """HealpixRunner.py:321, :441 call model.displacement(r, M, a) / model.projected(cosmo, r, M, a) on ANY object.  A plain-Python model
-    (no raw_input_*, no setup_interpolator) goes through process(): it is tabulated once on the catalog's (z, M) support and the result
-    equals the oracle fed the same tabulation; objects with neither method are still refused"""
+    (no raw_input_*, no setup_interpolator) goes through process() in one of two ways: called once per halo on that halo's own pixel
+    separations -- the reference's loop, reproduced to 1e-10 (catalogs up to 50 000 halos, or model.bfgx_exact = True) --, or tabulated once
+    on the catalog's (z, M) support (larger catalogs, or model.bfgx_exact = False): then the result equals the oracle fed the same tabulation
+    and differs from the reference by the table's interpolation error; objects with neither method are still refused"""
     import baryonification_amd as bfg
     from baryonification_amd import synthetic as syn
     from baryonification_amd.Runners import _model as RM
@@ -352,6 +354,7 @@ def test_callable_models_are_tabulated_on_first_use(gpu):
     hmap = syn.make_map(nside, seed=5)
     Shell = bfg.utils.LightconeShell(map=hmap, cosmo=syn.COSMO)
     model = PlainDisplacement()
+    model.bfgx_exact = False                                                    # the tabulated bridge (the default above 50 000 halos)
     runner = bfg.Runners.BaryonifyShell(Catalog, Shell, eps, model, verbose=False)
     runner.acc_f64 = True
     out = runner.process()
@@ -390,6 +393,18 @@ def test_callable_models_are_tabulated_on_first_use(gpu):
     err = np.abs(out - direct_map).max() / np.abs(direct_map - hmap).max()
     print("callable bridge vs per-halo calls: %.2e of the largest change of the map" % err)
     assert err < 5e-3
+    # the EXACT route (the default for a catalog of this size; model.bfgx_exact = True for any): the model is called once per halo on the
+    # separations of that halo's own pixels, as the reference does -- no table, no interpolation error
+    del model.bfgx_exact
+    PlainDisplacement.calls = 0
+    out_exact = runner.process()
+    assert PlainDisplacement.calls == N and np.isclose(out_exact.sum(), hmap.sum())
+    err_exact = np.abs(out_exact - direct_map).max() / np.abs(direct_map - hmap).max()
+    print("per-halo route vs the reference's loop: %.2e of the largest change of the map" % err_exact)
+    assert err_exact <= 1e-8 and np.abs(out_exact - direct_map).max() <= 1e-10 * np.abs(direct_map).max()       # (3e-10 of the change measured)
+    assert runner.last_stats['n_pairs'] > 4 * N
+    model.bfgx_exact = False
+    PlainDisplacement.calls = n_calls
     # a finer table on request, and a changed parameter is seen (the cached table is keyed by the model's attributes)
     model.bfgx_table_grid = (12, 40, 1000)
     with pytest.warns(RuntimeWarning, match="tabulated once on 12 x 40 x 1000"):
@@ -405,6 +420,20 @@ def test_callable_models_are_tabulated_on_first_use(gpu):
     pshell = bfg.utils.LightconeShell(map=np.zeros(12 * nside * nside), cosmo=syn.COSMO)
     pr = bfg.Runners.PaintProfilesShell(Catalog, pshell, eps, prof, verbose=False)
     pr.acc_f64 = True
+    # exact route first (default at this size): the reference's loop (HealpixRunner.py:417-445) restated with the oracle's primitives
+    painted_exact = pr.process()
+    ref_paint = np.zeros(12 * nside * nside)
+    for j in range(N):
+        M_j, z_j = used['M'][j], used['z'][j]
+        a_j = 1 / (1 + z_j)
+        R_j, D_j = bg.get_radius(np.atleast_1d(M_j), a_j)[0], float(Da(z_j))
+        vec_j = O.ang2vec_lonlat(used['ra'][j], used['dec'][j]).reshape(3)
+        pix = O.query_disc(nside, vec_j, R_j * eps / D_j)
+        r_sep = np.sqrt((((O.pix2vec(nside, pix) - vec_j) * D_j) ** 2).sum(axis=1))
+        P = prof.projected(cosmo, r_sep / a_j, M_j, a_j)
+        ref_paint[pix] += np.where(np.isfinite(P), P, 0)
+    assert ref_paint.max() > 0 and np.abs(painted_exact - ref_paint).max() <= 1e-10 * ref_paint.max()
+    prof.bfgx_exact = False
     painted = pr.process()
     hp_ = prof._bfgx_tabulated[1]
     with np.errstate(divide='ignore'):
