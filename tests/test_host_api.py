@@ -453,3 +453,39 @@ def test_round4_fault_sequence_small_arrays_are_never_page_locked_in_place(gpu, 
     pinned2, _, smallest2 = spans()
     assert pinned2 == pinned0
     assert smallest2 < 0 or smallest2 >= (32 << 20)                # whatever this process page-locked in place before owned its pages
+
+
+def test_which_route_a_callable_model_takes():
+    """Runners/_model.py: a plain Python callable (no table, no setup_interpolator) is called per halo -- the reference's loop,
+    HealpixRunner.py:321, :441 -- on catalogs of up to EXACT_MAX_HALOS halos or when model.bfgx_exact is set; table classes never are"""
+    import baryonification_amd as bfg
+    from baryonification_amd import synthetic as syn
+    from baryonification_amd.Runners import _model as RM
+
+    class Plain(object):
+        def displacement(self, r, M, a):
+            return 0 * r
+
+        def projected(self, cosmo, r, M, a):
+            return 0 * r
+
+    cat = syn.make_catalog(50)
+    Catalog = bfg.utils.HaloLightConeCatalog(ra=cat['ra'], dec=cat['dec'], M=cat['M'], z=cat['z'], cosmo=syn.COSMO)
+    Shell = bfg.utils.LightconeShell(map=np.ones(12 * 16 * 16), cosmo=syn.COSMO)
+    m = Plain()
+    r = bfg.Runners.BaryonifyShell(Catalog, Shell, 5.0, m, verbose=False)
+    assert RM.plain_callable(m, 'displacement') and RM.plain_callable(m, 'projected') and not RM.plain_callable(m, 'real')
+    assert RM.wants_exact(r, 'displacement') and RM.wants_exact(r, 'projected')
+    m.bfgx_exact = False
+    assert not RM.wants_exact(r, 'displacement')
+    m.bfgx_exact = True
+    old = RM.EXACT_MAX_HALOS
+    try:
+        RM.EXACT_MAX_HALOS = 10
+        assert RM.wants_exact(r, 'displacement')                       # asked for: whatever the size
+        del m.bfgx_exact
+        assert not RM.wants_exact(r, 'displacement')                   # by size: 50 halos > 10
+    finally:
+        RM.EXACT_MAX_HALOS = old
+    tab = bfg.Profiles.Baryonification2D(None, None, bfg.utils.Cosmology.from_dict(syn.COSMO))
+    assert not RM.plain_callable(tab, 'displacement') and not RM.plain_callable(None, 'projected') and not RM.plain_callable(object(), 'displacement')
