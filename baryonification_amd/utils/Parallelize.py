@@ -51,7 +51,7 @@ import os
 import numpy as np
 
 __all__ = ['SplitJoinParallel', 'SimpleParallel', 'shard_slices', 'distributed_process', 'band_partition', 'sliced_reduce',
-           'halo_exchange', 'gather_slices', 'route_halos', 'route_halos_fixed', 'route_step_fixed', 'band_ring_bounds']
+           'halo_exchange', 'gather_slices', 'gather_slices_start', 'route_halos', 'route_halos_fixed', 'route_step_fixed', 'band_ring_bounds']
 
 
 def shard_slices(n, world):
@@ -404,6 +404,33 @@ def gather_slices(mine, pb, npix, result='root', recv=None, out=None, root_in_pl
     if rank != 0:
         return None
     return recv
+
+
+class _Done(object):
+    """the handle of a collective that has already completed (gloo rehearsal: staged through the host, synchronous)"""
+
+    def wait(self):
+        return True
+
+
+def gather_slices_start(mine, pb, npix, out=None, group=None):
+    """gather_slices(..., result='root', root_in_place=True) as an ASYNCHRONOUS collective on `group` (a process group of its own: RCCL runs it
+    on that communicator's stream, so the caller's stream goes on with the NEXT pass while the slices travel to rank 0 -- at 2 / 4 / 8 GPUs
+    a rank's 50 / 25 / 12.6 MB of map cross ONE xGMI link each, 1.0 / 0.5 / 0.26 ms against 0.6 / 0.3 / 0.15 ms of kernels).  Rank 0 has written its
+    own slice into `out` already.  Returns a handle: .wait() before `mine` / `out` are written again."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lens = [int(pb[j + 1] - pb[j]) for j in range(world)]
+    ins = [0] * world if rank == 0 else [lens[rank]] + [0] * (world - 1)
+    outs = [0] + lens[1:] if rank == 0 else [0] * world
+    recv = out[int(pb[1]):] if rank == 0 else mine.new_empty(0)
+    send = mine.new_empty(0) if rank == 0 else mine
+    if mine.is_cuda and dist.get_backend(group) == 'gloo':          # rehearsal: through the host, done when this returns
+        r = send.new_empty(recv.numel(), device='cpu')
+        dist.all_to_all_single(r, send.cpu(), output_split_sizes=outs, input_split_sizes=ins, group=group)
+        recv.copy_(r)
+        return _Done()
+    return dist.all_to_all_single(recv, send, output_split_sizes=outs, input_split_sizes=ins, group=group, async_op=True)
 
 
 def _hip_bounds(runner, plan, world):

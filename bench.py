@@ -615,8 +615,8 @@ def shell_line(args, ctx, scaling, brief):
     route_far = [False]                # set (on every rank) when the untimed trial step finds such deposits
     spatial = (world > 1 or force_x) and args.exchange == 'spatial' and args.algo == 1
     if slices or spatial:
-        from baryonification_amd.utils.Parallelize import (_hip_reach, band_partition, band_ring_bounds, gather_slices, halo_exchange,
-                                                           route_halos, route_halos_fixed, route_step_fixed, sliced_reduce)
+        from baryonification_amd.utils.Parallelize import (_hip_reach, band_partition, band_ring_bounds, gather_slices, gather_slices_start,
+                                                           halo_exchange, route_halos, route_halos_fixed, route_step_fixed, sliced_reduce)
         first = plan.bands()
         cuts = band_partition(first, world)
         pb = first[cuts]
@@ -659,6 +659,16 @@ def shell_line(args, ctx, scaling, brief):
         route_work = {}
         sp_state = {'fixed': True, 'reach_known': False, 'nd': None, 'cd': None}
         stage_t = {}
+        # The slices of pass i travel to rank 0 WHILE pass i + 1 computes: the gather runs on a process group of its own (its own RCCL
+        # communicator and stream) out of one of two slice buffers into one of two final maps; a buffer is written again only after the
+        # gather that read it has been waited for, and fence() waits for what is still in flight, so the timed region ends with every map
+        # assembled.  (BFGX_BENCH_OVERLAP_GATHER=0: the gather inside the step, on the step's own communicator, as in rounds 3 - 4.)
+        # (a single forced rank has nothing to overlap with and pays ~12 us for the second communicator: off unless asked for with =1)
+        ov_env = os.environ.get('BFGX_BENCH_OVERLAP_GATHER')
+        ov = {'on': (ov_env == '1' or (ov_env != '0' and world > 1)) and not paint, 'k': 0, 'last': 0, 'pending': [None, None],
+              'slice': [d_slice, torch.zeros_like(d_slice)], 'fin': [d_fin, torch.zeros_like(d_fin)], 'group': None}
+        if ov['on'] and dist.is_initialized():
+            ov['group'] = dist.new_group(backend=backend)
 
         def mark(name):
             """BFGX_BENCH_STAGE_TIMES=1: one extra, untimed step with a synchronisation after every stage (rank 0 prints the stage times)"""
@@ -731,11 +741,24 @@ def shell_line(args, ctx, scaling, brief):
                 if not route_far[0]:
                     # rank 0's pixels are regridded straight into the final map (they never enter the gather), K0 .. K2 + far deposits + sums in
                     # ONE enqueue-only call (bfgx_offsets_regrid_bands_device)
-                    out_ptr = d_fin[p0:p1].data_ptr() if rank == 0 else d_slice.data_ptr()
+                    k = ov['k'] if ov['on'] else 0
+                    if ov['pending'][k] is not None:          # the gather that read this pair of buffers two passes ago
+                        ov['pending'][k].wait()
+                        ov['pending'][k] = None
+                    fin_k, slice_k = ov['fin'][k], ov['slice'][k]
+                    out_ptr = fin_k[p0:p1].data_ptr() if rank == 0 else slice_k.data_ptr()
                     plan_sp.offsets_regrid_bands(cd, B0, B1, sp_state['full'].data_ptr(), b0, b1, d_map.data_ptr(), out_ptr, d_sums.data_ptr(),
                                                  d_foreign.data_ptr(), acc_f64=acc_f64)
                     mark('K0+K1+K2')
-                    gather_slices(d_slice, pb, npix, 'root', out=d_fin if rank == 0 else None, root_in_place=True)
+                    if ov['on'] and dist.is_initialized():
+                        ov['pending'][k] = gather_slices_start(slice_k, pb, npix, out=fin_k if rank == 0 else None, group=ov['group'])
+                        if sp_state.get('staging'):
+                            ov['pending'][k].wait()
+                            ov['pending'][k] = None
+                        ov['k'], ov['last'] = k ^ 1, k
+                    else:
+                        gather_slices(slice_k, pb, npix, 'root', out=fin_k if rank == 0 else None, root_in_place=True)
+                        ov['last'] = k
                     mark('gather')
                     return
                 plan_sp.offsets_bands(cd, B0, B1, sp_state['full'].data_ptr(), acc_f64=acc_f64)
@@ -856,6 +879,11 @@ def shell_line(args, ctx, scaling, brief):
         return step
 
     def fence():
+        if spatial:
+            for q in (0, 1):                       # gathers still in flight belong to the passes before this fence
+                if ov['pending'][q] is not None:
+                    ov['pending'][q].wait()
+                    ov['pending'][q] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -978,7 +1006,7 @@ def shell_line(args, ctx, scaling, brief):
             pf.baryonify(cdf, d_map.data_ptr(), woff.data_ptr(), ref.data_ptr(), 0, acc_f64=acc_res)
         torch.cuda.synchronize()
         pf.status()
-        got = d_fin if (slices or spatial) else d_out
+        got = (ov['fin'][ov['last']] if spatial else d_fin) if (slices or spatial) else d_out
         scale = float(ref.abs().max().item()) if paint else float(ref.mean().item())
         diff = float((got - ref).abs().max().item())
         check = {"max_abs_diff_vs_single_gpu": diff, "scale": scale, "scale_is": "max |map|" if paint else "mean(map)",
@@ -1107,7 +1135,9 @@ def shell_line(args, ctx, scaling, brief):
                                         "memset (every control word of the binning and the regrid)", "halo_prep_kernel (blocked catalog: no transpose)",
                                         "tile_scan_kernel", "tile_place_kernel", "tile_scatter2f_kernel", "tile_apron_kernel", "tile_regrid3_kernel",
                                         "regrid_far_local_kernel (far deposits + the two sums)",
-                                        "all_to_all_single (map slices -> rank 0; rank 0 regrids its own slice in place)"]
+                                        "all_to_all_single (map slices -> rank 0; rank 0 regrids its own slice in place)" +
+                                        (" -- asynchronous, on a communicator of its own: it overlaps the next pass" if ov['on'] else "")]
+                out["gather_overlapped"] = bool(ov['on'])
         if kt is not None:
             kernels = {k: (ms / n if n else None) for k, (ms, n) in kt.items() if n}
             out["ms_per_step_with_kernel_events"] = elapsed_ev / args.steps * 1e3

@@ -109,3 +109,19 @@ def test_two_ranks_self_launched_strong_and_weak(gpu):
     assert out2.returncode == 0, out2.stderr[-3000:]
     d2 = json.loads([l for l in out2.stdout.strip().splitlines() if l.startswith('{')][0])
     assert 'check' not in d2 and d2['world_size_seen'] == 2
+
+
+def test_forced_single_rank_exchange_over_rccl_with_the_overlapped_gather(gpu):
+    """BFGX_FORCE_EXCHANGE=1: the N > 1 code of the shell path with ONE RCCL rank (the only RCCL run a one-GPU box allows), here with the
+    asynchronous gather on its own communicator forced on (BFGX_BENCH_OVERLAP_GATHER=1: the default for N > 1): two slice buffers, two final
+    maps, waits before a buffer is reused and at the fence -- and the assembled map still equals a single-GPU pass"""
+    env = dict(os.environ, BFGX_FORCE_EXCHANGE='1', BFGX_BENCH_OVERLAP_GATHER='1', BFGX_BENCH_CHECK='1')
+    env.pop('BFGX_DIST_BACKEND', None)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--halos', '30000', '--nside', '256', '--steps', '7', '--warmup', '2',
+                          '--no-extras', '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith('{')][0])
+    assert d['backend'] == 'nccl' and d['world_size_seen'] == 1 and d['gather_overlapped'] is True and d['mass_conserved'] is True
+    assert d['check']['ok'] is True and 'asynchronous' in d['step_launches'][-1]
