@@ -1199,8 +1199,11 @@ int bfgx_offsets_device(bfgx_plan *p, const bfgx_catalog *cat, void *offsets_dev
 }
 
 // K0 + K1 / K3 for the tiles of bands [band0, band1) only: out_slice_dev points at the first pixel of band0
-static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *out_slice_dev, int acc_f64, bool paint)
+static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, int32_t band1, void *out_slice_dev, int acc_f64, bool paint,
+                         float *lo_slice_dev = nullptr)
 {
+    // lo_slice_dev (displacements only): the parity-grade mode -- out_slice_dev takes the fp32 high halves of pix_offsets, lo_slice_dev the low halves of the
+    // same pixels (a caller that keeps both on ONE device: nothing of them crosses a link)
     if (int rc = check_catalog(p, cat)) return rc;
     if (p->algo != 1) return fail(BFGX_ERR_UNSUPPORTED, "band-restricted passes need the tiled algorithm (algo 1)");
     if (band0 < 0 || band1 > p->tiling.nbands || band0 > band1) return fail(BFGX_ERR_INVALID, "band range out of bounds");
@@ -1214,13 +1217,14 @@ static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, i
     p->k1_tile_lo = p->band_tile0_host[band0];
     p->k1_tile_n = p->band_tile0_host[band1] - p->k1_tile_lo;
     struct Reset { bfgx_plan *p; ~Reset() { p->k1_tile_lo = 0; p->k1_tile_n = -1; } } reset{p};
-    if (!paint) {        // the banded entries keep one array of pix_offsets: the parity-grade mode is served by fp64 throughout there
+    const bool split = !paint && lo_slice_dev != nullptr && use_fast(p);
+    if (!paint) {        // ONE array of pix_offsets (what travels between ranks): the parity-grade mode is served by fp64 throughout there
         if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
-        acc_f64 = resolve_acc(p, acc_f64) != BFGX_ACC_F32 ? 1 : 0;
+        acc_f64 = split ? 0 : (resolve_acc(p, acc_f64) != BFGX_ACC_F32 ? 1 : 0);
     }
     if (acc_f64 < 0 || acc_f64 > (paint ? 2 : 1)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
     const bool mixed = paint && acc_f64 == 2 && use_fast(p);
-    if (int rc = launch_prep_and_bin(p, cat, paint ? 0 : 1, acc_f64 != 0 && !mixed)) return rc;
+    if (int rc = launch_prep_and_bin(p, cat, paint ? 0 : 1, (acc_f64 != 0 && !mixed) || split)) return rc;
     if (p->blocking_growth) if (int rc = ensure_entry_capacity(p, cat)) return rc;
     p->paint_pair_f32 = mixed;
     struct ResetP { bfgx_plan *p; ~ResetP() { p->paint_pair_f32 = false; } } resetp{p};
@@ -1233,6 +1237,11 @@ static int bands_scatter(bfgx_plan *p, const bfgx_catalog *cat, int32_t band0, i
     // regrid then needs no second pass over the slice)
     p->omax_from_k1 = true;
     struct ResetO { bfgx_plan *p; ~ResetO() { p->omax_from_k1 = false; } } reseto{p};
+    if (split) {         // fp64 pair records + the parity-grade pair functions, high and low halves stored (launch_tile_scatter)
+        p->offsets_lo = lo_slice_dev - 3 * p0;
+        struct ResetL { bfgx_plan *p; ~ResetL() { p->offsets_lo = nullptr; } } resetl{p};
+        return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)out_slice_dev - 3 * p0);
+    }
     if (acc_f64) return launch_tile_scatter<MODE_OFFSETS, double>(p, (double *)out_slice_dev - 3 * p0);
     return launch_tile_scatter<MODE_OFFSETS, float>(p, (float *)out_slice_dev - 3 * p0);
 }
@@ -1258,13 +1267,17 @@ int bfgx_offsets_regrid_bands_device(bfgx_plan *p, const bfgx_catalog *cat, int3
 {
     if (!p || !cat) return fail(BFGX_ERR_INVALID, "NULL argument");
     if (B0 < 0 || B1 > p->tiling.nbands || B0 > b0 || b1 > B1 || b0 > b1) return fail(BFGX_ERR_INVALID, "band ranges must nest: [B0, B1) around [b0, b1)");
-    if (int rc = bands_scatter(p, cat, B0, B1, offsets_dev, acc_f64, false)) return rc;       // (its memset also zeroes the far list's counter)
+    if (!acc_valid(acc_f64)) return fail(BFGX_ERR_INVALID, "acc_f64 out of range");
+    const int64_t wlo = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * B0), whi = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * B1);
+    // the parity-grade mode: both halves of pix_offsets stay on this device (24 bytes per pixel, as fp64 would take): high halves
+    // [whi - wlo][3] fp32, then the low halves
+    float *lo = (resolve_acc(p, acc_f64) == BFGX_ACC_PARITY && use_fast(p) && offsets_dev) ? (float *)offsets_dev + 3 * (size_t)(whi - wlo) : nullptr;
+    if (int rc = bands_scatter(p, cat, B0, B1, offsets_dev, acc_f64, false, lo)) return rc;       // (its memset also zeroes the far list's counter)
     if (b0 == b1) {
         if (sums_dev) HIP_TRY(hipMemsetAsync(sums_dev, 0, 2 * sizeof(double), p->stream));
         return BFGX_OK;
     }
-    const int64_t wlo = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * B0), whi = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * B1);
-    if (int rc = regrid_bands_impl(p, b0, b1, map_in_dev, offsets_dev, wlo, whi, acc_f64, out_slice_dev, sums_dev, false, nullptr, true)) return rc;
+    if (int rc = regrid_bands_impl(p, b0, b1, map_in_dev, offsets_dev, wlo, whi, acc_f64, out_slice_dev, sums_dev, false, lo, true)) return rc;
     const int64_t p0 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * b0), p1 = ring_first_pixel(p->hpx, 1 + (int64_t)p->tiling.BR * b1);
     const int t0 = p->band_tile0_host[b0], t1 = p->band_tile0_host[b1];
     hipLaunchKernelGGL(regrid_far_local_kernel, dim3(64), dim3(256), 0, p->stream, p->far, out_slice_dev, p0, p1, foreign_dev, t1 - t0,

@@ -747,8 +747,10 @@ def shell_line(args, ctx, scaling, brief):
                         ov['pending'][k] = None
                     fin_k, slice_k = ov['fin'][k], ov['slice'][k]
                     out_ptr = fin_k[p0:p1].data_ptr() if rank == 0 else slice_k.data_ptr()
+                    # (nothing of pix_offsets leaves the device on this route: the parity-grade mode stays what it is on one GPU -- fp32 high
+                    # and low halves in the 24 bytes per pixel the fp64 buffer has)
                     plan_sp.offsets_regrid_bands(cd, B0, B1, sp_state['full'].data_ptr(), b0, b1, d_map.data_ptr(), out_ptr, d_sums.data_ptr(),
-                                                 d_foreign.data_ptr(), acc_f64=acc_f64)
+                                                 d_foreign.data_ptr(), acc_f64=(acc if (acc == _lib.ACC_PARITY and not paint) else acc_f64))
                     mark('K0+K1+K2')
                     if ov['on'] and dist.is_initialized():
                         ov['pending'][k] = gather_slices_start(slice_k, pb, npix, out=fin_k if rank == 0 else None, group=ov['group'])
@@ -1099,7 +1101,7 @@ def shell_line(args, ctx, scaling, brief):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": (("f64" if args.acc_f64 else "f64 ring-row geometry + f64 LDS accumulation + f64 map; f32 pair math (chord, ln r, read-out, exp)") if paint else
-                      DTYPES[1 if (acc_res != _lib.ACC_F32 and (world > 1 or slices or spatial)) else acc_res]),
+                      DTYPES[1 if (acc_res != _lib.ACC_F32 and (world > 1 or slices or spatial) and not (spatial and sp_state.get('local_apron') and not route_far[0])) else acc_res]),
             "data": "synthetic",
             "config": {"workload": "%s: %d-halo synthetic catalog %s (SURVEY 8d seeds), %s, "
                                    "NSIDE=%d shell, epsilon_max=%g, 10x10x500 %s %s table (edges = catalog min/max)" % (

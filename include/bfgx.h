@@ -261,8 +261,9 @@ int  bfgx_regrid_bands_device(bfgx_plan *p, int32_t band0, int32_t band1, const 
  * bfgx_plan_set_catalog_blocks(rows, stride): the catalogs of the following K0 launches are such blocks -- halo j's columns at
  * (j / rows) * stride + (j % rows) from the column pointers of block 0 (stride = ncols * blockcap); rows = 0: plain columns again.
  * bfgx_offsets_regrid_bands_device: K0 + binning + K1 for the bands [B0, B1) (the rank's own [b0, b1) and, with a route margin of one band, the
- * band either side: the aprons of its regrid, computed locally) into offsets_dev (pixels from the first pixel of band B0; f32 or f64 as
- * bfgx_offsets_bands_device resolves acc_f64), the banded regrid of [b0, b1) into out_slice_dev, the listed far deposits that fall into those
+ * band either side: the aprons of its regrid, computed locally) into offsets_dev (pixels from the first pixel of band B0: [pixels][3] f32 or f64;
+ * BFGX_ACC_PARITY -- or BFGX_ACC_AUTO on a table that asks for it -- keeps the parity-grade mode here, since nothing of pix_offsets leaves the
+ * device: [pixels][3] f32 high halves followed by [pixels][3] f32 low halves, 24 bytes per pixel like f64), the banded regrid of [b0, b1) into out_slice_dev, the listed far deposits that fall into those
  * pixels added (the others counted into *foreign_dev, which the caller zeroes once), the two sums of the mass check.  One memset, eight launches. */
 int  bfgx_route_step_device(bfgx_plan *p, const bfgx_catalog *cat_dev, int32_t world, int32_t rank, const int32_t *ring_bounds, int64_t blockcap,
                             int32_t ncols, const double *const *cols_dev, int32_t *cursor_dev, double *send_blocks_dev, double *recv_blocks_dev,

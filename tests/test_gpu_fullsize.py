@@ -951,3 +951,63 @@ def test_catalog_written_patch_by_patch_equals_shuffled(gpu):
     assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-13 * scale
     assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-6 * hmap.mean()
     plan.close()
+
+
+@pytest.mark.parametrize('scale', [1.0, 60.0])
+def test_fused_band_entry_keeps_the_parity_grade_mode(gpu, scale):
+    """bfgx_offsets_regrid_bands_device (a rank's share of a spatially sharded step: K0 .. K2 of its bands + the band either side) with
+    BFGX_ACC_PARITY: the split fp32 pix_offsets stay on the device, so the mode is what it is on one GPU -- the slices of three "ranks" put
+    together equal the full-map parity-grade call to 1e-9 mean(map) and the fp64 call to 1e-8"""
+    import torch
+    from baryonification_amd import _lib, engine, synthetic as syn
+    nside, nh = 256, 30_000
+    cat = syn.make_catalog(nh)
+    cat['dec'][:4] = [89.95, -89.9, 89.99, -89.999]
+    z, M, r = syn.table_grid(cat)
+    model, keep = engine.model_from_tables([np.log(1 + z), np.log(M), np.log(r)], syn.displacement_table(z, M, r) * scale, syn.COSMO, 10.0, 10.0)
+    dev = torch.device('cuda:0')
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = engine.ShellPlan(model, keep, nside, nh, device=0, stream=stream)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cat.items()}
+    lnz, lnM = _lib.table_coords(cat['M'], cat['z'])
+    t['lnz'], t['lnM'] = torch.from_numpy(lnz).to(dev), torch.from_numpy(lnM).to(dev)
+    cd = _lib.make_catalog_dev(nh, t['M'].data_ptr(), t['z'].data_ptr(), t['ra'].data_ptr(), t['dec'].data_ptr(), ln1pz_ptr=t['lnz'].data_ptr(), lnM_ptr=t['lnM'].data_ptr())
+    npix = 12 * nside * nside
+    d_map = torch.from_numpy(syn.make_map(nside)).to(dev)
+    ref = {}
+    for name, acc in (('parity', _lib.ACC_PARITY), ('f64', _lib.ACC_F64)):
+        off = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+        out = torch.zeros(npix, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.baryonify(cd, d_map.data_ptr(), off.data_ptr(), out.data_ptr(), sums.data_ptr(), acc_f64=acc)
+        torch.cuda.synchronize()
+        ref[name] = out.cpu().numpy()
+    assert np.abs(ref['parity'] - ref['f64']).max() <= 1e-8 * ref['f64'].mean() and np.abs(ref['f64'] - d_map.cpu().numpy()).max() > 0
+    first = plan.bands()
+    nb = len(first) - 1
+    cuts = [0, nb // 3, 2 * nb // 3, nb]
+    plan.set_band_reach(16)
+    got = np.zeros(npix)
+    foreign = torch.zeros(1, dtype=torch.int64, device=dev)
+    tot = np.zeros(2)
+    for q in range(3):
+        b0, b1 = cuts[q], cuts[q + 1]
+        B0, B1 = max(b0 - 1, 0), min(b1 + 1, nb)
+        wlo, whi, p0, p1 = int(first[B0]), int(first[B1]), int(first[b0]), int(first[b1])
+        full = torch.full(((whi - wlo) * 3,), np.nan, dtype=torch.float64, device=dev)                # 24 bytes per pixel: hi + lo halves
+        sl = torch.full((p1 - p0,), np.nan, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        plan.offsets_regrid_bands(cd, B0, B1, full.data_ptr(), b0, b1, d_map.data_ptr(), sl.data_ptr(), sums.data_ptr(), foreign.data_ptr(),
+                                  acc_f64=_lib.ACC_PARITY)
+        torch.cuda.synchronize()
+        plan.status()
+        got[p0:p1] = sl.cpu().numpy()
+        tot += sums.cpu().numpy()
+    plan.close()
+    assert np.isfinite(got).all()
+    if int(foreign.item()) == 0:            # (far deposits that leave a slice are the caller's to route: the polar halos here may produce a few)
+        assert np.abs(got - ref['parity']).max() <= 1e-9 * ref['parity'].mean(), np.abs(got - ref['parity']).max() / ref['parity'].mean()
+        assert abs(tot[1] - tot[0]) <= 1e-9 * tot[0]
+    else:
+        inside = np.abs(got - ref['parity']) <= 1e-9 * ref['parity'].mean()
+        assert (~inside).sum() <= 4 * int(foreign.item())
