@@ -293,3 +293,64 @@ def test_route_halos_gloo_every_halo_reaches_every_rank_it_touches(tmp_path):
         for j in range(world):
             want += int(((first < bounds[j + 1]) & (last >= bounds[j]) & (first <= last)).sum())
     assert total == want
+
+
+def _worker_overlapped_gather(rank, world, port, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from baryonification_amd.utils.Parallelize import gather_slices, gather_slices_start
+        pb = np.array([0, 700, 1500, 1501, 4000][:world + 1] if world == 4 else np.linspace(0, 3000, world + 1).astype(np.int64))
+        npix = int(pb[-1])
+        group = dist.new_group(backend='gloo')                         # the gathers travel on a communicator of their own
+        # bench.py's pattern: pass i computes into buffer pair i % 2 and starts its gather; the pair is written again only after that
+        # gather has been waited for; a fence waits for what is in flight.  Every pass's assembled map is checked.
+        slices = [torch.zeros(int(pb[rank + 1] - pb[rank]), dtype=torch.float64) for _ in (0, 1)]
+        fins = [torch.full((npix,), -1.0, dtype=torch.float64) if rank == 0 else None for _ in (0, 1)]
+        pending, seen = [None, None], []
+        for i in range(7):
+            k = i % 2
+            if pending[k] is not None:
+                pending[k][0].wait()
+                if rank == 0:
+                    seen.append((pending[k][1], fins[k].clone()))
+                pending[k] = None
+            val = torch.arange(int(pb[rank]), int(pb[rank + 1]), dtype=torch.float64) + 10000.0 * i
+            if rank == 0:
+                fins[k][int(pb[0]):int(pb[1])] = val                    # rank 0 regrids straight into the final map
+            else:
+                slices[k].copy_(val)
+            pending[k] = (gather_slices_start(slices[k], pb, npix, out=fins[k], group=group), i)
+            dist.all_reduce(torch.ones(1))                              # (the step's own collectives go on on the default group meanwhile)
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k][0].wait()
+                if rank == 0:
+                    seen.append((pending[k][1], fins[k].clone()))
+        if rank == 0:
+            assert sorted(i for i, _ in seen) == list(range(7))
+            for i, m in seen:
+                assert torch.equal(m, torch.arange(npix, dtype=torch.float64) + 10000.0 * i), i
+            # the in-line form gives the same map
+            full = torch.full((npix,), -1.0, dtype=torch.float64)
+            full[:int(pb[1])] = torch.arange(int(pb[1]), dtype=torch.float64)
+            gather_slices(slices[0], pb, npix, 'root', out=full, root_in_place=True)
+            np.save(out_path, np.array([1.0]))
+        else:
+            slices[0].copy_(torch.arange(int(pb[rank]), int(pb[rank + 1]), dtype=torch.float64))
+            gather_slices(slices[0], pb, npix, 'root', out=None, root_in_place=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_overlapped_gather_two_buffers_own_group(tmp_path, world):
+    """Parallelize.gather_slices_start: the slices of pass i travel to rank 0 asynchronously on a process group of their own while the ranks
+    go on (bench.py's N > 1 loop); with two buffer pairs and a wait before reuse every pass's map arrives whole (one rank owns a single pixel)"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / 'ok.npy')
+    mp.spawn(_worker_overlapped_gather, args=(world, port, out_path), nprocs=world, join=True)
+    assert os.path.exists(out_path)
