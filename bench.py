@@ -1196,7 +1196,7 @@ def roofline(args, kernels, n_pairs, nh, npix, paint, table=None, force=None, ac
     acc_b = 4 if acc == 0 else 8                 # (the parity-grade mode stores hi + lo: 8 bytes per component, like fp64)
     # K1 12 B/pair (24 B with fp64 accumulators) + 32 B/halo; K2 60 B per map pixel (3 acc + 8 + 4 x 8 + 8); K3 8 B/pair
     alg = {'offsets': n_pairs * 3 * acc_b + nh * 32, 'regrid': npix * (3 * acc_b + 8 + 4 * 8 + 8), 'paint': n_pairs * 8 + nh * 32 + npix * 8}
-    table = table or args.table
+    table = 'closed-form' if paint else (table or args.table)          # (painting has one synthetic table; --table is the displacement's)
     dom = force or ('paint' if paint else max(('offsets', 'regrid'), key=lambda k: kernels.get(k) or 0.0))
     real = 'float' if acc == 0 else 'double'
     areal = 'double' if acc == 1 else 'float'    # the type pix_offsets are stored in
