@@ -86,3 +86,20 @@ def test_null_arguments_are_refused_before_any_device_call():
     assert L.bfgx_grid_baryonify_device(None, None, None, None, None, C.byref(n)) == _lib.ERR_INVALID
     assert b'NULL' in L.bfgx_last_error()
     assert L.bfgx_power_spectrum_device(0, None, 64, None, 100.0, 10, None, None, None, None) == _lib.ERR_INVALID
+
+
+def test_round5_entries_refuse_bad_arguments_before_any_device_call():
+    """the entries added in round 5 (one-call snapshot -> map, per-halo callable bridge, fused band entry) check their arguments first"""
+    import ctypes as C
+    L = _lib.load()
+    n = C.c_int64(0)
+    h = C.c_void_p()
+    assert L.bfgx_shell_pairs_begin(None, None, 64, 0, 0, C.byref(h), None) == _lib.ERR_INVALID and not h.value
+    assert L.bfgx_shell_pairs_radii(None, None) == _lib.ERR_INVALID
+    assert L.bfgx_shell_pairs_apply(None, None, None, None, 1, None) == _lib.ERR_INVALID
+    L.bfgx_shell_pairs_end(None)                                                  # (a no-op)
+    assert L.bfgx_snapshot_displace_deposit_device(None, None, 0, None, None, None, None, 8, None, None, C.byref(n)) == _lib.ERR_INVALID
+    st = _lib.bfgx_stats()
+    assert L.bfgx_baryonify_snapshot_records_map(None, None, 3, 100.0, 0.0, 0, None, 32, 8, 16, 24, 0, 8, None, None, None, C.byref(st)) == _lib.ERR_INVALID
+    assert L.bfgx_offsets_regrid_bands_device(None, None, 0, 1, None, 0, 0, 1, None, None, None, None) == _lib.ERR_INVALID
+    assert b'NULL' in L.bfgx_last_error()
